@@ -1,0 +1,80 @@
+/* libtsasr_hip.so - C-ABI of the MI355X (gfx950) TS-ASR Conformer-Transducer hot path.
+ *
+ * The reference (lucadellalib/ts-asr) is 100 % Python: it has no FFI for this path. The boundary a
+ * maintainer binds is therefore the set of torch.nn.Module / loss callables the hparams YAML
+ * instantiates; every entry point below names the reference call it
+ * replaces (paths relative to the reference root; SB = vendor/speechbrain/speechbrain).
+ * The ctypes stubs a maintainer would add are in INTEGRATION.md; ts-asr_amd/_capi.py holds ours.
+ *
+ * Conventions
+ *   - plain pointers and sizes; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t; nothing allocates, nothing synchronises, nothing touches the
+ *     default stream: calls are graph-capturable and re-entrant per stream;
+ *   - scratch memory comes from the caller: `*_workspace_bytes()` says how much;
+ *   - return value: 0 = ok, <0 = error (TSASR_E_*); tsasr_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - io_dtype: TSASR_F32 (0) or TSASR_BF16 (1) = storage type of activations; contractions use
+ *     bf16 MFMA operands with fp32 accumulation, every reduction / softmax / LSE is fp32;
+ *   - lengths are ABSOLUTE int32 counts on the device (the host mirror converts the reference's
+ *     relative lengths with the reference's own rounding rule before the call).
+ */
+#ifndef TSASR_HIP_H
+#define TSASR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSASR_F32 0
+#define TSASR_BF16 1
+
+#define TSASR_E_INVALID (-1)  /* bad shape / unsupported size / null pointer */
+#define TSASR_E_LAUNCH (-2)   /* hipLaunch / runtime failure */
+#define TSASR_E_WORKSPACE (-3)
+
+const char *tsasr_last_error(void);
+int tsasr_version(void);
+/* 1 when a gfx950 device is current, 0 otherwise (no kernel is launched). */
+int tsasr_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * RNN-T joint + head  (replaces SB/nnet/transducer/transducer_joint.py:73-95 `Transducer_joint.forward`
+ * (joint="sum", LeakyReLU) followed by SB/nnet/linear.py:64-78 `Linear.forward` of `transducer_head`,
+ * call site train_librispeechmix_scratch.py:132-135) - the [B,T,U1,J] joint tensor is never materialised.
+ *   logits[b,t,u,v] = bias[v] + sum_k W[v,k] * lrelu(enc[b,t,k] + dec[b,u,k])      v < V <= 32
+ * logits rows are padded to `ldl` floats (ldl % 4 == 0, ldl >= V; columns >= V are written as 0).
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const float *bias, float *logits,
+                    int B, int T, int U1, int J, int V, int ldl, int io_dtype, float slope, void *stream);
+
+size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J);
+/* Backward of the above: denc[b,t,:], ddec[b,u,:] (io_dtype), dW[V,J], dbias[V] (fp32, OVERWRITTEN).
+ * tlen/ulen (may be NULL = full) let the kernel skip the part of the lattice whose dlogits are zero. */
+int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, const float *W,
+                    void *denc, void *ddec, float *dW, float *dbias,
+                    const int32_t *tlen, const int32_t *ulen,
+                    int B, int T, int U1, int J, int V, int ldl, int io_dtype, float slope,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RNN-T loss  (replaces SB/nnet/losses.py:29-87 `transducer_loss` -> torchaudio.functional.rnnt_loss,
+ * call site train_librispeechmix_scratch.py:158-160; lattice math as SB/nnet/loss/transducer_loss.py:60-236)
+ *   costs[b] = -log P(y_b | x_b)  (no /T), fused log-softmax over the V valid columns of each row.
+ * fwd keeps alpha/beta/lse in `workspace` (same pointer must be handed to bwd);
+ * bwd writes dlogits[b,t,u,v] = gscale[b] * d costs[b] / d logits  (zeros outside the lattice / v >= V).
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1);
+int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen,
+                        const int32_t *ulen, float *costs, int B, int T, int U1, int V, int ldl, int blank,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int tsasr_rnnt_loss_bwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen,
+                        const int32_t *ulen, const float *gscale /* [B] */, float *dlogits,
+                        int B, int T, int U1, int V, int ldl, int blank,
+                        const void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""ctypes binding of include/tsasr_hip.h  (the only door from Python into the HIP kernels).
+
+The library is loaded lazily so that host-only logic (YAML loader, Brain bookkeeping, gradient
+bucketing) can be imported and unit-tested in a container without a GPU; any attempt to *compute*
+without the library raises ``TsasrHipMissing`` - there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsasr_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class TsasrHipMissing(RuntimeError):
+    pass
+
+
+class TsasrHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tsasr_hip.h one to one
+_PROTOS = {
+    "tsasr_last_error": (ctypes.c_char_p, []),
+    "tsasr_version": (c_int, []),
+    "tsasr_device_ok": (c_int, []),
+    "tsasr_joint_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_float, c_void_p]),
+    "tsasr_joint_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
+    "tsasr_joint_bwd": (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
+    "tsasr_rnnt_loss_workspace_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_rnnt_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_rnnt_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """The loaded shared library; raises TsasrHipMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TsasrHipMissing(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or __graft_entry__.build()). ts-asr_amd has no CPU/ATen fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)  # AttributeError = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tsasr_last_error().decode(errors="replace")
+        raise TsasrHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def io_dtype(t):
+    import torch
+
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"ts-asr_amd kernels take float32 or bfloat16 activations, got {t.dtype}")
+
+
+def require_gpu(*tensors):
+    """Product ops never run on the CPU."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TsasrHipMissing("ts-asr_amd ops need tensors on an MI355X (cuda) device; there is no CPU path "
+                                  "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,653 @@
+// RNN-T joint + head + loss for gfx950 (MI355X).
+//
+// Replaces (reference paths; SB = vendor/speechbrain/speechbrain):
+//   SB/nnet/transducer/transducer_joint.py:73-95 + SB/nnet/linear.py:64-78   (joint "sum" + LeakyReLU + head)
+//   SB/nnet/losses.py:29-87 -> torchaudio.functional.rnnt_loss                (default loss path)
+//   SB/nnet/loss/transducer_loss.py:31-236                                    (the same lattice as Numba spin-lock kernels)
+//
+// Design (MI355X-first, not a translation of the Numba kernels):
+//   * joint_fwd: the [B,T,U1,J] joint tensor (2.48 GB fp32 in the reference) is never built. A workgroup owns
+//     (b, 32 lattice columns u); the dec tile and the head matrix live in LDS as bf16, each wave walks time
+//     frames, forms h = lrelu(enc[t]+dec[u]) in registers and feeds v_mfma_f32_32x32x16_bf16 with
+//     A = W (rows = vocabulary), B = h^T (cols = u) so that every lane ends up with 16 vocabulary entries
+//     of ONE lattice cell -> 16-byte row stores into logits rows padded to `ldl` floats.
+//   * loss: (1) rnnt_lp: fused log-softmax, 8 lanes per lattice cell, keeps only lse / lp(blank) / lp(label);
+//           (2) rnnt_alphabeta: ONE WAVE per (utterance, direction): lane l owns K consecutive columns, lanes
+//               are skewed by one time step, the neighbour's boundary value moves with a DPP wave shift ->
+//               no LDS, no barrier, no atomics (the reference serialises columns with an int32 spin-lock);
+//           (3) rnnt_grad: gradient w.r.t. logits (softmax * occupancy - transitions), written once.
+//   * joint_bwd: two deterministic kernels that both recompute dh = lrelu'(enc+dec) * (dlogits . W) on MFMA:
+//       X: workgroup (b, u-tile) walks t  -> ddec, head dW/dbias slabs (reduced by a tiny second kernel);
+//       Y: workgroup (b, 8 frames) walks u-tiles -> denc.  No float atomics anywhere => bitwise reproducible.
+#include "common.h"
+
+#define NEG_INF (-INFINITY)
+
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// ============================================================================================
+// joint forward
+// ============================================================================================
+// LDS row stride (in bf16) for a J-wide row: +8 elements (16 B) so that 16 consecutive rows start in
+// 16 different 16-byte slots of the 256-byte bank row (ds_read_b128 conflict-free; guide G4).
+__host__ __device__ static inline int lds_stride(int J) { return J + 8; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ enc, const T *__restrict__ dec,
+                                                        const float *__restrict__ W, const float *__restrict__ bias,
+                                                        float *__restrict__ logits, int Tn, int U1, int J, int V,
+                                                        int ldl, float slope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = lds_stride(J);
+    bf16_t *w_lds = reinterpret_cast<bf16_t *>(smem);  // [32][S]
+    bf16_t *d_lds = w_lds + 32 * S;                    // [32][S]
+    const int b = blockIdx.z, u0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // stage W (fp32 master -> bf16) and the dec tile
+    for (int i = tid; i < 32 * (J / 8); i += 256) {
+        const int row = i / (J / 8), c = (i % (J / 8)) * 8;
+        float w8[8];
+        if (row < V) ld8(W + (size_t)row * J + c, w8);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = 0.f;
+        }
+        st8(w_lds + row * S + c, w8);
+        float d8[8];
+        if (u0 + row < U1) ld8(dec + ((size_t)b * U1 + u0 + row) * J + c, d8);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d8[j] = 0.f;
+        }
+        st8(d_lds + row * S + c, d8);
+    }
+    __syncthreads();
+
+    // bias for this lane's 16 vocabulary rows
+    float bv[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int v = (g & 3) + 8 * (g >> 2) + 4 * h;
+        bv[g] = v < V ? bias[v] : 0.f;
+    }
+    const int tchunk = cdiv_dev(Tn, (int)gridDim.y);
+    const int t_begin = blockIdx.y * tchunk, t_end = min(Tn, t_begin + tchunk);
+    const bf16_t *wrow = w_lds + r * S + 8 * h;
+    const bf16_t *drow = d_lds + r * S + 8 * h;
+    const int nks = J / 16;
+    for (int t = t_begin + wave; t < t_end; t += 4) {
+        const T *erow = enc + ((size_t)b * Tn + t) * J + 8 * h;
+        f32x16 acc = {0};
+#pragma unroll 4
+        for (int s = 0; s < nks; ++s) {
+            float e8[8], d8[8];
+            ld8(erow + 16 * s, e8);
+            ld8(drow + 16 * s, d8);
+            bf16x8 hb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hb[j] = (bf16_t)lrelu(e8[j] + d8[j], slope);
+            const bf16x8 wa = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hb, acc, 0, 0, 0);
+        }
+        if (u0 + r < U1) {
+            float *orow = logits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // vocabulary rows 8q+4h .. 8q+4h+3 -> one 16-byte store
+                const int v0 = 8 * q + 4 * h;
+                if (v0 < ldl) {
+                    float4 o;
+                    o.x = (v0 + 0 < V) ? acc[4 * q + 0] + bv[4 * q + 0] : 0.f;
+                    o.y = (v0 + 1 < V) ? acc[4 * q + 1] + bv[4 * q + 1] : 0.f;
+                    o.z = (v0 + 2 < V) ? acc[4 * q + 2] + bv[4 * q + 2] : 0.f;
+                    o.w = (v0 + 3 < V) ? acc[4 * q + 3] + bv[4 * q + 3] : 0.f;
+                    *reinterpret_cast<float4 *>(orow + v0) = o;
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// joint backward: shared "masked dh tile" machinery
+// ============================================================================================
+#define KB 3  // 32-wide k-blocks per wave
+
+struct BwdFrags {
+    bf16x8 wf[KB][2];  // B operand of D = dlogits . W : W[v = 16s+8h+j][k_r + 32 kb]
+    int kb[KB];        // global k-block index or -1
+};
+
+__device__ __forceinline__ void load_w_frags(BwdFrags &f, const float *__restrict__ W, int J, int V, int wslot,
+                                             int nslots, int r, int h) {
+    const int nkb = J / 32;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        const int kb = wslot + i * nslots;
+        f.kb[i] = kb < nkb ? kb : -1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = 16 * s + 8 * h + j;
+                f.wf[i][s][j] = (bf16_t)((kb < nkb && v < V) ? W[(size_t)v * J + kb * 32 + r] : 0.f);
+            }
+    }
+}
+
+// A operand: dlogits[u_r][16s+8h+j] (fp32 -> bf16); rows beyond U1 read as zero
+__device__ __forceinline__ void load_a_frags(const float *__restrict__ dl_row, bool valid, int ldl, int h,
+                                             bf16x8 (&a)[2], float (&af)[2][8]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int v0 = 16 * s + 8 * h;
+        if (valid && v0 + 8 <= ldl) ld8(dl_row + v0, af[s]);
+        else if (valid && v0 + 4 <= ldl) {
+            const float4 x = *reinterpret_cast<const float4 *>(dl_row + v0);
+            af[s][0] = x.x; af[s][1] = x.y; af[s][2] = x.z; af[s][3] = x.w;
+            af[s][4] = af[s][5] = af[s][6] = af[s][7] = 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[s][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[s][j] = (bf16_t)af[s][j];
+    }
+}
+
+// u index (within the 32-row tile) of accumulator register g for lane half h (32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// ---- X: ddec + head-weight slabs ------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
+    const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
+    const float *__restrict__ W, T *__restrict__ ddec, float *__restrict__ slab_w /*[B*nut][32][J]*/,
+    float *__restrict__ slab_b /*[B*nut][32]*/, const int32_t *__restrict__ tlen, const int32_t *__restrict__ ulen,
+    int Tn, int U1, int J, int V, int ldl, float slope) {
+    __shared__ __attribute__((aligned(16))) bf16_t a_lds[4][32 * 32];  // per-wave dlogits tile [u][v]
+    const int b = blockIdx.z, ut = blockIdx.x, u0 = ut * 32, nut = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int nslots = gridDim.y * 4, wslot = blockIdx.y * 4 + wave;
+    const int Tb = tlen ? min(max(tlen[b], 1), Tn) : Tn;
+    const int Ub = ulen ? min(max(ulen[b], 0), U1 - 1) : U1 - 1;
+    const int t_end = (u0 <= Ub) ? Tb : 0;  // tile entirely outside the lattice -> dlogits are zero
+
+    BwdFrags f;
+    load_w_frags(f, W, J, V, wslot, nslots, r, h);
+    float dv[KB][16], dacc[KB][16];
+    f32x16 wacc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        wacc[i] = (f32x16){0};
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int u = u0 + acc_row(g, h);
+            dv[i][g] = (f.kb[i] >= 0 && u < U1) ? ld1(dec + ((size_t)b * U1 + u) * J + f.kb[i] * 32 + r) : 0.f;
+            dacc[i][g] = 0.f;
+        }
+    }
+    float bsum[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[s][j] = 0.f;
+
+    bf16_t *my_lds = a_lds[wave];
+    const bool row_ok = (u0 + r) < U1;
+    for (int t = 0; t < t_end; ++t) {
+        bf16x8 a[2];
+        float af[2][8];
+        load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[s][j] += af[s][j];
+            *reinterpret_cast<bf16x8 *>(my_lds + r * 32 + 16 * s + 8 * h) = a[s];
+        }
+        __builtin_amdgcn_wave_barrier();  // same-wave LDS write -> read (DS ops retire in order)
+        // A' operand of dW = dlogits^T . H : rows = v_r, inner index i <-> u = 16s + 8(j>>2) + 4h + (j&3)
+        bf16x8 at[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) at[s][j] = my_lds[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (f.kb[i] < 0) continue;
+            const float e = ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r);
+            f32x16 D = {0};
+            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
+            bf16x8 hb[2];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float x = e + dv[i][g];
+                dacc[i][g] += (x > 0.f) ? D[g] : slope * D[g];
+                hb[g >> 3][g & 7] = (bf16_t)lrelu(x, slope);
+            }
+            wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], hb[0], wacc[i], 0, 0, 0);
+            wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], hb[1], wacc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        if (f.kb[i] < 0) continue;
+        const int k = f.kb[i] * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int u = u0 + acc_row(g, h);
+            if (u < U1) st1(ddec + ((size_t)b * U1 + u) * J + k, dacc[i][g]);
+            slab_w[((size_t)(b * nut + ut) * 32 + acc_row(g, h)) * J + k] = wacc[i][g];
+        }
+    }
+    if (wslot == 0) {  // dbias partial: sum over the 32 lanes (u) that share h
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = bsum[s][j];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                if (r == 0) slab_b[(size_t)(b * nut + ut) * 32 + 16 * s + 8 * h + j] = x;
+            }
+    }
+}
+
+// ---- Y: denc -----------------------------------------------------------------------------------
+#define TG 8
+template <typename T>
+__global__ __launch_bounds__(256, 1) void joint_bwd_y_kernel(
+    const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
+    const float *__restrict__ W, T *__restrict__ denc, const int32_t *__restrict__ tlen,
+    const int32_t *__restrict__ ulen, int Tn, int U1, int J, int V, int ldl, float slope) {
+    const int b = blockIdx.z, t0 = blockIdx.x * TG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int nslots = gridDim.y * 4, wslot = blockIdx.y * 4 + wave;
+    const int Tb = tlen ? min(max(tlen[b], 1), Tn) : Tn;
+    const int Ub = ulen ? min(max(ulen[b], 0), U1 - 1) : U1 - 1;
+    BwdFrags f;
+    load_w_frags(f, W, J, V, wslot, nslots, r, h);
+    float eacc[TG][KB];
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+        for (int i = 0; i < KB; ++i) eacc[tt][i] = 0.f;
+    const int nt = max(0, min(TG, Tb - t0));
+    if (nt > 0) {
+        for (int u0 = 0; u0 <= Ub; u0 += 32) {
+            float dv[KB][16];
+#pragma unroll
+            for (int i = 0; i < KB; ++i)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int u = u0 + acc_row(g, h);
+                    dv[i][g] = (f.kb[i] >= 0 && u < U1) ? ld1(dec + ((size_t)b * U1 + u) * J + f.kb[i] * 32 + r) : 0.f;
+                }
+            const bool row_ok = (u0 + r) < U1;
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) {
+                if (tt >= nt) continue;
+                const int t = t0 + tt;
+                bf16x8 a[2];
+                float af[2][8];
+                load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+#pragma unroll
+                for (int i = 0; i < KB; ++i) {
+                    if (f.kb[i] < 0) continue;
+                    const float e = ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r);
+                    f32x16 D = {0};
+                    D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
+                    D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sacc += ((e + dv[i][g]) > 0.f) ? D[g] : slope * D[g];
+                    eacc[tt][i] += sacc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+        const int t = t0 + tt;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float x = eacc[tt][i] + __shfl_xor(eacc[tt][i], 32, 64);  // the two lane halves hold different u rows
+            if (t < Tn && f.kb[i] >= 0 && h == 0) st1(denc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r, x);
+        }
+    }
+}
+
+__global__ void joint_bwd_reduce_kernel(const float *__restrict__ slab_w, const float *__restrict__ slab_b,
+                                        float *__restrict__ dW, float *__restrict__ dbias, int nslab, int J, int V) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V * J) {
+        const int v = i / J, k = i % J;
+        float s = 0.f;
+        for (int n = 0; n < nslab; ++n) s += slab_w[((size_t)n * 32 + v) * J + k];
+        dW[i] = s;
+    }
+    if (i < V) {
+        float s = 0.f;
+        for (int n = 0; n < nslab; ++n) s += slab_b[(size_t)n * 32 + i];
+        dbias[i] = s;
+    }
+}
+
+// ============================================================================================
+// loss
+// ============================================================================================
+struct RnntWs {
+    float *lpb, *lpe_in, *lpe_out, *alpha, *beta, *lse, *logp;
+    int U1P, K;
+};
+
+static int rnnt_K(int U1) {
+    int K = 1;
+    while (64 * K < U1) K *= 2;
+    return K;
+}
+
+static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
+    RnntWs w;
+    w.K = rnnt_K(U1);
+    w.U1P = 64 * w.K;
+    const size_t n = (size_t)B * T * w.U1P;
+    float *p = reinterpret_cast<float *>(ws);
+    w.lpb = p; w.lpe_in = p + n; w.lpe_out = p + 2 * n; w.alpha = p + 3 * n; w.beta = p + 4 * n; w.lse = p + 5 * n;
+    w.logp = p + 6 * n;
+    return w;
+}
+
+__device__ __forceinline__ float logaddexp_f(float a, float b) {
+    const float m = fmaxf(a, b);
+    const float d = fminf(a, b) - m;  // <= 0, or NaN when both are -inf
+    return (m == NEG_INF) ? NEG_INF : m + __logf(1.f + __expf(d));
+}
+
+// (1) fused log-softmax per lattice cell: 8 lanes per cell, float4 per lane and chunk
+__global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ logits, const int32_t *__restrict__ targets,
+                                                      int ldt, const int32_t *__restrict__ tlen,
+                                                      const int32_t *__restrict__ ulen, RnntWs w, int B, int Tn, int U1,
+                                                      int V, int ldl, int blank) {
+    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    if (row >= (long long)B * Tn * U1) return;  // whole 8-lane groups leave together
+    const int u = row % U1, t = (row / U1) % Tn, b = row / ((long long)U1 * Tn);
+    const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
+    if (t >= Tb || u > Ub) return;
+    const float *rowp = logits + row * ldl;
+    float m = NEG_INF;
+    for (int c = sub * 4; c < V; c += 32) {
+        const float4 x = *reinterpret_cast<const float4 *>(rowp + c);
+        m = fmaxf(m, x.x);
+        if (c + 1 < V) m = fmaxf(m, x.y);
+        if (c + 2 < V) m = fmaxf(m, x.z);
+        if (c + 3 < V) m = fmaxf(m, x.w);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int c = sub * 4; c < V; c += 32) {
+        const float4 x = *reinterpret_cast<const float4 *>(rowp + c);
+        s += __expf(x.x - m);
+        if (c + 1 < V) s += __expf(x.y - m);
+        if (c + 2 < V) s += __expf(x.z - m);
+        if (c + 3 < V) s += __expf(x.w - m);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) {
+        const float lse = m + __logf(s);
+        const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+        w.lse[o] = lse;
+        w.lpb[o] = rowp[blank] - lse;
+        if (u < Ub) {
+            const float e = rowp[min(max(targets[(size_t)b * ldt + u], 0), V - 1)] - lse;
+            w.lpe_out[o] = e;
+            w.lpe_in[o + 1] = e;
+        }
+    }
+}
+
+// (2) alpha / beta: one wave per (utterance, direction). blockIdx.x = 2b + dir.
+template <int K>
+__global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int32_t *__restrict__ tlen,
+                                                            const int32_t *__restrict__ ulen, float *__restrict__ costs,
+                                                            int Tn, int U1) {
+    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1, l = threadIdx.x;
+    const int U1P = w.U1P;
+    const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
+    const size_t base = (size_t)b * Tn * U1P + (size_t)K * l;
+    const int nsteps = Tb + 63;
+    float prev[K], cur[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) prev[i] = NEG_INF;
+    float edge = NEG_INF;  // boundary value handed to the neighbour lane
+    if (dir == 0) {
+        for (int s = 0; s < nsteps; ++s) {
+            const int t = s - l;
+            const float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            if (t >= 0 && t < Tb) {
+                const float *pb = w.lpb + base + (size_t)(t > 0 ? t - 1 : 0) * U1P;
+                const float *pe = w.lpe_in + base + (size_t)t * U1P;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const int u = K * l + i;
+                    const float noemit = (t > 0) ? prev[i] + pb[i] : NEG_INF;
+                    const float lft = (i == 0) ? left : cur[i > 0 ? i - 1 : 0];
+                    const float emit = (u > 0) ? lft + pe[i] : NEG_INF;
+                    float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
+                    if (u > Ub) a = NEG_INF;
+                    cur[i] = a;
+                }
+                float *pa = w.alpha + base + (size_t)t * U1P;
+#pragma unroll
+                for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
+                edge = cur[K - 1];
+                if (t == Tb - 1) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i)
+                        if (K * l + i == Ub) {
+                            const float lp = cur[i] + w.lpb[base + (size_t)t * U1P + i];
+                            w.logp[b] = lp;
+                            costs[b] = -lp;
+                        }
+                }
+            }
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) {
+            const int t = Tb - 1 - (s - (63 - l));
+            const float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (t >= 0 && t < Tb) {
+                const float *pb = w.lpb + base + (size_t)t * U1P;
+                const float *pe = w.lpe_out + base + (size_t)t * U1P;
+#pragma unroll
+                for (int i = K - 1; i >= 0; --i) {
+                    const int u = K * l + i;
+                    const float lb = pb[i];
+                    const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
+                    const float rgt = (i == K - 1) ? right : cur[i < K - 1 ? i + 1 : K - 1];
+                    const float emit = (u < Ub) ? rgt + pe[i] : NEG_INF;
+                    float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
+                    if (u > Ub) v = NEG_INF;
+                    cur[i] = v;
+                }
+                float *pbeta = w.beta + base + (size_t)t * U1P;
+#pragma unroll
+                for (int i = 0; i < K; ++i) { pbeta[i] = cur[i]; prev[i] = cur[i]; }
+                edge = cur[0];
+            }
+        }
+    }
+}
+
+// (3) gradient w.r.t. logits; covers EVERY row of dlogits (zeros outside the lattice)
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict__ logits, const int32_t *__restrict__ targets,
+                                                        int ldt, const int32_t *__restrict__ tlen,
+                                                        const int32_t *__restrict__ ulen, const float *__restrict__ gscale,
+                                                        float *__restrict__ dlogits, RnntWs w, int B, int Tn, int U1, int V,
+                                                        int ldl, int blank) {
+    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    if (row >= (long long)B * Tn * U1) return;
+    const int u = row % U1, t = (row / U1) % Tn, b = row / ((long long)U1 * Tn);
+    const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
+    float *orow = dlogits + row * ldl;
+    if (t >= Tb || u > Ub) {
+        for (int c = sub * 4; c < ldl; c += 32) *reinterpret_cast<float4 *>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+    const float logp = w.logp[b], a = w.alpha[o], be = w.beta[o], lse = w.lse[o], lpb = w.lpb[o];
+    const float gs = gscale[b];
+    const float c0 = a + be - logp - lse;
+    float gblank;
+    if (t < Tb - 1) gblank = __expf(a + lpb + w.beta[o + w.U1P] - logp);
+    else gblank = (u == Ub) ? __expf(a + lpb - logp) : 0.f;
+    int lab = -1;
+    float gemit = 0.f;
+    if (u < Ub) {
+        lab = min(max(targets[(size_t)b * ldt + u], 0), V - 1);
+        gemit = __expf(a + w.lpe_out[o] + w.beta[o + 1] - logp);
+    }
+    const float *rowp = logits + row * ldl;
+    for (int c = sub * 4; c < ldl; c += 32) {
+        const float4 x = *reinterpret_cast<const float4 *>(rowp + c);
+        float g[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = c + j;
+            float val = 0.f;
+            if (v < V) {
+                val = __expf(c0 + g[j]);
+                if (v == blank) val -= gblank;
+                if (v == lab) val -= gemit;
+            }
+            g[j] = val * gs;
+        }
+        *reinterpret_cast<float4 *>(orow + c) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+template <int K>
+static void launch_ab(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
+    rnnt_alphabeta_kernel<K><<<2 * B, 64, 0, st>>>(w, tlen, ulen, costs, T, U1);
+}
+
+// ============================================================================================
+// C-ABI
+// ============================================================================================
+extern "C" {
+
+int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const float *bias, float *logits, int B, int T,
+                    int U1, int J, int V, int ldl, int io_dtype, float slope, void *stream) {
+    TSASR_CHECK_ARG(enc && dec && W && bias && logits, "tsasr_joint_fwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && U1 > 0, "tsasr_joint_fwd: empty batch (B=%d T=%d U1=%d)", B, T, U1);
+    TSASR_CHECK_ARG(J > 0 && J % 16 == 0, "tsasr_joint_fwd: J=%d must be a multiple of 16", J);
+    TSASR_CHECK_ARG(V > 0 && V <= 32, "tsasr_joint_fwd: V=%d not supported (1..32)", V);
+    TSASR_CHECK_ARG(ldl >= V && ldl % 4 == 0 && ldl <= 32, "tsasr_joint_fwd: ldl=%d must be a multiple of 4 in [V,32]", ldl);
+    const size_t lds = (size_t)2 * 32 * lds_stride(J) * sizeof(bf16_t);
+    TSASR_CHECK_ARG(lds <= 160 * 1024, "tsasr_joint_fwd: J=%d needs %zu B of LDS (>160 KiB)", J, lds);
+    const int nut = cdiv(U1, 32);
+    int tsplit = 1;  // enough workgroups to cover 256 CUs twice, at least 8 frames per wave
+    while (nut * B * tsplit < 512 && T / (tsplit * 2) >= 32) tsplit *= 2;
+    dim3 grid(nut, tsplit, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void *)joint_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        joint_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)enc, (const float *)dec, W, bias, logits, T, U1, J, V, ldl, slope);
+    } else if (io_dtype == TSASR_BF16) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void *)joint_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        joint_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, J, V, ldl, slope);
+    } else {
+        TSASR_CHECK_ARG(false, "tsasr_joint_fwd: bad io_dtype %d", io_dtype);
+    }
+    TSASR_CHECK_LAUNCH("tsasr_joint_fwd");
+    return 0;
+}
+
+size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J) {
+    (void)T;
+    const size_t nslab = (size_t)B * cdiv(U1, 32);
+    return align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256);
+}
+
+int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, const float *W, void *denc, void *ddec,
+                    float *dW, float *dbias, const int32_t *tlen, const int32_t *ulen, int B, int T, int U1, int J, int V,
+                    int ldl, int io_dtype, float slope, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dlogits && enc && dec && W && denc && ddec && dW && dbias && workspace, "tsasr_joint_bwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && U1 > 0, "tsasr_joint_bwd: empty batch");
+    TSASR_CHECK_ARG(J > 0 && J % 32 == 0, "tsasr_joint_bwd: J=%d must be a multiple of 32", J);
+    TSASR_CHECK_ARG(V > 0 && V <= 32 && ldl >= V && ldl % 4 == 0 && ldl <= 32, "tsasr_joint_bwd: V=%d ldl=%d unsupported", V, ldl);
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_joint_bwd_workspace_bytes(B, T, U1, J), "tsasr_joint_bwd: workspace too small");
+    const int nut = cdiv(U1, 32), nkb = J / 32;
+    const int ksplit = cdiv(nkb, 4 * KB);
+    const size_t nslab = (size_t)B * nut;
+    float *slab_w = (float *)workspace;
+    float *slab_b = (float *)((char *)workspace + align_up(nslab * 32 * J * sizeof(float), 256));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gx(nut, ksplit, B), gy(cdiv(T, TG), ksplit, B);
+    if (io_dtype == TSASR_F32) {
+        joint_bwd_x_kernel<float><<<gx, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope);
+        joint_bwd_y_kernel<float><<<gy, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+    } else if (io_dtype == TSASR_BF16) {
+        joint_bwd_x_kernel<bf16_t><<<gx, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope);
+        joint_bwd_y_kernel<bf16_t><<<gy, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+    } else {
+        TSASR_CHECK_ARG(false, "tsasr_joint_bwd: bad io_dtype %d", io_dtype);
+    }
+    joint_bwd_reduce_kernel<<<cdiv(V * J, 256), 256, 0, st>>>(slab_w, slab_b, dW, dbias, (int)nslab, J, V);
+    TSASR_CHECK_LAUNCH("tsasr_joint_bwd");
+    return 0;
+}
+
+size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1) {
+    if (B <= 0 || T <= 0 || U1 <= 0) return 0;
+    const size_t n = (size_t)B * T * 64 * rnnt_K(U1);
+    return align_up((6 * n + (size_t)B) * sizeof(float), 256);
+}
+
+int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen, const int32_t *ulen,
+                        float *costs, int B, int T, int U1, int V, int ldl, int blank, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(logits && targets && tlen && ulen && costs && workspace, "tsasr_rnnt_loss_fwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && U1 > 0, "tsasr_rnnt_loss_fwd: empty batch (B=%d T=%d U1=%d)", B, T, U1);
+    TSASR_CHECK_ARG(V > 0 && ldl >= V && ldl % 4 == 0, "tsasr_rnnt_loss_fwd: rows must be padded to a multiple of 4 floats (V=%d ldl=%d)", V, ldl);
+    TSASR_CHECK_ARG(blank >= 0 && blank < V, "tsasr_rnnt_loss_fwd: blank=%d outside [0,%d)", blank, V);
+    TSASR_CHECK_ARG(U1 <= 64 * 32, "tsasr_rnnt_loss_fwd: U1=%d > 2048 lattice columns not supported", U1);
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_rnnt_loss_workspace_bytes(B, T, U1), "tsasr_rnnt_loss_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    RnntWs w = rnnt_carve(workspace, B, T, U1);
+    const long long rows = (long long)B * T * U1;
+    rnnt_lp_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(logits, targets, ldt, tlen, ulen, w, B, T, U1, V, ldl, blank);
+    switch (w.K) {
+        case 1: launch_ab<1>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 2: launch_ab<2>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 4: launch_ab<4>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 8: launch_ab<8>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 16: launch_ab<16>(w, tlen, ulen, costs, B, T, U1, st); break;
+        default: launch_ab<32>(w, tlen, ulen, costs, B, T, U1, st); break;
+    }
+    TSASR_CHECK_LAUNCH("tsasr_rnnt_loss_fwd");
+    return 0;
+}
+
+int tsasr_rnnt_loss_bwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen, const int32_t *ulen,
+                        const float *gscale, float *dlogits, int B, int T, int U1, int V, int ldl, int blank,
+                        const void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(logits && targets && tlen && ulen && gscale && dlogits && workspace, "tsasr_rnnt_loss_bwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && V > 0 && ldl >= V && ldl % 4 == 0, "tsasr_rnnt_loss_bwd: bad shape");
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_rnnt_loss_workspace_bytes(B, T, U1), "tsasr_rnnt_loss_bwd: workspace too small");
+    RnntWs w = rnnt_carve(const_cast<void *>(workspace), B, T, U1);
+    const long long rows = (long long)B * T * U1;
+    rnnt_grad_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, (hipStream_t)stream>>>(logits, targets, ldt, tlen, ulen, gscale, dlogits, w, B, T, U1, V, ldl, blank);
+    TSASR_CHECK_LAUNCH("tsasr_rnnt_loss_bwd");
+    return 0;
+}
+
+}  // extern "C"
