@@ -1,0 +1,122 @@
+"""ConformerEncoder with speaker-embedding injection: host mirror of /root/reference models/conformer.py:31-288.
+
+Same constructor arguments, forward signature, state_dict keys (``custom_src_module.layers.0.w.*``, ``layers.N.*``,
+``norm.norm.*``, ``cat_proj.w.*`` / ``speaker_attn.att.*``, buffer ``positional_encoding.inv_freq``) and the same
+xavier_normal_ re-initialisation of every >1-D parameter (models/conformer.py:284-287).
+Differences underneath: padding is carried as int32 valid lengths on the device (no ``length_to_mask(..).max().item()``
+host sync, SB/dataio/dataio.py:791), the ``cat`` injection never builds the [B,T,2D] concatenation
+(cat_proj(cat[src, spk]) == src.W1^T + (spk.W2^T + b) broadcast over time).
+"""
+from typing import List, Optional, Union
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _capi as C
+from . import ops
+from .nnet import ConformerEncoderLayer, LayerNorm, Linear, RelPosEncXL, _cd, abs_lengths_round
+
+__all__ = ["ConformerEncoder"]
+
+
+class _SrcModule(nn.Module):
+    """state_dict-compatible stand-in for speechbrain's ModuleList(Linear, Dropout) (keys ``layers.0.w.*``)."""
+
+    def __init__(self, input_size, d_model, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([Linear(input_size=input_size, n_neurons=d_model, bias=True, combine_dims=False), nn.Dropout(dropout)])
+
+    def forward(self, x):
+        return self.layers[1](self.layers[0](x))
+
+
+class _SpeakerAttention(nn.Module):
+    """Holder for ``speaker_attn.att.*`` (torch.nn.MultiheadAttention parameters) - cross_attention injection."""
+
+    def __init__(self, nhead, d_model, dropout, bias):
+        super().__init__()
+        self.att = nn.MultiheadAttention(embed_dim=d_model, num_heads=nhead, dropout=dropout, bias=bias)
+        self.nhead, self.dropout = nhead, dropout
+
+    def forward(self, src, spk, key_lens):
+        B, T, D = src.shape
+        S, H = spk.shape[1], self.nhead
+        w, b = self.att.in_proj_weight, self.att.in_proj_bias
+        q = ops.linear(src, w[:D], b[:D]).view(B, T, H, D // H).transpose(1, 2)
+        kv = ops.linear(_cd(spk), w[D:], b[D:]).view(B, S, 2, H, D // H)
+        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+        s = torch.matmul(q, k.transpose(-1, -2)).float() / (D // H) ** 0.5
+        if key_lens is not None:
+            s = s.masked_fill((torch.arange(S, device=src.device)[None, :] >= key_lens[:, None]).view(B, 1, 1, S), float("-inf"))
+        p = F.dropout(torch.softmax(s, -1), self.dropout, self.training).to(v.dtype)
+        o = torch.matmul(p, v).transpose(1, 2).reshape(B, T, D)
+        return ops.linear(o, self.att.out_proj.weight, self.att.out_proj.bias)
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, input_size, d_model=512, nhead=8, num_layers=6, d_ffn=2048, dropout=0.0, activation=nn.ReLU,
+                 positional_encoding="fixed_abs_sine", kernel_size=31, bias=True, attention_type="RelPosMHAXL",
+                 max_length=2500, causal=False, injection_mode: "Optional[str]" = "prod",
+                 injection_after: "Union[int, List[int]]" = 0):
+        super().__init__()
+        if attention_type != "RelPosMHAXL":
+            raise NotImplementedError("attention_type must be RelPosMHAXL on this path")
+        self.input_size, self.d_model, self.nhead, self.num_layers = input_size, d_model, nhead, num_layers
+        self.d_ffn, self.dropout, self.kernel_size, self.causal = d_ffn, dropout, kernel_size, causal
+        self.injection_mode = injection_mode
+        self.injection_after = list(injection_after) if isinstance(injection_after, (list, tuple)) else [injection_after]
+        self.positional_encoding = RelPosEncXL(d_model)
+        self.custom_src_module = _SrcModule(input_size, d_model, dropout)
+        self.layers = nn.ModuleList([
+            ConformerEncoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, dropout=dropout, activation=activation,
+                                  kernel_size=kernel_size, bias=bias, causal=causal, attention_type=attention_type)
+            for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model, eps=1e-6)
+        if injection_mode == "cat":
+            self.cat_proj = Linear(input_size=2 * d_model, n_neurons=d_model, bias=True)
+        elif injection_mode == "cross_attention":
+            self.speaker_attn = _SpeakerAttention(nhead, d_model, dropout, bias)
+        elif injection_mode not in ("prod", "sum", None):
+            raise NotImplementedError(injection_mode)
+        for p in self.parameters():  # models/conformer.py:284-287
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+
+    def forward(self, src, wav_len=None, speaker_embs=None, speaker_embs_length=None, return_attn=False):
+        C.require_gpu(src)
+        if src.ndim == 4:
+            b, t, c1, c2 = src.shape
+            src = src.reshape(b, t, c1 * c2)
+        T = src.shape[1]
+        valid = abs_lengths_round(wav_len, T) if wav_len is not None else None
+        x = self.custom_src_module(_cd(src))
+        if -1 in self.injection_after and speaker_embs is not None:
+            x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
+        pos = self.positional_encoding(x)
+        attns = []
+        for i, layer in enumerate(self.layers):
+            x, attn = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn)
+            if return_attn:
+                attns.append(attn.detach())
+            if i in self.injection_after and speaker_embs is not None:
+                x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
+        x = self.norm(x)
+        return (x, attns) if return_attn else x
+
+    def _inject_speaker_emb(self, src, spk, spk_len):
+        spk = _cd(spk)
+        if self.injection_mode == "prod":
+            return src * spk
+        if self.injection_mode == "sum":
+            return src + spk
+        if self.injection_mode == "cat":
+            D = self.d_model
+            w, b = self.cat_proj.w.weight, self.cat_proj.w.bias
+            return ops.linear(src, w[:, :D], None) + ops.linear(spk, w[:, D:], b)  # [B,T,D] + [B,1,D]
+        if self.injection_mode == "cross_attention":
+            klen = abs_lengths_round(spk_len, spk.shape[-2]) if spk_len is not None else None
+            return self.speaker_attn(src, spk, klen)
+        if self.injection_mode is None:
+            return src
+        raise NotImplementedError

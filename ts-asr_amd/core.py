@@ -1,0 +1,284 @@
+"""Training runtime with the ``speechbrain.Brain`` surface the TS-ASR recipes program against
+(vendor/speechbrain/speechbrain/core.py:537-1643): ``Brain(modules, opt_class, hparams, run_opts, checkpointer)``,
+``compute_forward`` / ``compute_objectives`` overrides, ``fit_batch`` / ``evaluate_batch`` / ``fit`` / ``evaluate``,
+``on_stage_start/end``, ``on_fit_batch_end``, ``no_sync``; ``Stage``; ``parse_arguments``.
+
+What is different underneath (MI355X-first):
+  * one process per GPU; gradients of ALL modules live in one flat arena that is all-reduced in a few large
+    buckets over RCCL/xGMI while backward is still running (dp.GradArena) - the reference wraps each of its
+    9 trainable modules in its own DistributedDataParallel reducer (core.py:1464-1484);
+  * no host synchronisation inside the step: the loss, the gradient norm and the non-finite check stay on the
+    device (the reference does loss.detach().cpu() and grad_norm.item() every micro-batch, core.py:1086,1096);
+    ``fit_batch`` returns a device scalar, and the non-finite counter is read back once per ``fit`` epoch/flush;
+  * gradient clipping + AdamW run as one pass over the arena (optim.FusedClipAdamW) when opt_class is the
+    reference's torch.optim.AdamW partial; any other optimizer class is used as given.
+"""
+import argparse
+import contextlib
+import enum
+import logging
+import os
+import sys
+
+import torch
+
+from . import dp as _dp
+from . import optim as _optim
+
+logger = logging.getLogger(__name__)
+
+
+class Stage(enum.Enum):
+    TRAIN = enum.auto()
+    VALID = enum.auto()
+    TEST = enum.auto()
+
+
+class EpochCounter:
+    """speechbrain/utils/epoch_loop.py:17-60."""
+
+    def __init__(self, limit):
+        self.current, self.limit = 0, int(limit)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.current < self.limit:
+            self.current += 1
+            return self.current
+        raise StopIteration
+
+
+class NoamScheduler:
+    """speechbrain/nnet/schedulers.py:363-455: lr = lr0 * sqrt(W) * min(n^-0.5, n * W^-1.5)."""
+
+    def __init__(self, lr_initial, n_warmup_steps, model_size=None):
+        self.lr_initial, self.n_warmup_steps = lr_initial, n_warmup_steps
+        self.current_lr, self.losses, self.n_steps = lr_initial, [], 0
+        self.normalize = n_warmup_steps ** 0.5
+        if model_size is not None:
+            self.normalize = model_size ** (-0.5)
+
+    def __call__(self, opt):
+        self.n_steps += 1
+        current_lr = opt.param_groups[0]["lr"]
+        lr = self.lr_initial * self._get_lr_scale()
+        for group in opt.param_groups:
+            group["lr"] = lr
+        self.current_lr = current_lr
+        return current_lr, lr
+
+    def _get_lr_scale(self):
+        n, w = self.n_steps, self.n_warmup_steps
+        return self.normalize * min(n ** (-0.5), n * w ** (-1.5))
+
+
+RUN_OPT_DEFAULTS = {
+    "debug": False, "device": "cuda:0", "distributed_launch": False, "distributed_backend": "nccl",
+    "find_unused_parameters": False, "auto_mix_prec": False, "bfloat16_mix_prec": False, "max_grad_norm": 5.0,
+    "nonfinite_patience": 3, "noprogressbar": True, "ckpt_interval_minutes": 0, "grad_accumulation_factor": 1,
+    "optimizer_step_limit": None, "compute_dtype": None,
+}
+
+
+def parse_arguments(arg_list=None):
+    """(hparams_file, run_opts, overrides) like speechbrain.core.parse_arguments (core.py:134-393): known run options
+    become ``run_opts``; every other ``--key value`` becomes a YAML override. LOCAL_RANK rewrites ``device``."""
+    arg_list = list(sys.argv[1:] if arg_list is None else arg_list)
+    p = argparse.ArgumentParser(description="Run a TS-ASR experiment on MI355X")
+    p.add_argument("param_file", type=str)
+    p.add_argument("--debug", default=False, action="store_true")
+    p.add_argument("--device", type=str)
+    p.add_argument("--distributed_launch", default=False, action="store_true")
+    p.add_argument("--distributed_backend", type=str)
+    p.add_argument("--find_unused_parameters", default=False, action="store_true")
+    p.add_argument("--auto_mix_prec", default=None, action="store_true")
+    p.add_argument("--bfloat16_mix_prec", default=None, action="store_true")
+    p.add_argument("--max_grad_norm", type=float)
+    p.add_argument("--nonfinite_patience", type=int)
+    p.add_argument("--grad_accumulation_factor", type=int)
+    p.add_argument("--optimizer_step_limit", type=int)
+    p.add_argument("--local_rank", type=int)
+    run, rest = p.parse_known_args(arg_list)
+    run_opts = {k: v for k, v in vars(run).items() if v is not None and v is not False}
+    param_file = run_opts.pop("param_file")
+    overrides = {}
+    i = 0
+    while i < len(rest):
+        tok = rest[i]
+        if not tok.startswith("--"):
+            raise ValueError(f"unexpected argument {tok!r}")
+        if "=" in tok:
+            k, v = tok[2:].split("=", 1)
+            i += 1
+        else:
+            k, v = tok[2:], rest[i + 1] if i + 1 < len(rest) else "True"
+            i += 2
+        import yaml as _yaml
+        overrides[k] = _yaml.safe_load(v)
+    local_rank = run_opts.pop("local_rank", None)
+    if local_rank is None and "LOCAL_RANK" in os.environ:
+        local_rank = int(os.environ["LOCAL_RANK"])
+    if local_rank is not None and "cuda" in run_opts.get("device", "cuda"):
+        run_opts["device"] = f"cuda:{local_rank}"
+    return param_file, run_opts, overrides
+
+
+class Brain:
+    def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None, profiler=None):
+        self.opt_class, self.checkpointer, self.profiler = opt_class, checkpointer, profiler
+        run_opts = dict(run_opts or {})
+        hp = dict(hparams or {})
+        for k, default in RUN_OPT_DEFAULTS.items():  # CLI > YAML > default, as core.py:587-606
+            setattr(self, k, run_opts[k] if k in run_opts else hp.get(k, default))
+        self.device = str(self.device)
+        if "cuda" in self.device:
+            torch.cuda.set_device(int(self.device.split(":")[1]) if ":" in self.device else 0)
+        # components without a mirror on the hot path (augmenters, ...) arrive as hparams.Unavailable: not modules
+        mods = {k: m for k, m in (modules or {}).items() if isinstance(m, torch.nn.Module)}
+        self.skipped_modules = sorted(set(modules or {}) - set(mods))
+        self.modules = torch.nn.ModuleDict(mods).to(self.device)
+        from types import SimpleNamespace
+        self.hparams = SimpleNamespace(**hp)
+        if self.compute_dtype is None:
+            self.compute_dtype = "bf16" if (self.auto_mix_prec and self.bfloat16_mix_prec) else "fp32"
+        self.valid_step = self.step = self.optimizer_step = 0
+        self.nonfinite_count = 0
+        self._nonfinite_dev = None
+        self.avg_train_loss = 0.0
+        self.grad_norm_epoch = []
+        self.optimizer = None
+        self.arena = None
+        self.rank = int(os.environ.get("RANK", 0))
+        self.distributed = bool(self.distributed_launch) and _dp.is_initialized()
+
+    # ---- hooks the recipe overrides ----------------------------------------------------------
+    def compute_forward(self, batch, stage):
+        raise NotImplementedError
+
+    def compute_objectives(self, predictions, batch, stage):
+        raise NotImplementedError
+
+    def on_stage_start(self, stage, epoch=None):
+        pass
+
+    def on_stage_end(self, stage, stage_loss, epoch=None):
+        pass
+
+    def on_fit_batch_end(self, batch, outputs, loss, should_step):
+        pass
+
+    def on_fit_start(self):
+        self._setup_dtype()
+        self.init_optimizers()
+
+    # ---- setup ---------------------------------------------------------------------------------
+    def _setup_dtype(self):
+        from . import nnet
+        nnet.set_compute_dtype(torch.bfloat16 if self.compute_dtype in ("bf16", torch.bfloat16) else torch.float32)
+
+    def trainable_parameters(self):
+        seen, out = set(), []
+        for p in self.modules.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def init_optimizers(self):
+        if self.opt_class is None or self.optimizer is not None:
+            return
+        params = self.trainable_parameters()
+        # one flat fp32 gradient arena for every module; parameters ordered so that buckets complete in the order
+        # backward produces them (dp.GradArena docstring)
+        self.arena = _dp.GradArena(self.modules, world_size=_dp.world_size() if self.distributed else 1)
+        self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm)
+
+    # ---- the training step (core.py:1032-1096) -----------------------------------------------------
+    @contextlib.contextmanager
+    def no_sync(self, use=True):
+        if use and self.arena is not None:
+            old = self.arena.sync_enabled
+            self.arena.sync_enabled = False
+            try:
+                yield
+            finally:
+                self.arena.sync_enabled = old
+        else:
+            yield
+
+    def fit_batch(self, batch):
+        if self.optimizer is None:
+            self.on_fit_start()
+        self.valid_step += 1
+        should_step = (self.valid_step % self.grad_accumulation_factor) == 0
+        with self.no_sync(not should_step):
+            self.arena.begin_backward(should_step)
+            outputs = self.compute_forward(batch, Stage.TRAIN)
+            loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+            self.check_gradients(loss)
+            (loss / self.grad_accumulation_factor).backward()
+            if should_step:
+                self.arena.finish_backward()  # waits for the overlapped bucket all-reduces, averages over ranks
+                self.optimizer.step()         # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
+                self.arena.zero_()
+                self.optimizer_step += 1
+        self.on_fit_batch_end(batch, outputs, loss, should_step)
+        return loss.detach()
+
+    def check_gradients(self, loss):
+        """Counts non-finite losses on the device (reference: counted, the step is NOT skipped; core.py:1115-1150)."""
+        bad = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(())
+        self._nonfinite_dev = bad if self._nonfinite_dev is None else self._nonfinite_dev + bad
+        return True
+
+    def flush_nonfinite(self):
+        """One host read for all the steps since the last flush; raises like the reference when patience is exhausted."""
+        if self._nonfinite_dev is not None:
+            self.nonfinite_count += int(self._nonfinite_dev.item())
+            self._nonfinite_dev = None
+        if self.nonfinite_count > self.nonfinite_patience:
+            raise ValueError("Loss is not finite and patience is exhausted.")
+        return self.nonfinite_count
+
+    def evaluate_batch(self, batch, stage):
+        out = self.compute_forward(batch, stage=stage)
+        return self.compute_objectives(out, batch, stage=stage).detach()
+
+    # ---- loops ----------------------------------------------------------------------------------------
+    def fit(self, epoch_counter, train_set, valid_set=None, progressbar=None, train_loader_kwargs=None, valid_loader_kwargs=None):
+        self.on_fit_start()
+        for epoch in epoch_counter:
+            self.on_stage_start(Stage.TRAIN, epoch)
+            self.modules.train()
+            total, n = None, 0
+            for batch in train_set:
+                self.step += 1
+                loss = self.fit_batch(batch)
+                total = loss if total is None else total + loss
+                n += 1
+                if self.optimizer_step_limit is not None and self.optimizer_step >= self.optimizer_step_limit:
+                    break
+            self.flush_nonfinite()
+            self.avg_train_loss = float(total / max(n, 1)) if total is not None else 0.0
+            self.on_stage_end(Stage.TRAIN, self.avg_train_loss, epoch)
+            self.step = 0
+            if valid_set is not None:
+                self._eval_loop(valid_set, Stage.VALID, epoch)
+
+    def evaluate(self, test_set, max_key=None, min_key=None, progressbar=None, test_loader_kwargs=None):
+        return self._eval_loop(test_set, Stage.TEST, None)
+
+    def _eval_loop(self, data, stage, epoch):
+        self.on_stage_start(stage, epoch)
+        self.modules.eval()
+        total, n = None, 0
+        with torch.no_grad():
+            for batch in data:
+                loss = self.evaluate_batch(batch, stage)
+                total = loss if total is None else total + loss
+                n += 1
+        avg = float(total / max(n, 1)) if total is not None else 0.0
+        self.on_stage_end(stage, avg, epoch)
+        return avg

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
                                                         int ldl, float slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = lds_stride(J);
-    bf16_t *w_lds = reinterpret_cast<bf16_t *>(smem);  // [32][S]
-    bf16_t *d_lds = w_lds + 32 * S;                    // [32][S]
+    bf16_t *w_lds = reinterpret_cast<bf16_t *>(smem);     // [32][S] bf16 (MFMA operand)
+    T *d_lds = reinterpret_cast<T *>(w_lds + 32 * S);     // [32][S] in the activation storage type (no extra rounding)
     const int b = blockIdx.z, u0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
     const int tchunk = cdiv_dev(Tn, (int)gridDim.y);
     const int t_begin = blockIdx.y * tchunk, t_end = min(Tn, t_begin + tchunk);
     const bf16_t *wrow = w_lds + r * S + 8 * h;
-    const bf16_t *drow = d_lds + r * S + 8 * h;
+    const T *drow = d_lds + r * S + 8 * h;
     const int nks = J / 16;
     for (int t = t_begin + wave; t < t_end; t += 4) {
         const T *erow = enc + ((size_t)b * Tn + t) * J + 8 * h;
@@ -549,7 +549,7 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
     TSASR_CHECK_ARG(J > 0 && J % 16 == 0, "tsasr_joint_fwd: J=%d must be a multiple of 16", J);
     TSASR_CHECK_ARG(V > 0 && V <= 32, "tsasr_joint_fwd: V=%d not supported (1..32)", V);
     TSASR_CHECK_ARG(ldl >= V && ldl % 4 == 0 && ldl <= 32, "tsasr_joint_fwd: ldl=%d must be a multiple of 4 in [V,32]", ldl);
-    const size_t lds = (size_t)2 * 32 * lds_stride(J) * sizeof(bf16_t);
+    const size_t lds = (size_t)32 * lds_stride(J) * (sizeof(bf16_t) + (io_dtype == TSASR_F32 ? sizeof(float) : sizeof(bf16_t)));
     TSASR_CHECK_ARG(lds <= 160 * 1024, "tsasr_joint_fwd: J=%d needs %zu B of LDS (>160 KiB)", J, lds);
     const int nut = cdiv(U1, 32);
     int tsplit = 1;  // enough workgroups to cover 256 CUs twice, at least 8 frames per wave

@@ -1,0 +1,166 @@
+"""Data parallelism for the TS-ASR training step: one process per GPU, RCCL over xGMI through torch.distributed.
+
+Reference: speechbrain/core.py:1464-1484 wraps EACH trainable module in its own DistributedDataParallel (9 reducers
+for the scratch recipe, several with sub-MB payloads), speechbrain/utils/distributed.py:123-201 initialises the
+process group. Here instead:
+
+  * ``GradArena`` owns ONE flat fp32 buffer for the gradients (and one for the parameters) of every module;
+    ``p.grad`` / ``p.data`` are views into it. Parameters are laid out in the order backward finishes them
+    (recorded on the first step, like DDP's bucket rebuild), cut into a few large buckets (default 32 MiB: xGMI is
+    point-to-point, 7 links x ~153 GB/s per GPU, so a collective is per-link bound and wants few large messages).
+  * a bucket's all-reduce (average) is launched on RCCL's stream the moment its last gradient has been accumulated
+    (post-accumulate-grad hooks) and overlaps with the rest of backward; ``finish_backward`` only makes the compute
+    stream wait for the communication stream.
+  * grad accumulation: with ``sync_enabled = False`` (Brain.no_sync) nothing is sent, exactly like the reference's
+    ``require_backward_grad_sync = False`` (core.py:1585-1615).
+No data-path collective other than this one exists on the path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def ddp_init_group(run_opts):
+    """speechbrain/utils/distributed.py:123-201: env:// rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    if not run_opts.get("distributed_launch", False) or is_initialized():
+        return
+    if "RANK" not in os.environ or "LOCAL_RANK" not in os.environ:
+        raise ValueError("To use DDP backend, start your script with:\n\tpython -m torch.distributed.run "
+                         "--nproc-per-node=N train.py hparams.yaml --distributed_launch --distributed_backend=nccl")
+    backend = run_opts.get("distributed_backend", "nccl")
+    if backend not in ("nccl", "gloo", "mpi"):
+        raise ValueError(backend + " communication protocol doesn't exist.")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    dist.init_process_group(backend=backend)
+
+
+class GradArena:
+    def __init__(self, modules, world_size=1, bucket_bytes=32 << 20, group=None):
+        seen, params = set(), []
+        for p in modules.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("no trainable parameters")
+        self.params_ordered = params
+        self.world_size, self.group, self.bucket_bytes = world_size, group, bucket_bytes
+        self.device = params[0].device
+        self.numel = sum(p.numel() for p in params)
+        self.grads = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=self.device)
+        self.sync_enabled = True
+        self._sync_this_step = False
+        self._order_seen, self._order_final = [], False
+        self._handles = []
+        self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
+        self._reorder_pending = False
+        self._layout(params, first=True)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    # ---- layout ---------------------------------------------------------------------------------------
+    def _layout(self, params, first=False):
+        """Place parameters (and their gradients) contiguously in the given order; cut buckets. On a re-layout the
+        parameter values and every registered companion buffer (optimizer moments) are permuted alike."""
+        new_off, off = {}, 0
+        for p in params:
+            new_off[id(p)] = off
+            off += p.numel()
+        if first:
+            for p in params:
+                o, n = new_off[id(p)], p.numel()
+                self.flat_params[o:o + n].copy_(p.data.reshape(-1).float())
+        else:
+            for buf in [self.flat_params] + self.companions:
+                old = buf.clone()
+                for p in params:
+                    o, n, oo = new_off[id(p)], p.numel(), self.offset[id(p)]
+                    buf[o:o + n].copy_(old[oo:oo + n])
+        self.offset = new_off
+        for p in params:
+            o, n = new_off[id(p)], p.numel()
+            p.data = self.flat_params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+        self.params_ordered = list(params)
+        self.buckets, start, pend = [], 0, []
+        limit = max(1, self.bucket_bytes // 4)
+        for p in params:
+            pend.append(id(p))
+            end = self.offset[id(p)] + p.numel()
+            if end - start >= limit:
+                self.buckets.append({"lo": start, "hi": end, "ids": set(pend), "left": len(pend)})
+                start, pend = end, []
+        if pend:
+            self.buckets.append({"lo": start, "hi": self.numel, "ids": set(pend), "left": len(pend)})
+        self.bucket_of = {i: b for b in self.buckets for i in b["ids"]}
+
+    # ---- per step --------------------------------------------------------------------------------------
+    def begin_backward(self, will_sync):
+        self._sync_this_step = bool(will_sync) and self.sync_enabled and self.world_size > 1
+        for b in self.buckets:
+            b["left"], b["sent"] = len(b["ids"]), False
+        self._handles = []
+
+    def _on_grad(self, p):
+        if not self._order_final:
+            self._order_seen.append(p)
+        if not self._sync_this_step or not self._order_final:
+            return
+        b = self.bucket_of[id(p)]
+        b["left"] -= 1
+        if b["left"] == 0:
+            self._send(b)
+
+    def _send(self, b):
+        if b.get("sent"):
+            return
+        b["sent"] = True
+        chunk = self.grads[b["lo"]:b["hi"]]
+        if dist.get_backend(self.group) == "nccl":
+            self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        else:  # gloo has no AVG
+            self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+
+    def finish_backward(self):
+        if self._sync_this_step:
+            for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step
+                self._send(b)
+            for h, chunk in self._handles:
+                h.wait()
+                if chunk is not None:
+                    chunk.div_(self.world_size)
+            self._handles = []
+        if not self._order_final and self._order_seen:
+            self._finalize_order()
+
+    def _finalize_order(self):
+        """Re-lay the arena in the order gradients became ready on the first backward (grads must be consumed first:
+        called from zero_() at the end of the step)."""
+        self._reorder_pending = True
+
+    def zero_(self):
+        self.grads.zero_()
+        if self._reorder_pending:
+            seen, order = set(), []
+            for p in self._order_seen:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    order.append(p)
+            for p in self.params_ordered:  # parameters that never produced a gradient go last
+                if id(p) not in seen:
+                    order.append(p)
+            self._layout(order)
+            self._order_final, self._reorder_pending, self._order_seen = True, False, []
+
+    def grad_norm(self):
+        return torch.linalg.vector_norm(self.grads)

@@ -1,0 +1,87 @@
+"""Optimizer step over the flat arena: global-norm clipping + AdamW in one pass.
+
+Reference: speechbrain/core.py:1082-1093 (torch.nn.utils.clip_grad_norm_(max_grad_norm) -> optimizer.step() ->
+zero_grad) with opt_class = torch.optim.AdamW(lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+(hparams conformer-t_scratch.yaml:267-271); >= 3 passes over 51 M parameters x (p, g, m, v) and a host sync for
+grad_norm.item(). Here the norm stays on the device and clip + decoupled weight decay + Adam moments + update are one
+kernel over four flat buffers (``tsasr_clip_adamw_step`` in csrc/optim.hip).
+"""
+import functools
+
+import torch
+
+from . import _capi as C
+
+
+class FusedClipAdamW:
+    """Exposes ``param_groups`` (the Noam scheduler writes ``lr`` there) and ``step()``; state = flat m, v."""
+
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+        self.arena = arena
+        self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
+                              "params": arena.params_ordered}]
+        self.max_grad_norm = float(max_grad_norm or 0.0)
+        self.exp_avg = torch.zeros_like(arena.grads)
+        self.exp_avg_sq = torch.zeros_like(arena.grads)
+        arena.companions += [self.exp_avg, self.exp_avg_sq]  # follow the arena's one-time re-layout
+        self.t = 0
+        self.last_grad_norm = torch.zeros((), device=arena.device)  # device scalar, never synced in the step
+
+    def step(self):
+        g = self.param_groups[0]
+        self.t += 1
+        b1, b2 = g["betas"]
+        a = self.arena
+        _clip_adamw(a.flat_params, a.grads, self.exp_avg, self.exp_avg_sq, self.last_grad_norm, g["lr"], b1, b2, g["eps"],
+                    g["weight_decay"], self.t, self.max_grad_norm)
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_()
+
+    def state_dict(self):
+        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": [
+            {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+
+def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm):
+    """GLUE version (flat torch ops); replaced by the HIP kernel when csrc/optim.hip is present in the library."""
+    fn = getattr(C, "clip_adamw_step", None)
+    if fn is not None:
+        return fn(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm)
+    C.require_gpu(p)
+    norm = torch.linalg.vector_norm(g)
+    norm_out.copy_(norm)
+    if max_norm > 0:
+        g.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+    p.mul_(1.0 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = (v.sqrt() / (1.0 - b2 ** t) ** 0.5).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1.0 - b1 ** t))
+
+
+class _WrappedTorchOptimizer:
+    """Any other opt_class: used as given, clipping by torch (still one flat gradient buffer underneath)."""
+
+    def __init__(self, opt, arena, max_grad_norm):
+        self.opt, self.arena, self.max_grad_norm = opt, arena, float(max_grad_norm or 0.0)
+        self.param_groups = opt.param_groups
+        self.last_grad_norm = torch.zeros((), device=arena.device)
+
+    def step(self):
+        norm = self.arena.grad_norm()
+        self.last_grad_norm.copy_(norm)
+        if self.max_grad_norm > 0:
+            self.arena.grads.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
+        self.opt.step()
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_()
+
+
+def make_optimizer(opt_class, params, arena, max_grad_norm):
+    kw = opt_class.keywords if isinstance(opt_class, functools.partial) else {}
+    base = opt_class.func if isinstance(opt_class, functools.partial) else opt_class
+    if base is torch.optim.AdamW and not (set(kw) - {"lr", "betas", "eps", "weight_decay"}):
+        return FusedClipAdamW(arena, max_grad_norm=max_grad_norm, **kw)
+    return _WrappedTorchOptimizer(opt_class(params), arena, max_grad_norm)

@@ -1,0 +1,90 @@
+"""TS-ASR Brain: the reference recipes' ``TSASR(sb.Brain)`` on the MI355X runtime.
+
+Mirrors train_librispeechmix_scratch.py:33-195 (and the ``pretrained`` / ``none`` variants, which differ only in
+the speaker branch: train_librispeechmix_pretrained.py:45-63, train_librispeechmix_none.py): same module names in
+``self.modules``, same call order, same return values (``compute_forward -> (logits [B,T',U+1,V], hyps or None)``,
+``compute_objectives -> 0-dim loss with autograd``). Differences: joiner + head run as ONE fused HIP kernel
+(the [B,T',U+1,J] joint tensor is never built), lengths stay on the device, plotting/WER bookkeeping is left to the
+caller (out of scope).
+"""
+import torch
+
+from .. import core, rnnt
+from ..nnet import abs_lengths_round
+
+Stage = core.Stage
+
+
+class TSASR(core.Brain):
+    variant = "scratch"  # "scratch" | "pretrained" | "none"
+
+    # ---- speaker branch (train_librispeechmix_scratch.py:44-80) ------------------------------------
+    def _speaker_embedding(self, batch, epoch):
+        hp = self.hparams
+        if self.variant == "none":
+            return None, None
+        if self.variant == "pretrained":  # frozen speaker encoder's output is an input here (WavLM itself is out of scope)
+            embs, lens = batch.enroll_emb
+            return self.modules.speaker_proj(embs), lens
+        enroll, enroll_lens = batch.enroll_sig
+        if getattr(hp, "input_is_feats", False):
+            feats = enroll
+        else:
+            feats = self.modules.speaker_feature_extractor(enroll)
+            feats = self.modules.speaker_normalizer(feats, enroll_lens, epoch=epoch)
+        feats = self.modules.speaker_frontend(feats)
+        embs = self.modules.speaker_encoder(feats, enroll_lens)
+        if hp.injection_mode != "cross_attention":
+            Te = embs.shape[-2]
+            n = (enroll_lens * Te).ceil().clamp(max=Te)
+            mask = (torch.arange(Te, device=embs.device)[None, :] < n[:, None]).unsqueeze(-1).to(embs.dtype)
+            embs = (embs * mask).sum(dim=-2, keepdim=True) / mask.sum(dim=-2, keepdim=True)
+        return self.modules.speaker_proj(embs), enroll_lens
+
+    def compute_forward(self, batch, stage):
+        hp = self.hparams
+        epoch = hp.epoch_counter.current if hasattr(hp, "epoch_counter") else 0
+        batch = batch.to(self.device)
+        mixed, mixed_lens = batch.mixed_sig
+        tokens_bos, tokens_bos_lens = batch.tokens_bos
+        speaker_embs, enroll_lens = self._speaker_embedding(batch, epoch)
+
+        if getattr(hp, "input_is_feats", False):
+            feats = mixed
+        else:
+            feats = self.modules.feature_extractor(mixed)
+            feats = self.modules.normalizer(feats, mixed_lens, epoch=epoch)
+        feats = self.modules.frontend(feats)
+        enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
+        enc_out = self.modules.encoder_proj(enc_out)
+
+        embs = self.modules.embedding(tokens_bos)
+        dec_out, _ = self.modules.decoder(embs, lengths=tokens_bos_lens)
+        dec_out = self.modules.decoder_proj(dec_out)
+
+        # joiner + transducer_head fused (train_librispeechmix_scratch.py:132-135)
+        head = self.modules.transducer_head.w
+        tlen = abs_lengths_round(mixed_lens, enc_out.shape[1])
+        ulen = abs_lengths_round(batch.tokens.lengths.to(self.device), batch.tokens.data.shape[1])
+        logits = rnnt.fused_joint_logits(enc_out, dec_out, head.weight, head.bias, self.modules.joiner.nonlinearity.negative_slope,
+                                         tlen, ulen)
+        hyps = None
+        if stage == Stage.VALID:
+            if epoch % getattr(hp, "valid_search_freq", 1) == 0 and hasattr(hp, "greedy_searcher"):
+                hyps, _, _, _ = hp.greedy_searcher(enc_out)
+        elif stage == Stage.TEST and hasattr(hp, "beam_searcher"):
+            hyps, _, _, _ = hp.beam_searcher(enc_out)
+        return logits, hyps
+
+    def compute_objectives(self, predictions, batch, stage):
+        logits, hyps = predictions
+        _, mixed_lens = batch.mixed_sig
+        tokens, tokens_lens = batch.tokens
+        loss = self.hparams.transducer_loss(logits, tokens, mixed_lens, tokens_lens)
+        if hyps is not None:
+            self.last_hyps = hyps  # the reference feeds them to its WER/CER statistics (out of scope here)
+        return loss
+
+    def on_fit_batch_end(self, batch, outputs, loss, should_step):
+        if getattr(self.hparams, "enable_scheduler", False) and should_step:
+            self.hparams.noam_scheduler(self.optimizer)

@@ -9,6 +9,7 @@ Extra (MI355X-native) entry: ``fused_joint_logits`` = joiner + transducer_head w
 import torch
 
 from . import _capi as C
+from . import prof
 
 _LDL = 32  # logits rows are padded to 32 floats (128 B) so that every row access is a 16-byte multiple
 
@@ -29,8 +30,9 @@ class _JointLogitsFn(torch.autograd.Function):
         U1 = dec.shape[1]
         V = w32.shape[0]
         buf = torch.empty(B, T, U1, _LDL, dtype=torch.float32, device=enc.device)
-        C.check(C.lib().tsasr_joint_fwd(C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(b32), C.ptr(buf), B, T, U1, J, V, _LDL,
-                                        C.io_dtype(enc), float(slope), C.stream_ptr()), "tsasr_joint_fwd")
+        with prof.region("joint_fwd"):
+            C.check(C.lib().tsasr_joint_fwd(C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(b32), C.ptr(buf), B, T, U1, J, V, _LDL,
+                                            C.io_dtype(enc), float(slope), C.stream_ptr()), "tsasr_joint_fwd")
         ctx.save_for_backward(enc, dec, w32, tlen, ulen)
         ctx.slope, ctx.V = float(slope), V
         ctx.wdtype, ctx.bdtype = weight.dtype, bias.dtype
@@ -47,9 +49,10 @@ class _JointLogitsFn(torch.autograd.Function):
         db = torch.empty(V, dtype=torch.float32, device=enc.device)
         nws = C.lib().tsasr_joint_bwd_workspace_bytes(B, T, U1, J)
         ws = _ws(nws, enc.device)
-        C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
-                                        C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), C.io_dtype(enc), ctx.slope,
-                                        C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_bwd")
+        with prof.region("joint_bwd"):
+            C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
+                                            C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), C.io_dtype(enc), ctx.slope,
+                                            C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_bwd")
         return denc, ddec, dW.to(ctx.wdtype), db.to(ctx.bdtype), None, None, None
 
 
@@ -83,9 +86,10 @@ class _RnntLossFn(torch.autograd.Function):
             raise ValueError(f"targets must be [B, >= U1-1] = [{B}, >= {U1 - 1}], got {tuple(tg.shape)}")
         costs = torch.empty(B, dtype=torch.float32, device=lg.device)
         ws = _ws(C.lib().tsasr_rnnt_loss_workspace_bytes(B, T, U1), lg.device)
-        C.check(C.lib().tsasr_rnnt_loss_fwd(C.ptr(lg), C.ptr(tg), tg.stride(0), C.ptr(tlen), C.ptr(ulen), C.ptr(costs),
-                                            B, T, U1, V, lg.stride(-2), int(blank), C.ptr(ws), ws.numel(), C.stream_ptr()),
-                "tsasr_rnnt_loss_fwd")
+        with prof.region("rnnt_loss_fwd"):
+            C.check(C.lib().tsasr_rnnt_loss_fwd(C.ptr(lg), C.ptr(tg), tg.stride(0), C.ptr(tlen), C.ptr(ulen), C.ptr(costs),
+                                                B, T, U1, V, lg.stride(-2), int(blank), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                    "tsasr_rnnt_loss_fwd")
         ctx.save_for_backward(lg, tg, tlen, ulen, ws)
         ctx.blank, ctx.in_dtype = int(blank), logits.dtype
         return costs
@@ -97,9 +101,10 @@ class _RnntLossFn(torch.autograd.Function):
         ldl = lg.stride(-2)
         gs = gcosts.float().contiguous()
         buf = torch.empty(B, T, U1, ldl, dtype=torch.float32, device=lg.device)
-        C.check(C.lib().tsasr_rnnt_loss_bwd(C.ptr(lg), C.ptr(tg), tg.stride(0), C.ptr(tlen), C.ptr(ulen), C.ptr(gs), C.ptr(buf),
-                                            B, T, U1, V, ldl, ctx.blank, C.ptr(ws), ws.numel(), C.stream_ptr()),
-                "tsasr_rnnt_loss_bwd")
+        with prof.region("rnnt_loss_bwd"):
+            C.check(C.lib().tsasr_rnnt_loss_bwd(C.ptr(lg), C.ptr(tg), tg.stride(0), C.ptr(tlen), C.ptr(ulen), C.ptr(gs), C.ptr(buf),
+                                                B, T, U1, V, ldl, ctx.blank, C.ptr(ws), ws.numel(), C.stream_ptr()),
+                    "tsasr_rnnt_loss_bwd")
         g = buf[..., :V]
         return (g if ctx.in_dtype == torch.float32 else g.to(ctx.in_dtype)), None, None, None, None
 
