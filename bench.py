@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Conformer-Transducer TS-ASR training step (conformer-t_scratch, T=1000 mel frames, B=32/GPU, bf16).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = TSASR.fit_batch on one synthetic batch resident in HBM: speaker branch + front-end + 12-layer Conformer
+encoder + predictor + fused joint/head + RNN-T loss, backward, gradient all-reduce (N > 1), clip + AdamW.
+Workload = BASELINE.json configs[1]: mel N(0,1) [32,1000,80] (already normalised; fed after A2),
+enrollment mel [32,500,80], tokens randint(1,29) [32,120], all lengths 1.0, injection_mode=cat, dropout 0.1 active,
+grad_accumulation_factor 1, per-rank data seed 1234+rank, weights random-init (seed 0).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "ts-asr_amd"
+B_LOCAL, T_MEL, T_ENROLL, U = 32, 1000, 500, 120
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def build_brain(device, compute_dtype="bf16", accum=1, overrides=None):
+    import torch
+    hp = importlib.import_module(PKG + ".hparams")
+    tsasr = importlib.import_module(PKG + ".recipes.tsasr")
+    ov = dict(input_is_feats=True, compute_dtype=compute_dtype, grad_accumulation_factor=accum)
+    ov.update(overrides or {})
+    with open(os.path.join(ROOT, "hparams", "conformer-t_scratch_mi355x.yaml")) as f:
+        h = hp.load_hyperpyyaml(f, ov)
+    run_opts = {"device": device, "compute_dtype": compute_dtype, "grad_accumulation_factor": accum,
+                "distributed_launch": int(os.environ.get("WORLD_SIZE", "1")) > 1}
+    brain = tsasr.TSASR(h["modules"], h["opt_class"], h, run_opts)
+    brain.modules.train()
+    return brain, h, torch
+
+
+# algorithmic HBM bytes per launch of each hand-written kernel family at configs[1] (DESIGN.md "Kernels")
+def algorithmic_bytes(B=B_LOCAL, Tp=T_MEL // 4, U1=U + 1, J=640, V=29):
+    cells = B * Tp * U1
+    act = (B * Tp * J + B * U1 * J) * 2            # enc_proj + dec_proj, bf16
+    return {
+        "joint_fwd": act + cells * V * 4,                       # read enc/dec, write logits fp32
+        "rnnt_loss_fwd": cells * V * 4 + cells * 4 * 4,         # read logits; alpha/beta/lp pairs round trip
+        "rnnt_loss_bwd": 2 * cells * V * 4,                     # read logits, write dlogits
+        "joint_bwd": cells * V * 4 + act + act,                 # read dlogits + enc/dec, write denc/ddec
+    }
+
+
+def cpu_baseline(brain, torch, budget_steps=2, B=2):
+    """Oracle (CPU restatement of the reference) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import rnnt_ref, tsasr_ref
+    batch_mod = importlib.import_module(PKG + ".batch")
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TSASR_CPU_BASELINE_THREADS", "16")))  # the box's CPU share
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()}, affinity={len(os.sched_getaffinity(0))})")
+    sd = {f"{n}.{k}": v.detach().cpu().float().clone().requires_grad_(v.dtype.is_floating_point)
+          for n, m in brain.modules.items() for k, v in m.state_dict().items()}
+    cfg = dict(nhead=4, encoder_num_layers=12, speaker_num_layers=6, vocab_size=29, blank_index=0)
+    bt = batch_mod.synthetic_batch(B, T_MEL, T_ENROLL, U, feats=True, seed=999)
+    cb = {"mixed_feats": bt.mixed_sig.data, "mixed_lens": bt.mixed_sig.lengths, "enroll_feats": bt.enroll_sig.data,
+          "enroll_lens": bt.enroll_sig.lengths, "tokens_bos": bt.tokens_bos.data, "tokens_bos_lens": bt.tokens_bos.lengths}
+    times = []
+    for i in range(1 + budget_steps):
+        log(f"cpu baseline step {i}")
+        t0 = time.perf_counter()
+        logits = tsasr_ref.compute_forward(cb, sd, cfg, "cat", from_feats=True)
+        loss = rnnt_ref.transducer_loss_ref_torch(logits, bt.tokens.data, bt.mixed_sig.lengths, bt.tokens.lengths, 0, "mean")
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B * T_MEL / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"fwd+loss+bwd of the same model/shape at B={B} (T=1000 mel, U=120, 5 s enrollment), fp32, median of {len(times)} steps after 1 warm-up; optimizer step excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ragged", action="store_true", help="lengths U(0.6,1) sorted ascending instead of all 1.0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    dp = importlib.import_module(PKG + ".dp")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dp.ddp_init_group({"distributed_launch": True, "distributed_backend": "nccl"})
+    prof = importlib.import_module(PKG + ".prof")
+    batch_mod = importlib.import_module(PKG + ".batch")
+
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # GLUE convs/LSTM: no exhaustive MIOpen search on first use
+    log("building model")
+    brain, h, _ = build_brain(device, args.dtype, args.accum)
+    log("model built")
+    if world > 1:  # identical initial weights on every rank (reference: DDP constructor broadcast)
+        for p in brain.modules.parameters():
+            torch.distributed.broadcast(p.data, 0)
+    batch = batch_mod.synthetic_batch(B_LOCAL, T_MEL, T_ENROLL, U, feats=True, seed=1234 + rank, ragged=args.ragged).to(device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        brain.fit_batch(batch)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done")
+    sync()
+    prof.ENABLED = True
+    prof.reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = brain.fit_batch(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof.ENABLED = False
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    nonfinite = brain.flush_nonfinite()
+    kern = prof.collect()
+
+    if rank == 0:
+        frames = world * B_LOCAL * T_MEL * args.steps
+        ms_step = elapsed / args.steps * 1e3
+        ab = algorithmic_bytes()
+        fam = {k: {"launches": n, "avg_ms": round(ms, 4), "algorithmic_GBps": round(ab[k] / (ms * 1e-3) / 1e9, 1) if k in ab and ms > 0 else None}
+               for k, (n, ms) in kern.items()}
+        dom = max((k for k in fam if k in ab), key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)
+        roof = None
+        if dom is not None:
+            ach = ab[dom] / (fam[dom]["avg_ms"] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": fam[dom]["avg_ms"]}
+        rnnt_ms = sum(fam[k]["avg_ms"] for k in ("joint_fwd", "rnnt_loss_fwd", "rnnt_loss_bwd", "joint_bwd") if k in fam)
+        out = {
+            "metric": "utterance-frames/sec (conformer-t_scratch training step, T=1000, B=32/GPU)",
+            "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: conformer-t_scratch 12L d256 (+6L speaker encoder), mel [32,1000,80] + "
+                                   "enrollment mel [32,500,80] + tokens [32,120], injection cat, dropout 0.1, lens "
+                                   + ("U(0.6,1) ascending" if args.ragged else "1.0"),
+                       "global_batch": world * B_LOCAL, "grad_accumulation_factor": args.accum, "parallelism": f"dp{world}"},
+            "frames_per_sec_per_gpu": round(frames / elapsed / world, 1),
+            "rnnt_joint_loss_ms": round(rnnt_ms, 4),
+            "loss": round(float(loss), 4), "nonfinite_steps": nonfinite,
+            "hip_kernels": fam,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(brain, torch)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

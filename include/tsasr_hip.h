@@ -74,6 +74,58 @@ int tsasr_rnnt_loss_bwd(const float *logits, const int32_t *targets, int ldt, co
                         int B, int T, int U1, int V, int ldl, int blank,
                         const void *workspace, size_t workspace_bytes, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels of the Conformer block (HBM-bound, one pass each, fp32 math, deterministic column reductions).
+ * LayerNorm: replaces torch.nn.LayerNorm / SB/nnet/normalization.py:172-223 as used at
+ *   SB/lobes/models/transformer/Conformer.py:73,93,194-217 and SB/lobes/models/convolution.py (norm over [F,C]);
+ *   act_slope >= 0 fuses the LeakyReLU that follows it (Conformer.py:93-95, convolution.py ConvBlock); < 0 = none.
+ * x,y: [M, D] io_dtype; gamma,beta,dgamma,dbeta: fp32 [D]; mean,rstd: fp32 [M] (saved for backward). D % 8 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                        long long M, int D, float eps, float act_slope, int io_dtype, void *stream);
+size_t tsasr_layernorm_bwd_workspace_bytes(long long M, int D);
+int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
+                        const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                        int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* y = dropout_p(act(x + bias))  - the Linear-bias + activation() + Dropout chain of PositionalwiseFeedForward
+ * (SB/nnet/attention.py:820-836). bias may be NULL; act_slope < 0 = no activation; the dropout mask is a pure function
+ * of (seed, element index) and is regenerated by the backward (never stored). dbias may be NULL. N % 8 == 0. */
+int tsasr_bias_act_dropout_fwd(const void *x, const float *bias, void *y, long long M, int N, float act_slope, float p,
+                               unsigned long long seed, int io_dtype, void *stream);
+size_t tsasr_colpart_workspace_bytes(long long M, int N);
+int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, long long M, int N, float act_slope,
+                               float p, unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
+/* out = res + alpha * timemask(dropout_p(x + bias)) - the "Dropout -> 0.5*x + residual" and
+ * "Dropout -> masked_fill_(pad) -> + residual" tails of ConformerEncoderLayer / ConvolutionModule
+ * (Conformer.py:113-114,239-259). rows = [B, Trows] flattened; valid_lens (int32 [B], may be NULL) zeroes frames
+ * t >= valid_lens[b] of the x branch. res may be NULL. Backward gives dx (dres = dout needs no kernel). */
+int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
+                          float p, unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *stream);
+int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
+                          unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Conformer convolution-module core: z = LeakyReLU(LayerNorm(depthwise_conv1d_K(GLU(y2 + b2)))) on channels-last rows.
+ * Replaces SB/lobes/models/transformer/Conformer.py:101-115 between the two pointwise GEMMs: bottleneck bias + nn.GLU
+ * (:76-82), depthwise nn.Conv1d(D,D,K,groups=D) 'same' or causal pad+chomp (:68-71,84-93,108-110), after_conv LayerNorm +
+ * activation (:95-97).  y2 [B,T,2D] io_dtype = bottleneck GEMM output without bias; b2 [2D] or NULL; conv_w [D,K] (the
+ * [D,1,K] parameter); conv_b, gamma, beta [D]. D % 8 == 0, D <= 256, K in {31,15,7,3}. c_save [B,T,D], mean/rstd [B*T] are
+ * written by fwd and read by bwd. bwd: dparams fp32 = [dgamma D | dbeta D | dconv_b D | db2 2D | dconv_w D*K], overwritten.
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_convmod_fwd(const void *y2, const float *b2, const float *conv_w, const float *conv_b, const float *gamma,
+                      const float *beta, void *z, void *c_save, float *mean, float *rstd, int B, int T, int D, int K, int causal,
+                      float eps, float slope, int io_dtype, void *stream);
+size_t tsasr_convmod_bwd_workspace_bytes(int B, int T, int D, int K);
+int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const float *conv_w, const float *gamma, const float *beta,
+                      const void *c_save, const float *mean, const float *rstd, void *dy2, float *dparams, int B, int T, int D,
+                      int K, int causal, float slope, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

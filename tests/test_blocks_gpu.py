@@ -1,0 +1,203 @@
+"""GPU parity of the Conformer block kernels (through the C-ABI) vs golden vectors produced by the reference
+(tests/golden/c1_blocks.npz: RelPosMHAXL, ConvolutionModule, FFN, ConformerEncoderLayer - outputs AND gradients) and vs
+plain fp32 torch formulas for the row kernels."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.golden_recipe import CFG1, det_tensor, load_det_weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nn_():
+    m = importlib.import_module("ts-asr_amd.nnet")
+    m.set_compute_dtype(torch.float32)
+    return m
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return importlib.import_module("ts-asr_amd.ops")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def close(a, b, atol, rtol=1e-3):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), np.asarray(b), atol=atol, rtol=rtol)
+
+
+def block_inputs(golden):
+    g = golden["c1_blocks"]
+    x = T(g["x"]).to(DEV).requires_grad_(True)
+    lens = (T(np.asarray(CFG1["mix_lens"], np.float32)) * 50).round().to(torch.int32).to(DEV)
+    probe = T(det_tensor("probe.blk", (4, 50, 144), 1.0)).to(DEV)
+    return g, x, lens, probe
+
+
+def check_grads(mod, g, tag, atol=3e-4, rtol=2e-3, skip=()):
+    n = 0
+    for name, p in mod.named_parameters():
+        key = f"{tag}:d.{name}"
+        if key in g.files and name not in skip:
+            close(p.grad, g[key], atol, rtol)
+            n += 1
+    return n
+
+
+# ---------------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("M,D", [(200, 144), (8000, 256), (37, 1024), (50, 2560), (33, 5120)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("slope", [None, 0.01])
+def test_layernorm(ops, M, D, dtype, slope):
+    g = torch.Generator().manual_seed(M + D)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(dtype)
+    w, b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.2
+    dy = torch.randn(M, D, generator=g).to(dtype)
+    xr = x.float().clone().requires_grad_()
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.layer_norm(xr, (D,), wr, br, 1e-5)
+    if slope is not None:
+        yr = F.leaky_relu(yr, slope)
+    yr.backward(dy.float())
+    xg = x.to(DEV).requires_grad_()
+    wg, bg = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.layer_norm(xg, wg, bg, 1e-5, slope)
+    y.backward(dy.to(DEV))
+    lo = dtype == torch.bfloat16
+    close(y, yr.detach(), 3e-2 if lo else 2e-5, 1e-2 if lo else 1e-4)
+    close(xg.grad, xr.grad, 6e-2 if lo else 1e-4, 2e-2 if lo else 1e-3)
+    close(wg.grad, wr.grad, (0.5 if lo else 2e-3) * (M / 200) ** 0.5, 2e-2 if lo else 1e-3)
+    close(bg.grad, br.grad, (0.5 if lo else 2e-3) * (M / 200) ** 0.5, 2e-2 if lo else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_act_dropout(ops, dtype):
+    M, N = 500, 2048
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, N, generator=g).to(dtype)
+    b = torch.randn(N, generator=g) * 0.1
+    # p = 0: exact formula
+    xg, bg = x.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.bias_act_dropout(xg, bg, 0.01, 0.0, True)
+    ref = F.leaky_relu(x.float() + b, 0.01)
+    close(y, ref, 2e-2 if dtype == torch.bfloat16 else 1e-6)
+    dy = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    y.backward(dy)
+    dref = dy.float().cpu() * torch.where(ref > 0, 1.0, 0.01)
+    close(xg.grad, dref, 2e-2 if dtype == torch.bfloat16 else 1e-6)
+    close(bg.grad, dref.sum(0), 0.3 if dtype == torch.bfloat16 else 1e-3, 2e-2)
+    # p = 0.1: kept fraction, scaling, and backward regenerates the very same mask
+    xg = x.to(DEV).requires_grad_()
+    y = ops.bias_act_dropout(xg, None, None, 0.1, True)
+    keep = (y != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.9) < 3e-3
+    close(y[keep], (x.to(DEV).float() / 0.9)[keep], 2e-2 if dtype == torch.bfloat16 else 1e-6)
+    y.backward(torch.ones_like(y))
+    close(xg.grad, keep.float() / 0.9, 1e-2 if dtype == torch.bfloat16 else 1e-6)
+    # eval mode: identity (+bias)
+    close(ops.bias_act_dropout(x.to(DEV), None, None, 0.1, False), x.float(), 0)
+
+
+def test_dropout_add_and_time_mask(ops):
+    B, Tn, N = 3, 17, 64
+    g = torch.Generator().manual_seed(2)
+    x, res = torch.randn(B, Tn, N, generator=g), torch.randn(B, Tn, N, generator=g)
+    b = torch.randn(N, generator=g)
+    lens = torch.tensor([17, 9, 1], dtype=torch.int32)
+    xg, rg, bg = x.to(DEV).requires_grad_(), res.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    out = ops.dropout_add(xg, bg, rg, 0.5, 0.0, True, lens.to(DEV))
+    mask = (torch.arange(Tn)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    ref = res + 0.5 * (x + b) * mask
+    close(out, ref, 1e-6)
+    dout = torch.randn(B, Tn, N, generator=g)
+    out.backward(dout.to(DEV))
+    close(xg.grad, 0.5 * dout * mask, 1e-6)
+    close(rg.grad, dout, 0)
+    close(bg.grad, (0.5 * dout * mask).sum((0, 1)), 1e-5)
+    # broadcast residual [B,1,N] (speaker embedding injection)
+    r1 = torch.randn(B, 1, N, generator=g).to(DEV).requires_grad_()
+    o2 = ops.dropout_add(xg.detach(), None, r1)
+    o2.sum().backward()
+    close(o2, x + r1.detach().cpu(), 1e-6)
+    close(r1.grad, torch.full((B, 1, N), float(Tn)), 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- blocks vs reference golden
+@pytest.mark.parametrize("tag,causal", [("conv", False), ("conv_causal", True)])
+def test_convolution_module_vs_reference(nn_, golden, tag, causal):
+    g, x, lens, probe = block_inputs(golden)
+    m = load_det_weights(nn_.ConvolutionModule(144, 31, True, torch.nn.LeakyReLU, 0.0, causal=causal), "blk.conv.").to(DEV)
+    out = m(x, valid_lens=lens)
+    (out * probe).sum().backward()
+    close(out, g[f"{tag}:out"], 1e-4)
+    close(x.grad, g[f"{tag}:dx"], 3e-4, 2e-3)
+    assert check_grads(m, g, tag) == 10
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_convmod_core_full_width(ops, dtype, causal):
+    """D=256, T=250 (BASELINE configs[1] layer shape), ragged tile edge (250 = 7*32 + 26): HIP vs torch fp32 formula."""
+    B, Tn, D, K = 3, 250, 256, 31
+    g = torch.Generator().manual_seed(5)
+    y2 = torch.randn(B, Tn, 2 * D, generator=g).to(dtype)
+    b2, cw, cb = torch.randn(2 * D, generator=g) * 0.1, torch.randn(D, 1, K, generator=g) / K ** 0.5, torch.randn(D, generator=g) * 0.1
+    lw, lb = torch.randn(D, generator=g) * 0.1 + 1, torch.randn(D, generator=g) * 0.1
+    dz = torch.randn(B, Tn, D, generator=g).to(dtype)
+    ps = [t.clone().requires_grad_() for t in (y2.float(), b2, cw, cb, lw, lb)]
+    h = ps[0] + ps[1]
+    gl = (h[..., :D] * torch.sigmoid(h[..., D:])).transpose(1, 2)
+    gl = F.pad(gl, (K - 1, 0)) if causal else F.pad(gl, (K // 2, K // 2))
+    c = F.conv1d(gl, ps[2], ps[3], groups=D).transpose(1, 2)
+    zr = F.leaky_relu(F.layer_norm(c, (D,), ps[4], ps[5], 1e-5), 0.01)
+    zr.backward(dz.float())
+    pg = [t.to(DEV).requires_grad_() for t in (y2, b2, cw, cb, lw, lb)]
+    z = ops.convmod_core(*pg, causal, 1e-5, 0.01)
+    z.backward(dz.to(DEV))
+    lo = dtype == torch.bfloat16
+    close(z, zr.detach(), 4e-2 if lo else 1e-4, 2e-2 if lo else 1e-3)
+    for a, r, name in zip(pg, ps, ("dy2", "db2", "dcw", "dcb", "dlnw", "dlnb")):
+        rel = float((a.grad.float().cpu() - r.grad).norm() / r.grad.norm())
+        assert rel < (2e-2 if lo else 2e-4), (name, rel)
+
+
+def test_ffn_and_layer_vs_reference(nn_, golden):
+    g, x, lens, probe = block_inputs(golden)
+    for tag, causal in (("layer", False), ("layer_causal", True)):
+        x.grad = None
+        lay = load_det_weights(nn_.ConformerEncoderLayer(d_model=144, d_ffn=576, nhead=4, kernel_size=31, activation=torch.nn.LeakyReLU,
+                                                         dropout=0.0, causal=causal), "blk.layer.").to(DEV)
+        pe = nn_.RelPosEncXL(144).to(DEV)(x)
+        out, _ = lay(x, pos_embs=pe, valid_lens=lens, need_attn=False)
+        (out * probe).sum().backward()
+        close(out, g[f"{tag}:out"], 2e-4, 2e-3)
+        close(x.grad, g[f"{tag}:dx"], 1e-3, 5e-3)
+        assert check_grads(lay, g, tag, atol=2e-3, rtol=5e-3) > 20
+    # macaron half step alone: x + 0.5*FFN(x); golden holds FFN(x) and its grads
+    x2 = T(g["x"]).to(DEV).requires_grad_(True)
+    y = lay._ffn_add(x2, lay.ffn_module1)
+    close((y - x2) * 2, g["ffn:out"], 1e-4)
+
+
+@pytest.mark.parametrize("tag,use_lens,causal", [("mha_nomask", False, False), ("mha_kpm", True, False), ("mha_kpm_causal", True, True)])
+def test_relpos_mha_vs_reference(nn_, golden, tag, use_lens, causal):
+    g, x, lens, probe = block_inputs(golden)
+    m = load_det_weights(nn_.RelPosMHAXL(144, 4, dropout=0.0, mask_pos_future=causal), "blk.mha.").to(DEV)
+    pe = nn_.RelPosEncXL(144).to(DEV)(x)
+    close(pe, golden["c1_blocks"]["relpos_table"], 1e-6)
+    out, attn = m(x, x, x, pe, key_lens=lens if use_lens else None, causal=causal, return_attn_weights=True)
+    (out * probe).sum().backward()
+    close(out, g[f"{tag}:out"], 1e-4)
+    close(x.grad, g[f"{tag}:dx"], 3e-4, 2e-3)
+    assert check_grads(m, g, tag) == 6
+    if tag == "mha_kpm":
+        close(attn[1], g["mha_kpm:attn_b1"], 1e-5)

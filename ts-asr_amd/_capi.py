@@ -24,6 +24,7 @@ class TsasrHipError(RuntimeError):
 _lib = None
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+c_ll, c_ull = ctypes.c_longlong, ctypes.c_ulonglong
 
 # name -> (restype, argtypes); mirrors include/tsasr_hip.h one to one
 _PROTOS = {
@@ -36,6 +37,17 @@ _PROTOS = {
     "tsasr_rnnt_loss_workspace_bytes": (c_size_t, [c_int] * 3),
     "tsasr_rnnt_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_rnnt_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_ll, c_int, c_float, c_float, c_int, c_void_p]),
+    "tsasr_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
+    "tsasr_layernorm_bwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_bias_act_dropout_fwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_int, c_void_p]),
+    "tsasr_colpart_workspace_bytes": (c_size_t, [c_ll, c_int]),
+    "tsasr_bias_act_dropout_bwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_dropout_add_fwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p]),
+    "tsasr_dropout_add_bwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_convmod_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_int, c_void_p]),
+    "tsasr_convmod_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
+    "tsasr_convmod_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 

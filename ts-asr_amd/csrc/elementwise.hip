@@ -1,0 +1,529 @@
+// HBM-bound row kernels of the Conformer block for gfx950: LayerNorm (+fused LeakyReLU) fwd/bwd,
+// bias+LeakyReLU+dropout fwd/bwd, dropout+scale+residual(+time mask) fwd/bwd, column-sum reduction of partials.
+//
+// Replaces the ATen chains the reference issues for (SB = vendor/speechbrain/speechbrain):
+//   nn.LayerNorm / SB LayerNorm                      SB/nnet/normalization.py:172-223, Conformer.py:73,93,194-214,216-217
+//   Linear bias + activation() + Dropout             SB/nnet/attention.py:820-836 (PositionalwiseFeedForward)
+//   Dropout + 0.5*x + residual, masked_fill_ of pads Conformer.py:113-114,239-259
+// Design: every kernel is one pass, 16-byte (8 x bf16 / 4 x fp32) accesses per lane, fp32 math, one wave per row for
+// model-width rows (D <= 2048) and one workgroup per row for the front-end's [F*C] rows. Column reductions
+// (dgamma/dbeta/dbias) are two-stage and deterministic: per-workgroup partial rows, then a small column-sum kernel -
+// no float atomics. Dropout is counter-based (hash of element index and a per-call seed): the mask is never stored,
+// backward regenerates it.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// counter-based uniform bits (murmur3 finaliser over index ^ seed stream); keep iff bits >= threshold
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned rng_bits(unsigned long long idx, unsigned long long seed) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
+
+template <typename T> struct Vec;  // 16-byte vector of T
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T, int N> __device__ __forceinline__ void ldv(const T *p, float (&o)[N]);
+template <> __device__ __forceinline__ void ldv<float, 4>(const float *p, float (&o)[4]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
+template <> __device__ __forceinline__ void ldv<bf16_t, 8>(const bf16_t *p, float (&o)[8]) { ld8(p, o); }
+template <typename T, int N> __device__ __forceinline__ void stv(T *p, const float (&v)[N]);
+template <> __device__ __forceinline__ void stv<float, 4>(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void stv<bf16_t, 8>(bf16_t *p, const float (&v)[8]) { st8(p, v); }
+
+// block-wide sum for TPR (threads per row) = 64 (one wave) or 256 (one workgroup)
+template <int TPR> __device__ __forceinline__ float row_sum(float v, float *red) {
+    v = wave_sum(v);
+    if (TPR == 64) return v;
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = act(gamma * (x - mean) * rstd + beta)
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TPR, int ITERS>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, T *__restrict__ y,
+                                                            float *__restrict__ mean, float *__restrict__ rstd, long long M,
+                                                            int D, float eps, float slope) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float red[4];
+    const int rows_per_blk = 256 / TPR;
+    const long long row = (long long)blockIdx.x * rows_per_blk + threadIdx.x / TPR;
+    const int l = threadIdx.x % TPR;
+    if (TPR == 64 && row >= M) return;
+    const T *xr = x + row * D;
+    float v[ITERS][N];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * TPR + l) * N;
+        if (c < D) {
+            ldv<T, N>(xr + c, v[it]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s += v[it][j];
+        }
+    }
+    const float mu = row_sum<TPR>(s, red) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * TPR + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const float d = v[it][j] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(row_sum<TPR>(q, red) / D + eps);
+    if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+    T *yr = y + row * D;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * TPR + l) * N;
+        if (c < D) {
+            float g[N], b[N], o[N];
+            ldv<float, 4>(gamma + c, *reinterpret_cast<float(*)[4]>(&g[0]));
+            ldv<float, 4>(beta + c, *reinterpret_cast<float(*)[4]>(&b[0]));
+            if (N == 8) {
+                ldv<float, 4>(gamma + c + 4, *reinterpret_cast<float(*)[4]>(&g[N == 8 ? 4 : 0]));
+                ldv<float, 4>(beta + c + 4, *reinterpret_cast<float(*)[4]>(&b[N == 8 ? 4 : 0]));
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t = (v[it][j] - mu) * rs * g[j] + b[j];
+                if (slope >= 0.f) t = lrelu(t, slope);
+                o[j] = t;
+            }
+            stv<T, N>(yr + c, o);
+        }
+    }
+}
+
+// LayerNorm backward. Each workgroup walks `rows_per_wg` consecutive rows, keeps column partials of dgamma/dbeta in
+// registers, and writes them to part[blockIdx][2][D]; colsum_kernel finishes.
+template <typename T, int TPR, int ITERS>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            T *__restrict__ dx, float *__restrict__ part, long long M, int D,
+                                                            float slope, int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float red[4];
+    __shared__ float colred[(TPR == 64) ? 1 : 1];
+    (void)colred;
+    const int rpb = 256 / TPR;
+    const int sub = threadIdx.x / TPR, l = threadIdx.x % TPR;
+    float ag[ITERS][N], abt[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = 0.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    for (int rr = sub; rr < rows_per_wg; rr += rpb) {
+        const long long row = r0 + rr;
+        const bool live = row < M;
+        if (TPR == 64 && !live) break;
+        const T *xr = x + row * D, *dyr = dy + row * D;
+        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+        float xh[ITERS][N], gdy[ITERS][N];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * TPR + l) * N;
+            if (c < D && live) {
+                float xv[N], dv[N], g[N], b[N];
+                ldv<T, N>(xr + c, xv);
+                ldv<T, N>(dyr + c, dv);
+                ldv<float, 4>(gamma + c, *reinterpret_cast<float(*)[4]>(&g[0]));
+                if (N == 8) ldv<float, 4>(gamma + c + 4, *reinterpret_cast<float(*)[4]>(&g[N == 8 ? 4 : 0]));
+                if (slope >= 0.f) {
+                    ldv<float, 4>(beta + c, *reinterpret_cast<float(*)[4]>(&b[0]));
+                    if (N == 8) ldv<float, 4>(beta + c + 4, *reinterpret_cast<float(*)[4]>(&b[N == 8 ? 4 : 0]));
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float h = (xv[j] - mu) * rs;
+                    float d = dv[j];
+                    if (slope >= 0.f && (h * g[j] + b[j]) <= 0.f) d *= slope;  // LeakyReLU' on the pre-activation
+                    xh[it][j] = h;
+                    ag[it][j] += d * h;
+                    abt[it][j] += d;
+                    const float gd = d * g[j];
+                    gdy[it][j] = gd;
+                    s1 += gd;
+                    s2 += gd * h;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) xh[it][j] = gdy[it][j] = 0.f;
+            }
+        }
+        const float m1 = row_sum<TPR>(s1, red) / D;
+        const float m2 = row_sum<TPR>(s2, red) / D;
+        if (live) {
+            T *dxr = dx + row * D;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int c = (it * TPR + l) * N;
+                if (c < D) {
+                    float o[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) o[j] = rs * (gdy[it][j] - m1 - xh[it][j] * m2);
+                    stv<T, N>(dxr + c, o);
+                }
+            }
+        }
+    }
+    // column partials: combine the `rpb` row-slots of this workgroup through LDS, then one row per workgroup
+    extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [rpb][2][D] when rpb > 1
+    float *pw = part + (size_t)blockIdx.x * 2 * D;
+    if (rpb == 1) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * TPR + l) * N;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { pw[c + j] = ag[it][j]; pw[D + c + j] = abt[it][j]; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * TPR + l) * N;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    colbuf[(sub * 2 + 0) * D + c + j] = ag[it][j];
+                    colbuf[(sub * 2 + 1) * D + c + j] = abt[it][j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * D; i += 256) {
+            float s = 0.f;
+            for (int q = 0; q < rpb; ++q) s += colbuf[q * 2 * D + i];
+            pw[i] = s;
+        }
+    }
+}
+
+// out[c] = sum_n part[n][c]  (ncols columns, nparts rows) ; out2 optional second half (part rows are [2][D])
+__global__ void colsum_kernel(const float *__restrict__ part, float *__restrict__ out_a, float *__restrict__ out_b, int nparts,
+                              int D, int stride) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= stride) return;
+    float s = 0.f;
+    for (int n = 0; n < nparts; ++n) s += part[(size_t)n * stride + c];
+    if (c < D) { if (out_a) out_a[c] = s; }
+    else if (out_b) out_b[c - D] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y = dropout(act(x + bias))           (act = LeakyReLU(slope) when slope >= 0)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
+                                                                   T *__restrict__ y, long long total, int Ncols, float slope,
+                                                                   float p, unsigned long long seed) {
+    constexpr int N = Vec<T>::N;
+    const unsigned thr = drop_threshold(p);
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
+        float v[N];
+        ldv<T, N>(x + i, v);
+        const int c = (int)(i % Ncols);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t = v[j] + (bias ? bias[c + j] : 0.f);
+            if (slope >= 0.f) t = lrelu(t, slope);
+            if (p > 0.f) t = (rng_bits(i + j, seed) >= thr) ? t * keep_scale : 0.f;
+            v[j] = t;
+        }
+        stv<T, N>(y + i, v);
+    }
+}
+
+// dx = dy * keep/(1-p) * act'(y) ; dbias partial rows part[blockIdx][Ncols] (blocks walk whole rows)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ y,
+                                                                   T *__restrict__ dx, float *__restrict__ part, long long M,
+                                                                   int Ncols, float slope, float p, unsigned long long seed,
+                                                                   int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    const unsigned thr = drop_threshold(p);
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    for (int c = threadIdx.x * N; c < Ncols; c += 256 * N) {
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = 0.f;
+        for (int rr = 0; rr < rows_per_wg; ++rr) {
+            const long long row = r0 + rr;
+            if (row >= M) break;
+            const long long i = row * Ncols + c;
+            float d[N], yv[N];
+            ldv<T, N>(dy + i, d);
+            if (slope >= 0.f) ldv<T, N>(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float g = d[j];
+                if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                if (slope >= 0.f && yv[j] < 0.f) g *= slope;  // sign(y) = sign(pre-activation) for kept elements
+                d[j] = g;
+                acc[j] += g;
+            }
+            stv<T, N>(dx + i, d);
+        }
+        if (part) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out = res + alpha * mask_t( dropout(x + bias) )      rows = [B, T] flattened; mask_t zeroes rows t >= valid_lens[b]
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
+                                                              const T *__restrict__ res, T *__restrict__ out, long long total,
+                                                              int Ncols, float alpha, float p, unsigned long long seed,
+                                                              const int32_t *__restrict__ valid_lens, int Trows) {
+    constexpr int N = Vec<T>::N;
+    const unsigned thr = drop_threshold(p);
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
+        float v[N], r[N];
+        ldv<T, N>(x + i, v);
+        if (res) ldv<T, N>(res + i, r);
+        const long long row = i / Ncols;
+        const int c = (int)(i - row * Ncols);
+        const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t = v[j] + (bias ? bias[c + j] : 0.f);
+            if (p > 0.f) t = (rng_bits(i + j, seed) >= thr) ? t * keep_scale : 0.f;
+            t = live ? t * alpha : 0.f;
+            v[j] = (res ? r[j] : 0.f) + t;
+        }
+        stv<T, N>(out + i, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restrict__ dout, T *__restrict__ dx,
+                                                              float *__restrict__ part, long long M, int Ncols, float alpha,
+                                                              float p, unsigned long long seed,
+                                                              const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    const unsigned thr = drop_threshold(p);
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    for (int c = threadIdx.x * N; c < Ncols; c += 256 * N) {
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = 0.f;
+        for (int rr = 0; rr < rows_per_wg; ++rr) {
+            const long long row = r0 + rr;
+            if (row >= M) break;
+            const long long i = row * Ncols + c;
+            const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+            float d[N];
+            ldv<T, N>(dout + i, d);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float g = live ? d[j] * alpha : 0.f;
+                if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                d[j] = g;
+                acc[j] += g;
+            }
+            stv<T, N>(dx + i, d);
+        }
+        if (part) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------
+static int pick_rows_per_wg(long long M, int min_rows) {
+    // ~2048 workgroups (8 per CU) unless rows are few; at least `min_rows` rows each so partial slabs stay small
+    long long r = (M + 2047) / 2048;
+    if (r < min_rows) r = min_rows;
+    return (int)r;
+}
+
+template <typename T>
+static int launch_ln_fwd(const void *x, const float *g, const float *b, void *y, float *mean, float *rstd, long long M, int D,
+                         float eps, float slope, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    const int per_wave = 64 * N, per_wg = 256 * N;
+#define LN_FWD(TPR, IT)                                                                                                  \
+    layernorm_fwd_kernel<T, TPR, IT><<<(unsigned)((M + (256 / TPR) - 1) / (256 / TPR)), 256, 0, st>>>(                    \
+        (const T *)x, g, b, (T *)y, mean, rstd, M, D, eps, slope)
+    if (D <= per_wave) LN_FWD(64, 1);
+    else if (D <= 2 * per_wave) LN_FWD(64, 2);
+    else if (D <= 4 * per_wave) LN_FWD(64, 4);
+    else if (D <= 2 * per_wg) LN_FWD(256, 2);
+    else if (D <= 4 * per_wg) LN_FWD(256, 4);
+    else if (D <= 8 * per_wg) LN_FWD(256, 8);
+    else return -1;
+#undef LN_FWD
+    return 0;
+}
+
+template <typename T>
+static int launch_ln_bwd(const void *dy, const void *x, const float *g, const float *b, const float *mean, const float *rstd,
+                         void *dx, float *part, long long M, int D, float slope, int rpw, int nwg, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    const int per_wave = 64 * N, per_wg = 256 * N;
+#define LN_BWD(TPR, IT)                                                                                                  \
+    layernorm_bwd_kernel<T, TPR, IT><<<nwg, 256, (TPR == 64 ? (size_t)4 * 2 * D * sizeof(float) : 0), st>>>(             \
+        (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
+    if (D <= per_wave) LN_BWD(64, 1);
+    else if (D <= 2 * per_wave) LN_BWD(64, 2);
+    else if (D <= 4 * per_wave) LN_BWD(64, 4);
+    else if (D <= 2 * per_wg) LN_BWD(256, 2);
+    else if (D <= 4 * per_wg) LN_BWD(256, 4);
+    else if (D <= 8 * per_wg) LN_BWD(256, 8);
+    else return -1;
+#undef LN_BWD
+    return 0;
+}
+
+extern "C" {
+
+int tsasr_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                        long long M, int D, float eps, float act_slope, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(x && gamma && beta && y && mean && rstd, "tsasr_layernorm_fwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_layernorm_fwd: bad shape M=%lld D=%d (D %% 8 == 0 required)", M, D);
+    int rc = io_dtype == TSASR_F32 ? launch_ln_fwd<float>(x, gamma, beta, y, mean, rstd, M, D, eps, act_slope, (hipStream_t)stream)
+           : io_dtype == TSASR_BF16 ? launch_ln_fwd<bf16_t>(x, gamma, beta, y, mean, rstd, M, D, eps, act_slope, (hipStream_t)stream)
+                                    : -2;
+    TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_fwd: D=%d too large or bad io_dtype %d", D, io_dtype);
+    TSASR_CHECK_LAUNCH("tsasr_layernorm_fwd");
+    return 0;
+}
+
+size_t tsasr_layernorm_bwd_workspace_bytes(long long M, int D) {
+    const int rpw = pick_rows_per_wg(M, 8);
+    const long long nwg = (M + rpw - 1) / rpw;
+    return align_up((size_t)nwg * 2 * D * sizeof(float), 256);
+}
+
+int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
+                        const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                        int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && workspace, "tsasr_layernorm_bwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_layernorm_bwd: bad shape");
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_layernorm_bwd_workspace_bytes(M, D), "tsasr_layernorm_bwd: workspace too small");
+    const int rpw = pick_rows_per_wg(M, 8);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    int rc = io_dtype == TSASR_F32 ? launch_ln_bwd<float>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
+           : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
+                                    : -2;
+    TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_bwd: D=%d too large or bad io_dtype %d", D, io_dtype);
+    colsum_kernel<<<cdiv(2 * D, 256), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
+    TSASR_CHECK_LAUNCH("tsasr_layernorm_bwd");
+    return 0;
+}
+
+static unsigned ew_grid(long long total, int N) {
+    long long blocks = (total / N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;  // grid-stride beyond 16 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int tsasr_bias_act_dropout_fwd(const void *x, const float *bias, void *y, long long M, int N, float act_slope, float p,
+                               unsigned long long seed, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(x && y, "tsasr_bias_act_dropout_fwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_bias_act_dropout_fwd: bad shape/p (M=%lld N=%d p=%f)", M, N, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32)
+        bias_act_dropout_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (float *)y, M * N, N, act_slope, p, seed);
+    else if (io_dtype == TSASR_BF16)
+        bias_act_dropout_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (bf16_t *)y, M * N, N, act_slope, p, seed);
+    else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+    TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_fwd");
+    return 0;
+}
+
+size_t tsasr_colpart_workspace_bytes(long long M, int N) {
+    const int rpw = pick_rows_per_wg(M, 16);
+    return align_up((size_t)((M + rpw - 1) / rpw) * N * sizeof(float), 256);
+}
+
+int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, long long M, int N, float act_slope,
+                               float p, unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    TSASR_CHECK_ARG(dy && dx && (act_slope < 0.f || y), "tsasr_bias_act_dropout_bwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "tsasr_bias_act_dropout_bwd: bad shape");
+    TSASR_CHECK_ARG(!dbias || (workspace && workspace_bytes >= tsasr_colpart_workspace_bytes(M, N)), "tsasr_bias_act_dropout_bwd: workspace too small");
+    const int rpw = pick_rows_per_wg(M, 16);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    float *part = dbias ? (float *)workspace : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32)
+        bias_act_dropout_bwd_kernel<float><<<nwg, 256, 0, st>>>((const float *)dy, (const float *)y, (float *)dx, part, M, N, act_slope, p, seed, rpw);
+    else if (io_dtype == TSASR_BF16)
+        bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, rpw);
+    else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+    if (dbias) colsum_kernel<<<cdiv(N, 256), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_bwd");
+    return 0;
+}
+
+int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
+                          float p, unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(x && out, "tsasr_dropout_add_fwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_dropout_add_fwd: bad shape/p");
+    TSASR_CHECK_ARG(!valid_lens || (Trows > 0 && M % Trows == 0), "tsasr_dropout_add_fwd: rows %lld not a multiple of T=%d", M, Trows);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32)
+        dropout_add_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (const float *)res, (float *)out, M * N, N, alpha, p, seed, valid_lens, Trows);
+    else if (io_dtype == TSASR_BF16)
+        dropout_add_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)out, M * N, N, alpha, p, seed, valid_lens, Trows);
+    else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+    TSASR_CHECK_LAUNCH("tsasr_dropout_add_fwd");
+    return 0;
+}
+
+int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
+                          unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dout && dx, "tsasr_dropout_add_bwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "tsasr_dropout_add_bwd: bad shape");
+    TSASR_CHECK_ARG(!dbias || (workspace && workspace_bytes >= tsasr_colpart_workspace_bytes(M, N)), "tsasr_dropout_add_bwd: workspace too small");
+    const int rpw = pick_rows_per_wg(M, 16);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    float *part = dbias ? (float *)workspace : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32)
+        dropout_add_bwd_kernel<float><<<nwg, 256, 0, st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+    else if (io_dtype == TSASR_BF16)
+        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+    else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+    if (dbias) colsum_kernel<<<cdiv(N, 256), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
+    return 0;
+}
+
+}  // extern "C"

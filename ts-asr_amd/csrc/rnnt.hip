@@ -558,11 +558,11 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32) {
         if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)joint_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)joint_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         joint_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)enc, (const float *)dec, W, bias, logits, T, U1, J, V, ldl, slope);
     } else if (io_dtype == TSASR_BF16) {
         if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)joint_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)joint_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         joint_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, J, V, ldl, slope);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_joint_fwd: bad io_dtype %d", io_dtype);

@@ -312,13 +312,20 @@ class RelPosMHAXL(nn.Module):
             key_lens = (~key_padding_mask).sum(-1).to(torch.int32)
         if causal is None:
             causal = attn_mask is not None
-        x = _cd(query)
-        qkv = ops.linear(x, self.in_proj_weight, None)                      # [B,T,H*3*Dh] per-head interleaved Q|K|V
-        pk = ops.linear(_cd(pos_embs[0]), self.linear_pos.weight, None)     # [2T-1, D]
-        o, attn = ops.relpos_attention(qkv, pk, self.pos_bias_u, self.pos_bias_v, key_lens, self.num_heads, self.scale,
-                                       causal, self.dropout if self.training else 0.0, return_attn_weights)
+        o, attn = self._context(_cd(query), pos_embs, key_lens, causal, return_attn_weights)
         out = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
         return (out, attn) if return_attn_weights else out
+
+    def _context(self, x, pos_embs, key_lens, causal, need_weights):
+        qkv = ops.matmul_nt(x, self.in_proj_weight)                          # [B,T,H*3*Dh] per-head interleaved Q|K|V
+        pk = ops.matmul_nt(_cd(pos_embs[0]), self.linear_pos.weight)         # [2T-1, D]
+        return ops.relpos_attention(qkv, pk, self.pos_bias_u, self.pos_bias_v, key_lens, self.num_heads, self.scale, causal,
+                                    self.dropout if self.training else 0.0, need_weights)
+
+    def forward_add(self, x, res, pos_embs, key_lens=None, causal=False, need_weights=False):
+        """res + out_proj(attention(x)) with the projection bias and the residual add in one epilogue pass."""
+        o, attn = self._context(_cd(x), pos_embs, key_lens, causal, need_weights)
+        return ops.dropout_add(ops.matmul_nt(o, self.out_proj.weight), self.out_proj.bias, res), attn
 
 
 class PositionalwiseFeedForward(nn.Module):
@@ -357,15 +364,16 @@ class ConvolutionModule(nn.Module):
         """``valid_lens`` int32 [B] replaces the boolean pad mask ([B,T,1], True = padded) of the reference."""
         if valid_lens is None and mask is not None:
             valid_lens = (~mask.squeeze(-1)).sum(-1).to(torch.int32)
+        return self.forward_add(x, None, valid_lens)
+
+    def forward_add(self, x, res, valid_lens=None):
+        """res + module(x) with dropout, pad masking and the residual add fused into the last pass."""
         y = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5)
-        y = ops.linear(y, self.bottleneck[0].weight.squeeze(-1), self.bottleneck[0].bias)          # 1x1 conv D->2D
-        y = ops.glu_dwconv_ln_act(y, self.conv.weight, self.conv.bias, self.after_conv[0].weight, self.after_conv[0].bias,
-                                  self.causal, 1e-5, self.slope)                                     # GLU+depthwise+LN+act
-        y = ops.linear(y, self.after_conv[2].weight, self.after_conv[2].bias)
-        y = F.dropout(y, self.dropout, self.training)
-        if valid_lens is not None:
-            y = ops.mask_time(y, valid_lens)
-        return y
+        y = ops.matmul_nt(y, self.bottleneck[0].weight.squeeze(-1))                                # 1x1 conv D->2D (bias below)
+        y = ops.convmod_core(y, self.bottleneck[0].bias, self.conv.weight, self.conv.bias, self.after_conv[0].weight,
+                             self.after_conv[0].bias, self.causal, 1e-5, self.slope)                # bias+GLU+depthwise+LN+act
+        y = ops.matmul_nt(y, self.after_conv[2].weight)
+        return ops.dropout_add(y, self.after_conv[2].bias, res, 1.0, self.dropout, self.training, valid_lens)
 
 
 class ConformerEncoderLayer(nn.Module):
@@ -383,26 +391,22 @@ class ConformerEncoderLayer(nn.Module):
         self.drop = nn.Dropout(dropout)
         self.causal, self.dropout, self.slope = causal, dropout, _act_slope(activation)
 
-    def _ffn(self, x, mod):
+    def _ffn_add(self, x, mod):
+        """x + 0.5 * Dropout(PFF(LN(x)))  - macaron half-step (Conformer.py:243,258)."""
         ln, pff = mod[0], mod[1].ffn
         y = ops.layer_norm(x, ln.weight, ln.bias, 1e-5)
-        y = ops.linear(y, pff[0].weight, pff[0].bias, act_slope=self.slope)
-        y = F.dropout(y, self.dropout, self.training)
-        y = ops.linear(y, pff[3].weight, pff[3].bias)
-        return F.dropout(y, self.dropout, self.training)
+        y = ops.linear(y, pff[0].weight, pff[0].bias, self.slope, self.dropout, self.training)   # GEMM + bias/LeakyReLU/dropout pass
+        y = ops.matmul_nt(y, pff[3].weight)
+        return ops.dropout_add(y, pff[3].bias, x, 0.5, self.dropout, self.training)
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True):
         """Returns (x, attention weights [B,H,T,T] or None). The reference always materialises the weights
         (Conformer.py:247-254); the encoder passes need_attn=False unless return_attn is requested."""
         if valid_lens is None and src_key_padding_mask is not None:
             valid_lens = (~src_key_padding_mask).sum(-1).to(torch.int32)
-        x = x + 0.5 * self._ffn(x, self.ffn_module1)
+        x = self._ffn_add(x, self.ffn_module1)
         y = self.norm1(x)
-        y, attn = self.mha_layer(y, y, y, pos_embs, key_lens=valid_lens, causal=self.causal or src_mask is not None,
-                                 return_attn_weights=True) if need_attn else (
-            self.mha_layer(y, y, y, pos_embs, key_lens=valid_lens, causal=self.causal or src_mask is not None,
-                           return_attn_weights=False), None)
-        x = y + x
-        x = x + self.convolution_module(x, valid_lens=valid_lens)
-        x = self.norm2(x + 0.5 * self._ffn(x, self.ffn_module2))
+        x, attn = self.mha_layer.forward_add(y, x, pos_embs, valid_lens, self.causal or src_mask is not None, need_attn)
+        x = self.convolution_module.forward_add(x, x, valid_lens)
+        x = self.norm2(self._ffn_add(x, self.ffn_module2))
         return x, attn

@@ -12,13 +12,30 @@ import torch
 import torch.nn.functional as F
 
 from . import _capi as C
+from . import prof
 
 STATUS = {
-    "joint_logits": "HIP", "rnnt_loss": "HIP",
-    "linear": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "frontend_conv": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
-    "layer_norm": "GLUE", "layer_norm2": "GLUE", "sentence_norm": "GLUE", "relpos_attention": "GLUE",
-    "glu_dwconv_ln_act": "GLUE", "mask_time": "GLUE",
+    "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
+    "convmod_core": "HIP",
+    "matmul": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "frontend_conv": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
+    "sentence_norm": "GLUE", "relpos_attention": "GLUE",
 }
+
+_seed_counter = [0]
+
+
+def next_seed():
+    """Fresh 64-bit dropout seed per call: torch's global seed + a call counter (so torch.manual_seed makes runs repeatable)."""
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _f32(p):
+    return p if p.dtype == torch.float32 else p.float()
 
 
 def _w(p, like):
@@ -27,11 +44,16 @@ def _w(p, like):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def linear(x, weight, bias=None, act_slope=None):
-    y = F.linear(x, _w(weight, x), _w(bias, x))
-    if act_slope is not None:
-        y = F.leaky_relu(y, act_slope)
-    return y
+def matmul_nt(x, weight):
+    """x @ weight^T : plain library GEMM (hipBLASLt through PyTorch-ROCm), weight cast to the activation dtype."""
+    return F.linear(x, _w(weight, x))
+
+
+def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
+    """Library GEMM + ONE hand-written epilogue pass (bias, LeakyReLU, dropout); bias-only rows ride the GEMM epilogue."""
+    if act_slope is None and not (training and dropout_p > 0):
+        return F.linear(x, _w(weight, x), _w(bias, x))
+    return bias_act_dropout(matmul_nt(x, weight), bias, act_slope, dropout_p, training)
 
 
 def lstm(x, rnn, hx=None):
@@ -40,23 +62,139 @@ def lstm(x, rnn, hx=None):
     return out.to(x.dtype), hn
 
 
-def layer_norm(x, weight, bias, eps):
-    return F.layer_norm(x.float(), weight.shape, weight, bias, eps).to(x.dtype)
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, slope):
+        C.require_gpu(x, weight, bias)
+        D = weight.numel()
+        xc = x.contiguous()
+        M = xc.numel() // D
+        g, b = _f32(weight).reshape(-1).contiguous(), _f32(bias).reshape(-1).contiguous()
+        y = torch.empty_like(xc)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        with prof.region("layernorm_fwd"):
+            C.check(C.lib().tsasr_layernorm_fwd(C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(y), C.ptr(mean), C.ptr(rstd), M, D, float(eps),
+                                                float(slope), C.io_dtype(xc), C.stream_ptr()), "tsasr_layernorm_fwd")
+        ctx.save_for_backward(xc, g, b, mean, rstd)
+        ctx.slope, ctx.wshape, ctx.wdtype = float(slope), weight.shape, weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, g, b, mean, rstd = ctx.saved_tensors
+        D = g.numel()
+        M = xc.numel() // D
+        dy = dy.contiguous()
+        dx = torch.empty_like(xc)
+        dg, db = torch.empty_like(g), torch.empty_like(b)
+        ws = _ws(C.lib().tsasr_layernorm_bwd_workspace_bytes(M, D), xc.device)
+        with prof.region("layernorm_bwd"):
+            C.check(C.lib().tsasr_layernorm_bwd(C.ptr(dy), C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(mean), C.ptr(rstd), C.ptr(dx), C.ptr(dg),
+                                                C.ptr(db), M, D, ctx.slope, C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                    "tsasr_layernorm_bwd")
+        return dx, dg.view(ctx.wshape).to(ctx.wdtype), db.view(ctx.wshape).to(ctx.wdtype), None, None
+
+
+def layer_norm(x, weight, bias, eps, act_slope=None):
+    """LayerNorm over the trailing dims covered by ``weight`` (1-D model width or the front-end's [F, C]),
+    optionally fused with the LeakyReLU that follows it."""
+    return _LayerNormFn.apply(x, weight, bias, eps, -1.0 if act_slope is None else act_slope)
 
 
 def layer_norm2(x, weight, bias, eps, act_slope=None):
-    """LayerNorm over the last TWO dims ([F, C] of the front-end), optional fused LeakyReLU."""
-    y = F.layer_norm(x.float(), weight.shape, weight, bias, eps)
-    if act_slope is not None:
-        y = F.leaky_relu(y, act_slope)
-    return y.to(x.dtype)
+    return layer_norm(x, weight, bias, eps, act_slope)
+
+
+class _BiasActDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, slope, p, seed):
+        C.require_gpu(x)
+        xc = x.contiguous()
+        N = xc.shape[-1]
+        M = xc.numel() // N
+        b = None if bias is None else _f32(bias).contiguous()
+        y = torch.empty_like(xc)
+        with prof.region("bias_act_dropout_fwd"):
+            C.check(C.lib().tsasr_bias_act_dropout_fwd(C.ptr(xc), C.ptr(b), C.ptr(y), M, N, float(slope), float(p), seed,
+                                                       C.io_dtype(xc), C.stream_ptr()), "tsasr_bias_act_dropout_fwd")
+        ctx.save_for_backward(y)
+        ctx.cfg = (float(slope), float(p), seed, bias is not None, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        slope, p, seed, has_bias, bdtype = ctx.cfg
+        N = y.shape[-1]
+        M = y.numel() // N
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        db = torch.empty(N, dtype=torch.float32, device=y.device) if has_bias else None
+        ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), y.device) if has_bias else None
+        with prof.region("bias_act_dropout_bwd"):
+            C.check(C.lib().tsasr_bias_act_dropout_bwd(C.ptr(dy), C.ptr(y), C.ptr(dx), C.ptr(db), M, N, slope, p, seed, C.io_dtype(y),
+                                                       C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                    "tsasr_bias_act_dropout_bwd")
+        return dx, (db.to(bdtype) if has_bias else None), None, None, None
+
+
+def bias_act_dropout(x, bias, act_slope, p, training):
+    """dropout_p(LeakyReLU(x + bias)) in one pass (act_slope None = no activation)."""
+    p = float(p) if training else 0.0
+    return _BiasActDropoutFn.apply(x, bias, -1.0 if act_slope is None else act_slope, p, next_seed() if p > 0 else 0)
+
+
+class _DropoutAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, res, alpha, p, seed, valid_lens, trows):
+        C.require_gpu(x)
+        xc = x.contiguous()
+        N = xc.shape[-1]
+        M = xc.numel() // N
+        b = None if bias is None else _f32(bias).contiguous()
+        r = None
+        if res is not None:
+            r = res.expand_as(xc).contiguous() if res.shape != xc.shape else res.contiguous()
+        out = torch.empty_like(xc)
+        with prof.region("dropout_add_fwd"):
+            C.check(C.lib().tsasr_dropout_add_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(out), M, N, float(alpha), float(p), seed,
+                                                  C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()), "tsasr_dropout_add_fwd")
+        ctx.save_for_backward(valid_lens)
+        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias is not None, None if bias is None else bias.dtype,
+                   None if res is None else res.shape, xc.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (valid_lens,) = ctx.saved_tensors
+        alpha, p, seed, trows, has_bias, bdtype, rshape, xshape = ctx.cfg
+        dout = dout.contiguous()
+        N = xshape[-1]
+        M = dout.numel() // N
+        dx = torch.empty_like(dout)
+        db = torch.empty(N, dtype=torch.float32, device=dout.device) if has_bias else None
+        ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), dout.device) if has_bias else None
+        with prof.region("dropout_add_bwd"):
+            C.check(C.lib().tsasr_dropout_add_bwd(C.ptr(dout), C.ptr(dx), C.ptr(db), M, N, alpha, p, seed, C.ptr(valid_lens), trows,
+                                                  C.io_dtype(dout), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                    "tsasr_dropout_add_bwd")
+        dres = None
+        if rshape is not None:
+            dres = dout if tuple(rshape) == tuple(xshape) else dout.sum_to_size(rshape)
+        return dx, (db.to(bdtype) if has_bias else None), dres, None, None, None, None, None
+
+
+def dropout_add(x, bias=None, res=None, alpha=1.0, p=0.0, training=False, valid_lens=None):
+    """res + alpha * timemask(dropout_p(x + bias)); x is [B, T, N] when valid_lens (int32 [B]) is given."""
+    p = float(p) if training else 0.0
+    trows = x.shape[-2] if valid_lens is not None else 0
+    return _DropoutAddFn.apply(x, bias, res, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows)
 
 
 def mask_time(x, valid_lens):
     """Zero frames t >= valid_lens[b] of x [B,T,D] (ConvolutionModule's masked_fill_, Conformer.py:113-114)."""
-    T = x.shape[1]
-    keep = torch.arange(T, device=x.device)[None, :] < valid_lens[:, None]
-    return x * keep.unsqueeze(-1).to(x.dtype)
+    return dropout_add(x, None, None, 1.0, 0.0, False, valid_lens)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -121,13 +259,51 @@ def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal
     return o, (attn if need_weights else None)
 
 
+class _ConvModCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y2, b2, conv_w, conv_b, ln_w, ln_b, causal, eps, slope):
+        C.require_gpu(y2)
+        y2c = y2.contiguous()
+        B, T, D2 = y2c.shape
+        D, K = D2 // 2, conv_w.shape[-1]
+        f = lambda t: None if t is None else _f32(t).contiguous()  # noqa: E731
+        b2f, cw, cb, g, be = f(b2), f(conv_w).reshape(D, K), f(conv_b), f(ln_w), f(ln_b)
+        z = torch.empty(B, T, D, dtype=y2c.dtype, device=y2c.device)
+        c_save = torch.empty_like(z)
+        mean = torch.empty(B * T, dtype=torch.float32, device=y2c.device)
+        rstd = torch.empty_like(mean)
+        with prof.region("convmod_fwd"):
+            C.check(C.lib().tsasr_convmod_fwd(C.ptr(y2c), C.ptr(b2f), C.ptr(cw), C.ptr(cb), C.ptr(g), C.ptr(be), C.ptr(z), C.ptr(c_save),
+                                              C.ptr(mean), C.ptr(rstd), B, T, D, K, int(bool(causal)), float(eps), float(slope),
+                                              C.io_dtype(y2c), C.stream_ptr()), "tsasr_convmod_fwd")
+        ctx.save_for_backward(y2c, b2f, cw, g, be, c_save, mean, rstd)
+        ctx.cfg = (bool(causal), float(slope), b2 is not None, conv_w.shape, [t.dtype for t in (conv_w, conv_b, ln_w, ln_b)],
+                   None if b2 is None else b2.dtype)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y2c, b2f, cw, g, be, c_save, mean, rstd = ctx.saved_tensors
+        causal, slope, has_b2, wshape, dts, b2dt = ctx.cfg
+        B, T, D2 = y2c.shape
+        D, K = D2 // 2, cw.shape[-1]
+        dz = dz.contiguous()
+        dy2 = torch.empty_like(y2c)
+        dpar = torch.empty(D * (K + 5), dtype=torch.float32, device=y2c.device)
+        ws = _ws(C.lib().tsasr_convmod_bwd_workspace_bytes(B, T, D, K), y2c.device)
+        with prof.region("convmod_bwd"):
+            C.check(C.lib().tsasr_convmod_bwd(C.ptr(dz), C.ptr(y2c), C.ptr(b2f), C.ptr(cw), C.ptr(g), C.ptr(be), C.ptr(c_save), C.ptr(mean),
+                                              C.ptr(rstd), C.ptr(dy2), C.ptr(dpar), B, T, D, K, int(causal), slope, C.io_dtype(y2c),
+                                              C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_convmod_bwd")
+        dg, dbe, dcb, db2, dcw = dpar[:D], dpar[D:2 * D], dpar[2 * D:3 * D], dpar[3 * D:5 * D], dpar[5 * D:]
+        return (dy2, db2.to(b2dt) if has_b2 else None, dcw.view(wshape).to(dts[0]), dcb.to(dts[1]), dg.to(dts[2]), dbe.to(dts[3]),
+                None, None, None)
+
+
+def convmod_core(y2, b2, conv_w, conv_b, ln_w, ln_b, causal, eps, slope):
+    """y2 [B,T,2D] (bottleneck GEMM output, bias b2 folded in here) -> LeakyReLU(LN(depthwise_conv(GLU(y2 + b2)))) [B,T,D]."""
+    return _ConvModCoreFn.apply(y2, b2, conv_w, conv_b, ln_w, ln_b, causal, eps, slope)
+
+
 def glu_dwconv_ln_act(y2, conv_w, conv_b, ln_w, ln_b, causal, eps, slope):
-    """y2 [B,T,2D] -> GLU -> depthwise conv over time (K taps, 'same' or causal left pad) -> LayerNorm(D) -> LeakyReLU."""
-    D = y2.shape[-1] // 2
-    K = conv_w.shape[-1]
-    g = y2[..., :D] * torch.sigmoid(y2[..., D:])
-    gt = g.transpose(1, 2)
-    gt = F.pad(gt, (K - 1, 0)) if causal else F.pad(gt, ((K - 1) // 2, (K - 1) // 2))
-    c = F.conv1d(gt, _w(conv_w, y2), _w(conv_b, y2), groups=D).transpose(1, 2)
-    c = F.layer_norm(c.float(), (D,), ln_w, ln_b, eps)
-    return F.leaky_relu(c, slope).to(y2.dtype)
+    return convmod_core(y2, None, conv_w, conv_b, ln_w, ln_b, causal, eps, slope)
