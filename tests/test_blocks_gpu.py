@@ -31,6 +31,8 @@ def T(x):
 
 
 def close(a, b, atol, rtol=1e-3):
+    if isinstance(b, torch.Tensor):
+        b = b.detach().float().cpu().numpy()
     np.testing.assert_allclose(a.detach().float().cpu().numpy(), np.asarray(b), atol=atol, rtol=rtol)
 
 
