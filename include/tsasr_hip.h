@@ -126,6 +126,23 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
                       const void *c_save, const float *mean, const float *rstd, void *dy2, float *dparams, int B, int T, int D,
                       int K, int causal, float slope, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutional front-end (SB/lobes/models/convolution.py:103-266, Conv2d.forward SB/nnet/CNN.py:629-711): stride-2 3x3
+ * conv ('same' = reflect padding, or causal = (2,0) zero pad on time, (1,1) on frequency) + 1x1 stride-2 residual conv.
+ * Tensors are the reference's [B,T,F,C]. Block 1 (C_in = 1) is a direct kernel producing both branches; for wider inputs
+ * the taps are gathered (im2col, column order (kt,kf,c)) so that the contraction is a plain library GEMM, and col2im is the
+ * deterministic inverse gather-sum for the input gradient (dR = gradient of the 1x1 branch w.r.t. its sub-sampled input).
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_frontend_out_len(int n);
+int tsasr_frontend_c1_fwd(const void *x, const float *w1, const float *b1, const float *w2, const float *b2, void *y1, void *y2,
+                          int B, int T, int F, int C, int causal, int io_dtype, void *stream);
+size_t tsasr_frontend_c1_bwd_workspace_bytes(int C);
+int tsasr_frontend_c1_bwd(const void *x, const void *dy1, const void *dy2, float *dparams, int B, int T, int F, int C, int causal,
+                          int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+int tsasr_frontend_im2col(const void *x, void *A, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
+int tsasr_frontend_col2im(const void *dA, const void *dR, void *dx, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

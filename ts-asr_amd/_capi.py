@@ -48,6 +48,12 @@ _PROTOS = {
     "tsasr_convmod_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_int, c_void_p]),
     "tsasr_convmod_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_convmod_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_frontend_out_len": (c_int, [c_int]),
+    "tsasr_frontend_c1_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    "tsasr_frontend_c1_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "tsasr_frontend_c1_bwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_frontend_im2col": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
+    "tsasr_frontend_col2im": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
 }
 
 

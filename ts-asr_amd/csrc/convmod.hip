@@ -208,12 +208,16 @@ __global__ __launch_bounds__(256) void convmod_bwd_kernel(const T *__restrict__ 
     }
 }
 
-__global__ void convmod_colsum_kernel(const float *__restrict__ slab, float *__restrict__ out, int nparts, int width) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+__global__ __launch_bounds__(256) void convmod_colsum_kernel(const float *__restrict__ slab, float *__restrict__ out, int nparts,
+                                                             int width) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float s = 0.f;
-    for (int n = 0; n < nparts; ++n) s += slab[(size_t)n * width + c];
-    out[c] = s;
+    if (col < width)
+        for (int n = slice; n < nparts; n += 4) s += slab[(size_t)n * width + col];
+    red[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && col < width) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 template <typename T, int K>
@@ -275,7 +279,7 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
     else if (io_dtype == TSASR_BF16) CM_BK(bf16_t);
     else TSASR_CHECK_ARG(false, "tsasr_convmod_bwd: bad io_dtype %d", io_dtype);
     const int width = D * (K + 5), nparts = B * cdiv(T, CM_TT);
-    convmod_colsum_kernel<<<cdiv(width, 256), 256, 0, st>>>(slab, dparams, nparts, width);
+    convmod_colsum_kernel<<<cdiv(width, 64), 256, 0, st>>>(slab, dparams, nparts, width);
     TSASR_CHECK_LAUNCH("tsasr_convmod_bwd");
     return 0;
 }

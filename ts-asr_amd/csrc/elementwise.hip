@@ -219,15 +219,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
     }
 }
 
-// out[c] = sum_n part[n][c]  (ncols columns, nparts rows) ; out2 optional second half (part rows are [2][D])
-__global__ void colsum_kernel(const float *__restrict__ part, float *__restrict__ out_a, float *__restrict__ out_b, int nparts,
-                              int D, int stride) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= stride) return;
+// out[c] = sum_n part[n][c]: 64 columns x 4 row-slices per workgroup, slices combined through LDS (fixed order ->
+// deterministic). part rows are `stride` wide; columns [0,D) go to out_a, [D,stride) to out_b.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ part, float *__restrict__ out_a,
+                                                     float *__restrict__ out_b, int nparts, int D, int stride) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float s = 0.f;
-    for (int n = 0; n < nparts; ++n) s += part[(size_t)n * stride + c];
-    if (c < D) { if (out_a) out_a[c] = s; }
-    else if (out_b) out_b[c - D] = s;
+    if (col < stride)
+        for (int n = slice; n < nparts; n += 4) s += part[(size_t)n * stride + col];
+    red[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && col < stride) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (col < D) { if (out_a) out_a[col] = s; }
+        else if (out_b) out_b[col - D] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -362,8 +369,8 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
 static int pick_rows_per_wg(long long M, int min_rows) {
-    // ~2048 workgroups (8 per CU) unless rows are few; at least `min_rows` rows each so partial slabs stay small
-    long long r = (M + 2047) / 2048;
+    // ~512 workgroups (2 per CU) unless rows are few; at least `min_rows` rows each so partial slabs stay small
+    long long r = (M + 511) / 512;
     if (r < min_rows) r = min_rows;
     return (int)r;
 }
@@ -440,7 +447,7 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
            : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
                                     : -2;
     TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_bwd: D=%d too large or bad io_dtype %d", D, io_dtype);
-    colsum_kernel<<<cdiv(2 * D, 256), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
+    colsum_kernel<<<cdiv(2 * D, 64), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
     TSASR_CHECK_LAUNCH("tsasr_layernorm_bwd");
     return 0;
 }
@@ -486,7 +493,7 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
     else if (io_dtype == TSASR_BF16)
         bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 256), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) colsum_kernel<<<cdiv(N, 64), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_bwd");
     return 0;
 }
@@ -521,7 +528,7 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     else if (io_dtype == TSASR_BF16)
         dropout_add_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 256), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) colsum_kernel<<<cdiv(N, 64), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
     return 0;
 }

@@ -217,12 +217,11 @@ class ConvBlock(nn.Module):
         """x [B,T,F,C] (channels-last all the way: this IS the NHWC layout of a conv over (T,F))."""
         c, n = self.convs.conv_0.conv, self.convs.norm_0.norm
         rc, rn = self.reduce_conv.conv.conv, self.reduce_conv.norm.norm
-        y = ops.frontend_conv(x, c.weight, c.bias, self.k, self.stride, self.padding)
-        y = ops.layer_norm2(y, n.weight, n.bias, 1e-5, act_slope=0.01)
-        y = F.dropout(y, dropout, training)
-        r = ops.frontend_conv(x, rc.weight, rc.bias, 1, self.stride, "same")
-        r = ops.layer_norm2(r, rn.weight, rn.bias, 1e-5)
-        return F.dropout(y + r, dropout, training)
+        y, r = ops.frontend_convs(x, c.weight, c.bias, rc.weight, rc.bias, self.padding)
+        y = ops.layer_norm(y, n.weight, n.bias, 1e-5, act_slope=0.01)               # LN over [F,C] + LeakyReLU, one pass
+        r = ops.layer_norm(r, rn.weight, rn.bias, 1e-5)
+        y = ops.dropout_add(y, None, r, 1.0, dropout, training)                      # r + Dropout(y)
+        return ops.bias_act_dropout(y, None, None, dropout, training) if (training and dropout > 0) else y
 
 
 class ConvolutionFrontEnd(nn.Module):

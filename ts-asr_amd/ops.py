@@ -17,7 +17,8 @@ from . import prof
 STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
-    "matmul": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "frontend_conv": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
+    "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
+    "matmul": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
     "sentence_norm": "GLUE", "relpos_attention": "GLUE",
 }
 
@@ -217,20 +218,94 @@ def sentence_norm(x, abs_lens, eps):
     return (x - mean) / torch.clamp(var.sqrt(), min=eps)
 
 
-def frontend_conv(x, weight, bias, k, stride, padding):
-    """x [B,T,F,Cin] channels-last -> [B,T',F',Cout]. The reference convolves [B,C,F,T] (SB/nnet/CNN.py:629-676):
-    its kernel axes are (F, T); here the tensor is viewed [B,C,T,F] so the kernel is transposed instead."""
-    xin = x.permute(0, 3, 1, 2)  # [B,C,T,F] view of NHWC memory
-    if k > 1:
-        if padding == "same":
-            xin = F.pad(xin, (k // 2, k // 2, k // 2, k // 2), mode="reflect")
-        elif padding == "causal":
-            xin = F.pad(xin, (k // 2, k // 2, k - 1, 0))
-        else:
-            raise ValueError("Padding must be 'same' or 'causal'. Got " + str(padding))
-    w = _w(weight, x).transpose(2, 3)
-    y = F.conv2d(xin, w, _w(bias, x), stride=stride)
-    return y.permute(0, 2, 3, 1)  # [B,T',F',Cout]
+def _out_len(n):
+    return (n - 1) // 2 + 1
+
+
+class _FrontendC1Fn(torch.autograd.Function):
+    """Block 1 (one input channel): 3x3 stride-2 conv and 1x1 stride-2 residual conv in one direct HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, causal):
+        C.require_gpu(x)
+        xc = x.contiguous()
+        B, T, Fq = xc.shape
+        Co = w1.shape[0]
+        f = lambda t: _f32(t).contiguous()  # noqa: E731
+        y1 = torch.empty(B, _out_len(T), _out_len(Fq), Co, dtype=xc.dtype, device=xc.device)
+        y2 = torch.empty_like(y1)
+        with prof.region("frontend_c1_fwd"):
+            C.check(C.lib().tsasr_frontend_c1_fwd(C.ptr(xc), C.ptr(f(w1)), C.ptr(f(b1)), C.ptr(f(w2)), C.ptr(f(b2)), C.ptr(y1), C.ptr(y2),
+                                                  B, T, Fq, Co, int(causal), C.io_dtype(xc), C.stream_ptr()), "tsasr_frontend_c1_fwd")
+        ctx.save_for_backward(xc)
+        ctx.cfg = (bool(causal), Co, w1.shape, w2.shape, [t.dtype for t in (w1, b1, w2, b2)])
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        (xc,) = ctx.saved_tensors
+        causal, Co, s1, s2, dts = ctx.cfg
+        B, T, Fq = xc.shape
+        dpar = torch.empty(Co * 12, dtype=torch.float32, device=xc.device)
+        ws = _ws(C.lib().tsasr_frontend_c1_bwd_workspace_bytes(Co), xc.device)
+        with prof.region("frontend_c1_bwd"):
+            C.check(C.lib().tsasr_frontend_c1_bwd(C.ptr(xc), C.ptr(dy1.contiguous()), C.ptr(dy2.contiguous()), C.ptr(dpar), B, T, Fq, Co,
+                                                  int(causal), C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_frontend_c1_bwd")
+        return (None, dpar[:Co * 9].view(s1).to(dts[0]), dpar[Co * 9:Co * 10].to(dts[1]), dpar[Co * 10:Co * 11].view(s2).to(dts[2]),
+                dpar[Co * 11:].to(dts[3]), None)
+
+
+class _FrontendConvFn(torch.autograd.Function):
+    """Wider blocks: HIP tap gather (im2col, padding rule folded in) + library GEMMs + HIP inverse gather (col2im)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, causal):
+        C.require_gpu(x)
+        xc = x.contiguous()
+        B, T, Fq, Ci = xc.shape
+        Co = w1.shape[0]
+        To, Fo = _out_len(T), _out_len(Fq)
+        P = B * To * Fo
+        A = torch.empty(P, 9 * Ci, dtype=xc.dtype, device=xc.device)
+        with prof.region("frontend_im2col"):
+            C.check(C.lib().tsasr_frontend_im2col(C.ptr(xc), C.ptr(A), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
+                    "tsasr_frontend_im2col")
+        wm = w1.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype)   # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]
+        w2m = w2.reshape(Co, Ci).to(xc.dtype)
+        centre = 7 if causal else 4                                      # the tap that reads x[2t', 2f']
+        Ac = A.view(P, 9, Ci)[:, centre, :]
+        y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
+        y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
+        ctx.save_for_backward(A, wm, w2m)
+        ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        A, wm, w2m = ctx.saved_tensors
+        causal, (B, T, Fq, Ci), Co, centre, dw1t, db1t, dw2t, db2t, w2shape = ctx.cfg
+        P = A.shape[0]
+        g1, g2 = dy1.reshape(P, Co), dy2.reshape(P, Co)
+        dwm = g1.t() @ A                                                 # [Co, 9Ci]
+        dw1 = dwm.view(Co, 3, 3, Ci).permute(0, 3, 2, 1).to(dw1t)
+        dw2 = (g2.t() @ A.view(P, 9, Ci)[:, centre, :]).view(w2shape).to(dw2t)
+        db1, db2 = g1.sum(0, dtype=torch.float32).to(db1t), g2.sum(0, dtype=torch.float32).to(db2t)
+        dA = g1 @ wm
+        dR = g2 @ w2m
+        dx = torch.empty(B, T, Fq, Ci, dtype=A.dtype, device=A.device)
+        with prof.region("frontend_col2im"):
+            C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(A), C.stream_ptr()),
+                    "tsasr_frontend_col2im")
+        return dx, dw1, db1, dw2, db2, None
+
+
+def frontend_convs(x, w1, b1, w2, b2, padding):
+    """x [B,T,F,C] -> (conv3x3_s2(x) + b1, conv1x1_s2(x) + b2), both [B,T',F',C_out]; padding 'same' (reflect) or 'causal'."""
+    if padding not in ("same", "causal"):
+        raise ValueError("Padding must be 'same' or 'causal'. Got " + str(padding))
+    if x.shape[-1] == 1:
+        return _FrontendC1Fn.apply(x.squeeze(-1), w1, b1, w2, b2, padding == "causal")
+    return _FrontendConvFn.apply(x, w1, b1, w2, b2, padding == "causal")
 
 
 # ---------------------------------------------------------------------------------------------------------
