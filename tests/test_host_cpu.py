@@ -1,0 +1,193 @@
+"""CPU-side tests of the host logic: C-ABI surface, mini HyperPyYAML, state_dict compatibility, schedulers, CLI,
+Brain bookkeeping and the data-parallel gradient arena (gloo, world_size 2). No kernel is launched here."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    capi = importlib.import_module("ts-asr_amd._capi")
+    header = open(os.path.join(ROOT, "include", "tsasr_hip.h")).read()
+    declared = set(re.findall(r"\b(tsasr_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/tsasr_hip.h but not exported by libtsasr_hip.so"
+    assert declared == set(capi.exported_symbols()), declared ^ set(capi.exported_symbols())
+    assert capi.lib().tsasr_version() >= 1
+
+
+def test_product_ops_refuse_cpu_tensors(pkg):
+    rn = importlib.import_module("ts-asr_amd.rnnt")
+    ops = importlib.import_module("ts-asr_amd.ops")
+    capi = importlib.import_module("ts-asr_amd._capi")
+    with pytest.raises(capi.TsasrHipMissing):
+        ops.layer_norm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-5)
+    with pytest.raises(capi.TsasrHipMissing):
+        rn.fused_joint_logits(torch.zeros(1, 2, 32), torch.zeros(1, 2, 32), torch.zeros(5, 32), torch.zeros(5))
+
+
+def _load(path, ov=None):
+    hp = importlib.import_module("ts-asr_amd.hparams")
+    with open(path) as f:
+        return hp.load_hyperpyyaml(f, ov)
+
+
+SMALL = dict(d_model=144, nhead=4, encoder_num_layers=2, speaker_num_layers=2, d_ffn=576, joint_dim=160, decoder_neurons=128)
+
+
+def test_yaml_loader_and_state_dict_keys_match_reference_shapes():
+    from tests.test_oracle_golden import full_state_dict
+    from oracle.golden_recipe import CFG1
+    h = _load(os.path.join(ROOT, "hparams", "conformer-t_scratch_mi355x.yaml"), SMALL)
+    assert h["decoder"].rnn.input_size == 28                       # !ref <vocab_size> - 1
+    assert h["opt_class"].keywords == {"lr": 0.001, "betas": (0.9, 0.98), "eps": 1e-08, "weight_decay": 0.01}
+    assert h["modules"]["encoder"] is h["encoder"]                 # !ref returns the same object
+    ref = full_state_dict(CFG1, "cat")                             # key -> tensor, shapes as the reference's state_dict
+    mine = {f"{n}.{k}": tuple(v.shape) for n, m in h["modules"].items() for k, v in m.state_dict().items()}
+    for k, v in ref.items():
+        assert mine.get(k) == tuple(v.shape), (k, mine.get(k), tuple(v.shape))
+    extra = set(mine) - set(ref) - {"embedding.Embedding.weight", "encoder.positional_encoding.inv_freq",
+                                    "speaker_encoder.positional_encoding.inv_freq"}
+    assert not extra, extra
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hparams"), reason="reference YAMLs only exist in the build container")
+@pytest.mark.parametrize("name", ["conformer-t_scratch", "conformer-t_wavlm", "conformer-t_none"])
+def test_reference_yaml_files_load_unchanged(name):
+    h = _load(f"/root/reference/hparams/LibriSpeechMix/{name}.yaml", {"data_folder": "/nonexistent"})
+    n = sum(p.numel() for m in h["modules"].values() if isinstance(m, torch.nn.Module) for p in m.parameters() if p.requires_grad)
+    assert n == {"conformer-t_scratch": 51022749}.get(name, n)     # trainable total of the scratch recipe
+    assert type(h["augmentation"]).__name__ == "Unavailable"
+    with pytest.raises(ValueError):
+        _load(f"/root/reference/hparams/LibriSpeechMix/{name}.yaml")  # !PLACEHOLDER data_folder must be overridden
+
+
+def test_noam_scheduler_and_epoch_counter():
+    core = importlib.import_module("ts-asr_amd.core")
+    from oracle.tsasr_ref import noam_lr
+    sch = core.NoamScheduler(lr_initial=1e-3, n_warmup_steps=10000)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    for n in range(1, 6):
+        _, lr = sch(opt)
+        assert lr == pytest.approx(noam_lr(1e-3, n, 10000), rel=1e-12)
+        assert opt.param_groups[0]["lr"] == lr
+    sch.n_steps = 9999
+    assert sch(opt)[1] == pytest.approx(1e-3, rel=1e-9)             # peak at n = warm-up
+    assert list(core.EpochCounter(3)) == [1, 2, 3]
+
+
+def test_parse_arguments_like_speechbrain(monkeypatch):
+    core = importlib.import_module("ts-asr_amd.core")
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    f, run, ov = core.parse_arguments(["hp.yaml", "--device", "cuda:0", "--distributed_launch", "--injection_mode", "sum",
+                                       "--causal_encoder", "True", "--max_grad_norm", "1.5", "--lr=0.01"])
+    assert f == "hp.yaml" and run["distributed_launch"] is True and run["max_grad_norm"] == 1.5
+    assert ov == {"injection_mode": "sum", "causal_encoder": True, "lr": 0.01}
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert core.parse_arguments(["hp.yaml"])[1]["device"] == "cuda:3"
+
+
+def test_synthetic_batch_surface():
+    bm = importlib.import_module("ts-asr_amd.batch")
+    b = bm.synthetic_batch(4, 3200, 1600, 10, ragged=True)
+    sig, lens = b.mixed_sig
+    assert sig.shape == (4, 3200) and lens[-1] == 1.0 and torch.all(lens[:-1] <= lens[1:])
+    assert b.tokens_bos.data.shape == (4, 11) and torch.all(b.tokens_bos.data[:, 0] == 0)
+    assert torch.all(b.tokens.data[0, int(round(float(b.tokens.lengths[0]) * 10)):] == 0)
+
+
+class _ToyBrain:
+    pass
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    core = importlib.import_module("ts-asr_amd.core")
+    dp = importlib.import_module("ts-asr_amd.dp")
+    dp.ddp_init_group({"distributed_launch": True, "distributed_backend": "gloo"})
+    torch.manual_seed(0)
+    mods = {"a": torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16)),
+            "b": torch.nn.Linear(16, 3)}
+
+    class Toy(core.Brain):
+        def compute_forward(self, batch, stage):
+            return self.modules.b(self.modules.a(batch[0]))
+
+        def compute_objectives(self, predictions, batch, stage):
+            return ((predictions - batch[1]) ** 2).mean()
+
+    import functools
+    brain = Toy(mods, functools.partial(torch.optim.SGD, lr=0.1), {}, {"device": "cpu", "distributed_launch": True,
+                                                                     "distributed_backend": "gloo", "grad_accumulation_factor": 2,
+                                                                     "max_grad_norm": 0.0})
+    brain.arena_kwargs = {}
+    g = torch.Generator().manual_seed(100)
+    data = [(torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)) for _ in range(6)]
+    for step, (x, y) in enumerate(data):   # each rank trains on its half of every batch
+        brain.fit_batch((x[rank::world], y[rank::world]))
+    torch.save({k: v.clone() for k, v in brain.modules.state_dict().items()}, os.path.join(out_dir, f"w{rank}.pt"))
+    torch.save({"steps": brain.optimizer_step, "buckets": len(brain.arena.buckets)}, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_arena_gloo_world2(tmp_path):
+    """2 ranks x half batches with overlapped bucket all-reduce == 1 process on the full batches (grad accumulation 2)."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k                          # ranks stay in lock-step
+    assert torch.load(tmp_path / "m0.pt")["steps"] == 3               # 6 micro-batches / accumulation 2
+    # single-process reference on the full batches
+    core = importlib.import_module("ts-asr_amd.core")
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16))
+    b = torch.nn.Linear(16, 3)
+    opt = torch.optim.SGD(list(a.parameters()) + list(b.parameters()), lr=0.1)
+    g = torch.Generator().manual_seed(100)
+    data = [(torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)) for _ in range(6)]
+    for step, (x, y) in enumerate(data):
+        # mean over the two half-batch losses == what the two ranks average
+        loss = sum(((b(a(x[r::2])) - y[r::2]) ** 2).mean() for r in range(2)) / 2
+        (loss / 2).backward()
+        if step % 2 == 1:
+            opt.step()
+            opt.zero_grad()
+    ref = {**{"a." + k: v for k, v in a.state_dict().items()}, **{"b." + k: v for k, v in b.state_dict().items()}}
+    for k in ref:
+        torch.testing.assert_close(w0[k], ref[k], atol=1e-6, rtol=1e-5)
+
+
+def test_brain_counts_nonfinite_losses_on_cpu():
+    core = importlib.import_module("ts-asr_amd.core")
+    import functools
+
+    class Toy(core.Brain):
+        def compute_forward(self, batch, stage):
+            return self.modules.m(batch)
+
+        def compute_objectives(self, predictions, batch, stage):
+            return predictions.sum() * float("nan")
+
+    brain = Toy({"m": torch.nn.Linear(2, 2)}, functools.partial(torch.optim.SGD, lr=0.1), {"nonfinite_patience": 1}, {"device": "cpu"})
+    brain.fit_batch(torch.ones(1, 2))
+    assert brain.flush_nonfinite() == 1
+    brain.fit_batch(torch.ones(1, 2))
+    with pytest.raises(ValueError):
+        brain.flush_nonfinite()

@@ -210,14 +210,28 @@ __global__ __launch_bounds__(256) void convmod_bwd_kernel(const T *__restrict__ 
 
 __global__ __launch_bounds__(256) void convmod_colsum_kernel(const float *__restrict__ slab, float *__restrict__ out, int nparts,
                                                              int width) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col < width)
-        for (int n = slice; n < nparts; n += 4) s += slab[(size_t)n * width + col];
-    red[slice][threadIdx.x & 63] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < width) {
+        int n = slice;
+        for (; n + 48 < nparts; n += 64) {  // 4 independent loads in flight per lane
+            s0 += slab[(size_t)n * width + col];
+            s1 += slab[(size_t)(n + 16) * width + col];
+            s2 += slab[(size_t)(n + 32) * width + col];
+            s3 += slab[(size_t)(n + 48) * width + col];
+        }
+        for (; n < nparts; n += 16) s0 += slab[(size_t)n * width + col];
+    }
+    red[slice][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (slice == 0 && col < width) out[col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (slice == 0 && col < width) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        out[col] = s;
+    }
 }
 
 template <typename T, int K>
@@ -279,7 +293,7 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
     else if (io_dtype == TSASR_BF16) CM_BK(bf16_t);
     else TSASR_CHECK_ARG(false, "tsasr_convmod_bwd: bad io_dtype %d", io_dtype);
     const int width = D * (K + 5), nparts = B * cdiv(T, CM_TT);
-    convmod_colsum_kernel<<<cdiv(width, 64), 256, 0, st>>>(slab, dparams, nparts, width);
+    convmod_colsum_kernel<<<cdiv(width, 16), 256, 0, st>>>(slab, dparams, nparts, width);
     TSASR_CHECK_LAUNCH("tsasr_convmod_bwd");
     return 0;
 }

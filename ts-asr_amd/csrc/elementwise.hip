@@ -219,19 +219,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
     }
 }
 
-// out[c] = sum_n part[n][c]: 64 columns x 4 row-slices per workgroup, slices combined through LDS (fixed order ->
+// out[c] = sum_n part[n][c]: 16 columns x 16 row-slices per workgroup, slices combined through LDS (fixed order ->
 // deterministic). part rows are `stride` wide; columns [0,D) go to out_a, [D,stride) to out_b.
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ part, float *__restrict__ out_a,
                                                      float *__restrict__ out_b, int nparts, int D, int stride) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col < stride)
-        for (int n = slice; n < nparts; n += 4) s += part[(size_t)n * stride + col];
-    red[slice][threadIdx.x & 63] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < stride) {
+        int n = slice;
+        for (; n + 48 < nparts; n += 64) {  // 4 independent loads in flight per lane
+            s0 += part[(size_t)n * stride + col];
+            s1 += part[(size_t)(n + 16) * stride + col];
+            s2 += part[(size_t)(n + 32) * stride + col];
+            s3 += part[(size_t)(n + 48) * stride + col];
+        }
+        for (; n < nparts; n += 16) s0 += part[(size_t)n * stride + col];
+    }
+    red[slice][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && col < stride) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
         if (col < D) { if (out_a) out_a[col] = s; }
         else if (out_b) out_b[col - D] = s;
     }
@@ -262,40 +273,61 @@ __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const T *__re
     }
 }
 
-// dx = dy * keep/(1-p) * act'(y) ; dbias partial rows part[blockIdx][Ncols] (blocks walk whole rows)
+// dx = dy * keep/(1-p) * act'(y) ; dbias partial rows part[blockIdx][Ncols]. A workgroup owns `rows_per_wg` consecutive
+// rows; its 256 threads are laid out as (256 / tpr) row slots x tpr column chunks so that narrow rows still use every lane;
+// the row slots are combined through LDS in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ y,
                                                                    T *__restrict__ dx, float *__restrict__ part, long long M,
                                                                    int Ncols, float slope, float p, unsigned long long seed,
                                                                    int rows_per_wg) {
     constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float cred[];  // [slots][Ncols] when slots > 1 and part != NULL
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
+    const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
-    for (int c = threadIdx.x * N; c < Ncols; c += 256 * N) {
+    for (int c = lane * N; c < Ncols; c += tpr * N) {
         float acc[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) acc[j] = 0.f;
-        for (int rr = 0; rr < rows_per_wg; ++rr) {
-            const long long row = r0 + rr;
-            if (row >= M) break;
-            const long long i = row * Ncols + c;
-            float d[N], yv[N];
-            ldv<T, N>(dy + i, d);
-            if (slope >= 0.f) ldv<T, N>(y + i, yv);
+        if (slot < slots) {
+#pragma unroll 4
+            for (int rr = slot; rr < rows_per_wg; rr += slots) {
+                const long long row = r0 + rr;
+                if (row >= M) break;
+                const long long i = row * Ncols + c;
+                float d[N], yv[N];
+                ldv<T, N>(dy + i, d);
+                if (slope >= 0.f) ldv<T, N>(y + i, yv);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float g = d[j];
-                if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
-                if (slope >= 0.f && yv[j] < 0.f) g *= slope;  // sign(y) = sign(pre-activation) for kept elements
-                d[j] = g;
-                acc[j] += g;
+                for (int j = 0; j < N; ++j) {
+                    float g = d[j];
+                    if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                    if (slope >= 0.f && yv[j] < 0.f) g *= slope;  // sign(y) = sign(pre-activation) for kept elements
+                    d[j] = g;
+                    acc[j] += g;
+                }
+                stv<T, N>(dx + i, d);
             }
-            stv<T, N>(dx + i, d);
         }
         if (part) {
+            if (slots == 1) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+                for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+            } else if (slot < slots) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) cred[slot * Ncols + c + j] = acc[j];
+            }
+        }
+    }
+    if (part && slots > 1) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Ncols; i += 256) {
+            float s = 0.f;
+            for (int q = 0; q < slots; ++q) s += cred[q * Ncols + i];
+            part[(size_t)blockIdx.x * Ncols + i] = s;
         }
     }
 }
@@ -335,32 +367,51 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
                                                               float p, unsigned long long seed,
                                                               const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
     constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float cred[];
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
+    const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
-    for (int c = threadIdx.x * N; c < Ncols; c += 256 * N) {
+    for (int c = lane * N; c < Ncols; c += tpr * N) {
         float acc[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) acc[j] = 0.f;
-        for (int rr = 0; rr < rows_per_wg; ++rr) {
-            const long long row = r0 + rr;
-            if (row >= M) break;
-            const long long i = row * Ncols + c;
-            const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
-            float d[N];
-            ldv<T, N>(dout + i, d);
+        if (slot < slots) {
+#pragma unroll 4
+            for (int rr = slot; rr < rows_per_wg; rr += slots) {
+                const long long row = r0 + rr;
+                if (row >= M) break;
+                const long long i = row * Ncols + c;
+                const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+                float d[N];
+                ldv<T, N>(dout + i, d);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float g = live ? d[j] * alpha : 0.f;
-                if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
-                d[j] = g;
-                acc[j] += g;
+                for (int j = 0; j < N; ++j) {
+                    float g = live ? d[j] * alpha : 0.f;
+                    if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                    d[j] = g;
+                    acc[j] += g;
+                }
+                stv<T, N>(dx + i, d);
             }
-            stv<T, N>(dx + i, d);
         }
         if (part) {
+            if (slots == 1) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+                for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
+            } else if (slot < slots) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) cred[slot * Ncols + c + j] = acc[j];
+            }
+        }
+    }
+    if (part && slots > 1) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Ncols; i += 256) {
+            float s = 0.f;
+            for (int q = 0; q < slots; ++q) s += cred[q * Ncols + i];
+            part[(size_t)blockIdx.x * Ncols + i] = s;
         }
     }
 }
@@ -447,9 +498,14 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
            : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
                                     : -2;
     TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_bwd: D=%d too large or bad io_dtype %d", D, io_dtype);
-    colsum_kernel<<<cdiv(2 * D, 64), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
+    colsum_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
     TSASR_CHECK_LAUNCH("tsasr_layernorm_bwd");
     return 0;
+}
+
+static size_t slot_lds(int Ncols, int vec, const float *part) {
+    const int chunks = Ncols / vec, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
+    return (part && slots > 1) ? (size_t)slots * Ncols * sizeof(float) : 0;
 }
 
 static unsigned ew_grid(long long total, int N) {
@@ -489,11 +545,11 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
     float *part = dbias ? (float *)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        bias_act_dropout_bwd_kernel<float><<<nwg, 256, 0, st>>>((const float *)dy, (const float *)y, (float *)dx, part, M, N, act_slope, p, seed, rpw);
+        bias_act_dropout_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dy, (const float *)y, (float *)dx, part, M, N, act_slope, p, seed, rpw);
     else if (io_dtype == TSASR_BF16)
-        bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, rpw);
+        bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 64), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_bwd");
     return 0;
 }
@@ -524,11 +580,11 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     float *part = dbias ? (float *)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        dropout_add_bwd_kernel<float><<<nwg, 256, 0, st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
     else if (io_dtype == TSASR_BF16)
-        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, 0, st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 64), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
     return 0;
 }
