@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__re
         }
         if (part) {
             if (slots == 1) {
+                if (slot == 0)
 #pragma unroll
                 for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
             } else if (slot < slots) {
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
         }
         if (part) {
             if (slots == 1) {
+                if (slot == 0)
 #pragma unroll
                 for (int j = 0; j < N; ++j) part[(size_t)blockIdx.x * Ncols + c + j] = acc[j];
             } else if (slot < slots) {
