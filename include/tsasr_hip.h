@@ -143,6 +143,21 @@ int tsasr_frontend_c1_bwd(const void *x, const void *dy1, const void *dy2, float
 int tsasr_frontend_im2col(const void *x, void *A, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
 int tsasr_frontend_col2im(const void *dA, const void *dR, void *dx, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Fused relative-position multi-head self-attention: replaces the body of RelPosMHAXL.forward between in_proj and out_proj,
+ * SB/nnet/attention.py:586-633 (q+u/q+v, matrix_ac, matrix_bd + rel_shift :468-483, 1/sqrt(embed_dim) scale, -inf masks,
+ * softmax, dropout, .V) without any T x T tensor in HBM.
+ *   qkv [B,T,H,3*Dh] (per head Q|K|V, attention.py:549-553), pk [2T-1, H*Dh] = linear_pos(pos_embs),
+ *   bias_u/bias_v fp32 [H*Dh] = the (Dh,H) parameters' storage read as [H,Dh] (a view, attention.py:586-592),
+ *   key_lens int32 [B] or NULL (keys j >= key_lens[b] are masked), causal != 0 masks j > i.
+ *   out [B,T,H*Dh]; lse fp32 [B,H,T] (log-sum-exp of the scaled scores; needed by the backward). Dh <= 64.
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_relpos_attn_lds_bytes(void);
+int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                          void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                          unsigned long long seed, int io_dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

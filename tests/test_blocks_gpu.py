@@ -203,3 +203,50 @@ def test_relpos_mha_vs_reference(nn_, golden, tag, use_lens, causal):
     assert check_grads(m, g, tag) == 6
     if tag == "mha_kpm":
         close(attn[1], g["mha_kpm:attn_b1"], 1e-5)
+
+
+@pytest.mark.parametrize("tag,use_lens,causal", [("mha_nomask", False, False), ("mha_kpm", True, False), ("mha_kpm_causal", True, True)])
+def test_fused_attention_kernel_vs_reference(nn_, golden, tag, use_lens, causal):
+    """return_attn_weights=False routes through the fused HIP kernel (Dh = 36 here: padded head dim path)."""
+    g, x, lens, probe = block_inputs(golden)
+    m = load_det_weights(nn_.RelPosMHAXL(144, 4, dropout=0.0, mask_pos_future=causal), "blk.mha.").to(DEV)
+    pe = nn_.RelPosEncXL(144).to(DEV)(x)
+    out = m(x, x, x, pe, key_lens=lens if use_lens else None, causal=causal, return_attn_weights=False)
+    (out * probe).sum().backward()
+    # bf16 MFMA operands (q+u, k, p, v, probabilities): 2^-8 relative per operand on |out| ~ 1
+    close(out, g[f"{tag}:out"], 3e-2, 2e-2)
+    rel = float((out.detach().cpu() - T(g[f"{tag}:out"])).norm() / T(g[f"{tag}:out"]).norm())
+    assert rel < 8e-3, rel
+    rel_dx = float((x.grad.cpu() - T(g[f"{tag}:dx"])).norm() / T(g[f"{tag}:dx"]).norm())
+    assert rel_dx < 2e-2, rel_dx
+
+
+@pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 125, 4, 64), (1, 333, 2, 64), (2, 40, 4, 36)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
+    """HIP kernel vs the fp32 formula (oracle/tsasr_ref.relpos_mha's core) on bf16-rounded operands."""
+    D = H * Dh
+    g = torch.Generator().manual_seed(Tn + Dh)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(dtype)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(dtype)
+    u, v = torch.randn(Dh, H, generator=g) * 0.3, torch.randn(Dh, H, generator=g) * 0.3
+    lens = torch.tensor([Tn, max(1, Tn // 2), max(1, Tn - 7)][:B], dtype=torch.int32)
+    scale = 1.0 / D ** 0.5
+    out, _ = ops.relpos_attention(qkv.to(DEV), pk.to(DEV), u.to(DEV), v.to(DEV), lens.to(DEV), H, scale, causal, 0.0, False)
+    bfr = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    q, k, vv = qkv.float().view(B, Tn, H, 3 * Dh).chunk(3, dim=-1)
+    uu, vb = u.reshape(-1).view(1, 1, H, Dh), v.reshape(-1).view(1, 1, H, Dh)
+    p = bfr(pk.float()).view(1, -1, H, Dh)
+    ac = torch.matmul(bfr(q + uu).transpose(1, 2), bfr(k).permute(0, 2, 3, 1))
+    bd = torch.matmul(bfr(q + vb).transpose(1, 2), p.permute(0, 2, 3, 1))
+    idx = torch.arange(Tn)
+    bd = torch.gather(bd, 3, (idx[None, :] - idx[:, None] + Tn - 1).expand(B, H, Tn, Tn))
+    sc = (ac + bd) * scale
+    if causal:
+        sc = sc.masked_fill(idx[None, :] > idx[:, None], float("-inf"))
+    sc = sc.masked_fill((idx[None, :] >= lens[:, None]).view(B, 1, 1, Tn), float("-inf"))
+    ref = torch.matmul(torch.softmax(sc, -1), bfr(vv).transpose(1, 2)).transpose(1, 2).reshape(B, Tn, D)
+    rel = float((out.float().cpu() - ref).norm() / ref.norm())
+    assert rel < (6e-3 if dtype == torch.float32 else 1e-2), rel   # probabilities are rounded to bf16 for P.V
+    close(out, ref, 4e-2, 4e-2)

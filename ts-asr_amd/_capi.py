@@ -54,6 +54,8 @@ _PROTOS = {
     "tsasr_frontend_c1_bwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_frontend_im2col": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "tsasr_frontend_col2im": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "tsasr_relpos_attn_lds_bytes": (c_size_t, []),
+    "tsasr_relpos_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_int, c_void_p]),
 }
 
 

@@ -1,0 +1,246 @@
+// Fused relative-position multi-head self-attention (Transformer-XL style, as speechbrain's RelPosMHAXL) for gfx950.
+//
+// Replaces the body of RelPosMHAXL.forward, vendor/speechbrain/speechbrain/nnet/attention.py:485-639, between the input
+// projection and the output projection: q+u / q+v (:586-592), matrix_ac (:595), matrix_bd + rel_shift (:597-598, 468-483),
+// scale by 1/sqrt(embed_dim) (:604), look-ahead / key-padding masks filled with -inf (:607-623), softmax, dropout, .V (:625-633).
+// The reference materialises AC [B,H,T,T], BDraw [B,H,T,2T-1], the shifted copy, the masked copy, the softmax and the
+// dropped copy in HBM (>= 8 passes over 96 MB per layer at B=32, T=250). Here nothing of size T x T leaves the chip.
+//
+//   score[i,j] = scale * ( (q_i + u) . k_j  +  (q_i + v) . p_{j - i + T - 1} )        (rel_shift closed form)
+//   out[i]     = sum_j dropout(softmax_j(score[i,:]))[j] * v_j
+//
+// Mapping (flash-style, one pass over the keys, online softmax in fp32):
+//   * workgroup = (b, h, 128 consecutive queries), 4 waves x 32 queries; key tiles of 64 stream through LDS together with
+//     the band of positional rows p_r they can touch (191 rows).
+//   * every product runs on v_mfma_f32_32x32x16_bf16 in the TRANSPOSED orientation (rows = keys / band rows / head dims in
+//     the accumulator registers, column = query on the lane): a lane owns ONE query, so the softmax row statistics are
+//     in-lane reductions plus one cross-half exchange, and the probability tile is directly the B operand of P.V
+//     (guide section 3 "accumulator tile as the next MFMA's operand").
+//   * the relative shift BD[i,j] = G[i, j-i+31] (G = (Q+v).Pband^T for a 32x32 block) is a per-lane diagonal read: G^T goes
+//     through a per-wave fp32 LDS tile [64 r][32 i]; with row stride 32 the skewed read (r = j - i + 31, column i) hits bank
+//     (i mod 32): conflict-free.
+//   * V is consumed through ds_read_b64_tr_b16 (hardware transpose read) so that it can be staged row-major/coalesced.
+// qkv layout: [B, T, H, 3*Dh] with Q|K|V interleaved per head (attention.py:549-553); pk: [2T-1, H*Dh];
+// pos_bias_u/v: the (Dh, H) parameter's storage reinterpreted as [H, Dh] (a view, not a transpose; attention.py:586-592).
+#include "common.h"
+
+#define AT_QW 32          // queries per wave
+#define AT_QB 128         // queries per workgroup
+#define AT_KT 64          // keys per LDS tile
+#define AT_DP 64          // padded head dim (Dh <= 64)
+#define AT_LD 72          // LDS row stride in bf16 (144 B: 16-byte slots rotate by 9 per row -> conflict-free b128 reads)
+#define AT_BAND (AT_QB + AT_KT)  // 192 band rows per tile (191 used)
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ unsigned at_rng(unsigned long long idx, unsigned long long seed) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
+// stage `rows` rows of Dh elements (row r -> src + r*src_stride, or zeros when r is outside [lo,hi)) into lds[rows][AT_LD]
+template <typename T>
+__device__ __forceinline__ void stage_rows(bf16_t *lds, const T *src, long long src_stride, int first_row, int lo, int hi, int rows,
+                                           int Dh) {
+    const bool vec_ok = (Dh % (16 / (int)sizeof(T))) == 0;  // 16-byte aligned 8-element groups
+    for (int i = threadIdx.x; i < rows * (AT_DP / 8); i += 256) {
+        const int rr = i / (AT_DP / 8), c = (i % (AT_DP / 8)) * 8;
+        const int r = first_row + rr;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (r >= lo && r < hi) {
+            const T *p = src + (long long)r * src_stride + c;
+            if (vec_ok && c + 8 <= Dh) ld8(p, v);
+            else {
+                for (int j = 0; j < 8; ++j)
+                    if (c + j < Dh) v[j] = ld1(p + j);
+            }
+        }
+        st8(lds + rr * AT_LD + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+                                                              const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                              const int32_t *__restrict__ key_lens, T *__restrict__ out,
+                                                              float *__restrict__ lse, int Tn, int H, int Dh, float scale,
+                                                              int causal, float pdrop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);             // [AT_KT][AT_LD]
+    bf16_t *v_lds = k_lds + AT_KT * AT_LD;                        // [AT_KT][AT_LD]
+    bf16_t *p_lds = v_lds + AT_KT * AT_LD;                        // [AT_BAND][AT_LD]
+    float *g_all = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);  // [4 waves][64][32]
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    float *g_lds = g_all + wave * 64 * 32;
+    const int D = H * Dh;
+    const long long row_stride = 3LL * D;  // qkv row (b,t) stride
+    const T *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const int iq = i0 + wave * AT_QW + r;          // this lane's query row
+    const int iqc = min(iq, Tn - 1);
+
+    // Q + u, Q + v as B operands: lane (i = r, hh) holds dims 16s + 8hh + [0,8)
+    bf16x8 qu[4], qv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * s + 8 * hh + j;
+            float q = 0.f, uu = 0.f, vv = 0.f;
+            if (d < Dh) {
+                q = ld1(q_base + (long long)iqc * row_stride + d);
+                uu = bias_u[h * Dh + d];
+                vv = bias_v[h * Dh + d];
+            }
+            qu[s][j] = (bf16_t)(q + uu);
+            qv[s][j] = (bf16_t)(q + vv);
+        }
+    }
+    f32x16 o_acc[2];
+    o_acc[0] = (f32x16){0};
+    o_acc[1] = (f32x16){0};
+    float m_run = -INFINITY, l_run = 0.f;
+    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
+    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+
+    int j_end = len;
+    if (causal) j_end = min(j_end, i0 + AT_QB);  // keys beyond the last query of the workgroup are never attended
+    for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
+        __syncthreads();  // previous tile fully consumed
+        stage_rows<T>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        stage_rows<T>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        // band row R <-> r = j0 - i0 - (AT_QB - 1) + Tn - 1 + R
+        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, AT_BAND, Dh);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb >= j_end) break;                                       // wave-uniform
+            if (causal && jb > i0 + wave * AT_QW + 31) break;              // whole sub-block is in the future of this wave
+            // ---- AC^T: rows = keys, col = query
+            f32x16 s_acc = {0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(k_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qu[s], s_acc, 0, 0, 0);
+            }
+            // ---- G^T = Pband . (Q+v)^T : band rows base + [0,64)
+            const int base = 32 * sub - 32 * wave + (AT_QB - AT_QW);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 g_acc = {0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(p_lds + (base + 32 * rb + r) * AT_LD + 16 * s + 8 * hh);
+                    g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, qv[s], g_acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) g_lds[(32 * rb + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = g_acc[g];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- scores for this lane's query: 16 keys j = jb + (g&3) + 8(g>>2) + 4hh ; BD via the skewed read
+            float sc[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
+                const float bd = g_lds[(jl - r + 31) * 32 + r];
+                const int j = jb + jl;
+                float x = (s_acc[g] + bd) * scale;
+                if (j >= len || (causal && j > iq)) x = -INFINITY;
+                sc[g] = x;
+                mx = fmaxf(mx, x);
+            }
+            __builtin_amdgcn_wave_barrier();
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+            float psum = 0.f;
+            bf16x8 pb[2];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                float p = (m_new == -INFINITY) ? 0.f : __expf(sc[g] - m_new);
+                psum += p;
+                if (pdrop > 0.f) {
+                    const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
+                    p = (at_rng(idx, seed) >= thr) ? p * keep_scale : 0.f;
+                }
+                pb[g >> 3][g & 7] = (bf16_t)p;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) o_acc[db][g] *= alpha;
+            // ---- O^T += V^T . P^T ; A = V^T through the transposing LDS read
+            const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int kbase = 32 * sub + 16 * s + 4 * hh;
+                    const bf16_t *a0 = v_lds + (kbase + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0 + 8 * AT_LD));
+                    bf16x8 va;
+                    va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                    va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                    o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[s], o_acc[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: out[b, iq, h*Dh + d] = O / l ; lse = m + log l
+    if (iq < Tn) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        T *orow = out + ((long long)b * Tn + iq) * D + (long long)h * Dh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                if (d < Dh) st1(orow + d, o_acc[db][g] * inv);
+            }
+        if (hh == 0 && lse) lse[((long long)b * H + h) * Tn + iq] = m_run + __logf(l_run);
+    }
+}
+
+extern "C" {
+
+size_t tsasr_relpos_attn_lds_bytes(void) {
+    return (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)4 * 64 * 32 * sizeof(float);
+}
+
+/* out [B,T,H*Dh] = fused rel-pos attention; lse [B,H,T] fp32 (may be NULL) is kept for the backward.
+ * Dh <= 64; dropout mask is a pure function of (seed, b, h, i, j). */
+int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                          void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                          unsigned long long seed, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out, "tsasr_relpos_attn_fwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_fwd: head dim %d not supported (1..%d)", Dh, AT_DP);
+    TSASR_CHECK_ARG(pdrop >= 0.f && pdrop < 1.f, "tsasr_relpos_attn_fwd: bad dropout %f", pdrop);
+    const size_t lds = tsasr_relpos_attn_lds_bytes();
+    dim3 grid(cdiv(T, AT_QB), H, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32) {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        relpos_attn_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed);
+    } else if (io_dtype == TSASR_BF16) {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        relpos_attn_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed);
+    } else {
+        TSASR_CHECK_ARG(false, "tsasr_relpos_attn_fwd: bad io_dtype %d", io_dtype);
+    }
+    TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
+    return 0;
+}
+
+}  // extern "C"
