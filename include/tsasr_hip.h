@@ -157,6 +157,14 @@ size_t tsasr_relpos_attn_lds_bytes(void);
 int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, int io_dtype, void *stream);
+size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H);
+/* Backward: dqkv [B,T,H,3*Dh] fully written; d_bias_u/d_bias_v fp32 [H*Dh] ([H,Dh] reading of the parameter storage);
+ * dbd [H, 2T-1, B, T] (io_dtype) = scale * dS shifted back onto the (r, i) grid - ZERO-FILL it before the call; the host gets
+ * d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] * (q[b,i,h,:] + v[h,:]) with one library GEMM per head. */
+int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, float *d_bias_u,
+                          float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                          unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -250,3 +250,53 @@ def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
     rel = float((out.float().cpu() - ref).norm() / ref.norm())
     assert rel < (6e-3 if dtype == torch.float32 else 1e-2), rel   # probabilities are rounded to bf16 for P.V
     close(out, ref, 4e-2, 4e-2)
+
+
+@pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 70, 4, 36), (1, 200, 2, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
+    """HIP backward (dQ/dK/dV, d pos_bias_u/v, d pk) vs autograd through the fp32 formula."""
+    D = H * Dh
+    g = torch.Generator().manual_seed(Tn * 3 + Dh)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(dtype)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(dtype)
+    u, v = torch.randn(Dh, H, generator=g) * 0.3, torch.randn(Dh, H, generator=g) * 0.3
+    dout = torch.randn(B, Tn, D, generator=g).to(dtype)
+    lens = torch.tensor([Tn, max(1, Tn // 2), max(1, Tn - 7)][:B], dtype=torch.int32)
+    scale = 1.0 / D ** 0.5
+    leaf = [t.float().clone().requires_grad_() for t in (qkv, pk, u, v)]
+    ref, _ = ops._relpos_attention_glue(leaf[0], leaf[1], leaf[2], leaf[3], lens, H, scale, causal, 0.0, False)
+    ref.backward(dout.float())
+    dev = [t.to(DEV).requires_grad_() for t in (qkv, pk, u, v)]
+    out, _ = ops.relpos_attention(dev[0], dev[1], dev[2], dev[3], lens.to(DEV), H, scale, causal, 0.0, False)
+    out.backward(dout.to(DEV))
+    for a, r_, name in zip(dev, leaf, ("dqkv", "dpk", "du", "dv")):
+        rel = float((a.grad.float().cpu() - r_.grad).norm() / r_.grad.norm())
+        assert rel < (1.5e-2 if dtype == torch.float32 else 2.5e-2), (name, rel)   # bf16 MFMA operands incl. P and dS
+
+
+def test_fused_attention_dropout_consistency(ops):
+    """With dropout the backward must regenerate the forward's mask: check d(out)/d(V) . dout == out . dout structure via
+    finite differences on V (out is linear in V for a fixed mask)."""
+    B, Tn, H, Dh = 2, 96, 2, 64
+    D = H * Dh
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(DEV)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(DEV)
+    u, v = (torch.randn(Dh, H, generator=g) * 0.3).to(DEV), (torch.randn(Dh, H, generator=g) * 0.3).to(DEV)
+    dout = torch.randn(B, Tn, D, generator=g).to(DEV)
+    fn = ops._RelPosAttnFn
+    x = qkv.clone().requires_grad_()
+    out = fn.apply(x, pk, u, v, None, H, 1.0 / D ** 0.5, False, 0.3, 1234)
+    out.backward(dout)
+    # out is linear in V:  <dout, out(V + dV) - out(V)> == <grad_V, dV>
+    dV = torch.zeros_like(qkv)
+    dV.view(B, Tn, H, 3 * Dh)[..., 2 * Dh:] = torch.randn(B, Tn, H, Dh, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out2 = fn.apply(qkv + dV, pk, u, v, None, H, 1.0 / D ** 0.5, False, 0.3, 1234)
+    lhs = float(((out2 - out.detach()).double() * dout.double()).sum())
+    rhs = float((x.grad.double() * dV.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=3e-2), (lhs, rhs)
+    # and a different seed gives a different mask
+    out3 = fn.apply(qkv, pk, u, v, None, H, 1.0 / D ** 0.5, False, 0.3, 99)
+    assert float((out3 - out.detach()).abs().max()) > 1e-2

@@ -213,6 +213,362 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
     }
 }
 
+
+// =====================================================================================================================
+// Backward. Two deterministic passes that both recompute the probabilities from (q,k,p,lse) - no T x T tensor, no atomics:
+//   bwd_q  (query-major, same orientation as the forward): dQ = dQ_ac + dQ_bd, per-workgroup partial sums of the gradients
+//          of pos_bias_u / pos_bias_v, and the shifted-back score gradient dBD[h][r][b][i] = scale*dS[i, j=r+i-T+1] (compute
+//          dtype) from which the host obtains d(pk) with one library GEMM per head (d(pk) is a parameter-like reduction
+//          over the batch).
+//   bwd_kv (key-major: a lane owns one KEY, accumulators hold dK^T / dV^T): dK, dV.
+// dS = P * (dP - delta), delta_i = dO_i . O_i ; with dropout P_d = P*m/(1-p): dP = (dO.V^T)*m/(1-p), same counter-based mask.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                const int32_t *__restrict__ key_lens, const T *__restrict__ out,
+                                                                const T *__restrict__ dout, const float *__restrict__ lse,
+                                                                T *__restrict__ dqkv, T *__restrict__ dbd, float *__restrict__ slab_uv,
+                                                                int Bn, int Tn, int H, int Dh, float scale, int causal, float pdrop,
+                                                                unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);
+    bf16_t *v_lds = k_lds + AT_KT * AT_LD;
+    bf16_t *p_lds = v_lds + AT_KT * AT_LD;
+    float *g_all = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    float *g_lds = g_all + wave * 64 * 32;
+    const int D = H * Dh, R = 2 * Tn - 1;
+    const long long row_stride = 3LL * D;
+    const T *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const int iq = i0 + wave * AT_QW + r, iqc = min(iq, Tn - 1);
+    const bool q_ok = iq < Tn;
+
+    bf16x8 qu[4], qv[4], dob[4];
+    float delta = 0.f;
+    const T *orow = out + ((long long)b * Tn + iqc) * D + (long long)h * Dh;
+    const T *dorow = dout + ((long long)b * Tn + iqc) * D + (long long)h * Dh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * s + 8 * hh + j;
+            float q = 0.f, uu = 0.f, vv = 0.f, dd = 0.f, oo = 0.f;
+            if (d < Dh) {
+                q = ld1(q_base + (long long)iqc * row_stride + d);
+                uu = bias_u[h * Dh + d];
+                vv = bias_v[h * Dh + d];
+                if (q_ok) { dd = ld1(dorow + d); oo = ld1(orow + d); }
+            }
+            qu[s][j] = (bf16_t)(q + uu);
+            qv[s][j] = (bf16_t)(q + vv);
+            dob[s][j] = (bf16_t)dd;
+            delta += dd * oo;
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse_i = lse[((long long)b * H + h) * Tn + iqc];
+    f32x16 dqu[2], dqv[2];
+    dqu[0] = dqu[1] = dqv[0] = dqv[1] = (f32x16){0};
+    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
+    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+
+    int j_end = len;
+    if (causal) j_end = min(j_end, i0 + AT_QB);
+    for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
+        __syncthreads();
+        stage_rows<T>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        stage_rows<T>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
+        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, AT_BAND, Dh);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb >= j_end) break;
+            if (causal && jb > i0 + wave * AT_QW + 31) break;
+            f32x16 s_acc = {0}, dpd = {0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(k_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qu[s], s_acc, 0, 0, 0);
+                const bf16x8 va = *reinterpret_cast<const bf16x8 *>(v_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                dpd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dob[s], dpd, 0, 0, 0);
+            }
+            const int base = 32 * sub - 32 * wave + (AT_QB - AT_QW);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 g_acc = {0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(p_lds + (base + 32 * rb + r) * AT_LD + 16 * s + 8 * hh);
+                    g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, qv[s], g_acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) g_lds[(32 * rb + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = g_acc[g];
+            }
+            __builtin_amdgcn_wave_barrier();
+            float ds[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
+                const float bd = g_lds[(jl - r + 31) * 32 + r];
+                const int j = jb + jl;
+                const bool masked = (j >= len) || (causal && j > iq);
+                const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
+                float dp = dpd[g];
+                if (pdrop > 0.f) {
+                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
+                    dp = (at_rng(idx, seed) >= thr) ? dp * keep_scale : 0.f;
+                }
+                ds[g] = q_ok ? p * (dp - delta) * scale : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // inverse skew: dG^T[r_local = jl - i + 31][i] = dSs[i, jl]
+            bf16x8 dsb[2];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
+                g_lds[(jl - r + 31) * 32 + r] = ds[g];
+                dsb[g >> 3][g & 7] = (bf16_t)ds[g];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // dQ_ac^T += K^T . dSs^T   (A = K^T through the transposing read; k order of dsb = accumulator row order)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16_t *a0 = k_lds + (32 * sub + 16 * s + 4 * hh + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0 + 8 * AT_LD));
+                    bf16x8 ka;
+                    ka[0] = lo[0]; ka[1] = lo[1]; ka[2] = lo[2]; ka[3] = lo[3];
+                    ka[4] = hi[0]; ka[5] = hi[1]; ka[6] = hi[2]; ka[7] = hi[3];
+                    dqu[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, dsb[s], dqu[db], 0, 0, 0);
+                }
+            // dQ_bd^T += Pband^T . dG^T   (natural k order: band rows 16s' + 8hh + e), predicate = "this (r,i) has a key"
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                bf16x8 dgb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int rl = 16 * sp + 8 * hh + e, jl = rl + r - 31;
+                    dgb[e] = (bf16_t)((jl >= 0 && jl < 32) ? g_lds[rl * 32 + r] : 0.f);
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16_t *a0 = p_lds + (base + 16 * sp + 8 * hh + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(a0 + 4 * AT_LD));
+                    bf16x8 pa;
+                    pa[0] = lo[0]; pa[1] = lo[1]; pa[2] = lo[2]; pa[3] = lo[3];
+                    pa[4] = hi[0]; pa[5] = hi[1]; pa[6] = hi[2]; pa[7] = hi[3];
+                    dqv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, dgb, dqv[db], 0, 0, 0);
+                }
+            }
+            // shifted-back score gradient rows -> dbd[h][r][b][i]  (row = 32 consecutive queries = 64 contiguous bytes)
+            if (dbd && q_ok) {
+#pragma unroll 4
+                for (int qq = 0; qq < 32; ++qq) {
+                    const int rl = 2 * qq + hh, jl = rl + r - 31;
+                    const int rg = r_first + base + rl;
+                    if (rl < 63 && jl >= 0 && jl < 32 && jb + jl < Tn && rg >= 0 && rg < R)
+                        st1(dbd + (((long long)h * R + rg) * Bn + b) * Tn + iq, g_lds[rl * 32 + r]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
+    T *dq = dqkv + ((long long)b * Tn + iqc) * row_stride + (long long)h * 3 * Dh;
+    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * H + h) * 4 + wave) * 128;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
+            if (q_ok && d < Dh) st1(dq + d, dqu[db][g] + dqv[db][g]);
+            float su = q_ok ? dqu[db][g] : 0.f, sv = q_ok ? dqv[db][g] : 0.f;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
+            if (r == 0) { slab[d] = su; slab[64 + d] = sv; }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+                                                                 const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                 const int32_t *__restrict__ key_lens, const T *__restrict__ out,
+                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
+                                                                 T *__restrict__ dqkv, int Tn, int H, int Dh, float scale, int causal,
+                                                                 float pdrop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *qu_lds = reinterpret_cast<bf16_t *>(smem);      // [64][LD]  Q + u
+    bf16_t *qv_lds = qu_lds + AT_KT * AT_LD;                // [64][LD]  Q + v
+    bf16_t *do_lds = qv_lds + AT_KT * AT_LD;                // [64][LD]  dO
+    bf16_t *p_lds = do_lds + AT_KT * AT_LD;                 // [192][LD] band
+    float *st_lds = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);  // [2][64]: lse, delta of the query tile
+    float *g_all = st_lds + 128;                            // [4][32 i][64 r]
+    const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * AT_QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    float *g_lds = g_all + wave * 32 * 64;
+    const int D = H * Dh, R = 2 * Tn - 1;
+    const long long row_stride = 3LL * D;
+    const T *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const int jk = j0 + wave * AT_QW + r, jkc = min(jk, Tn - 1);   // this lane's key
+    const bool k_live = jk < len;                                   // masked / out-of-range keys get zero gradients
+
+    bf16x8 kb[4], vb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * s + 8 * hh + j;
+            kb[s][j] = (bf16_t)((d < Dh) ? ld1(q_base + (long long)jkc * row_stride + Dh + d) : 0.f);
+            vb[s][j] = (bf16_t)((d < Dh) ? ld1(q_base + (long long)jkc * row_stride + 2 * Dh + d) : 0.f);
+        }
+    f32x16 dk[2], dv[2];
+    dk[0] = dk[1] = dv[0] = dv[1] = (f32x16){0};
+    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
+    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const bool vec_ok = (Dh % (16 / (int)sizeof(T))) == 0;
+
+    const int i_begin = causal ? (j0 / AT_KT) * AT_KT : 0;   // queries before the first key of the workgroup never see it
+    for (int i0 = i_begin; i0 < Tn; i0 += AT_KT) {
+        __syncthreads();
+        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta
+        for (int idx = tid; idx < AT_KT * (AT_DP / 8); idx += 256) {
+            const int rr = idx / (AT_DP / 8), c = (idx % (AT_DP / 8)) * 8;
+            const int i = i0 + rr;
+            float q[8], d8[8], o8[8], a[8], c8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = d8[j] = o8[j] = 0.f;
+            if (i < Tn) {
+                const T *qp = q_base + (long long)i * row_stride + c;
+                const T *dp = dout + ((long long)b * Tn + i) * D + (long long)h * Dh + c;
+                const T *op = out + ((long long)b * Tn + i) * D + (long long)h * Dh + c;
+                if (vec_ok && c + 8 <= Dh) { ld8(qp, q); ld8(dp, d8); ld8(op, o8); }
+                else {
+                    for (int j = 0; j < 8; ++j)
+                        if (c + j < Dh) { q[j] = ld1(qp + j); d8[j] = ld1(dp + j); o8[j] = ld1(op + j); }
+                }
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = (c + j) < Dh;
+                a[j] = ok ? q[j] + bias_u[h * Dh + c + j] : 0.f;
+                c8[j] = ok ? q[j] + bias_v[h * Dh + c + j] : 0.f;
+                part += d8[j] * o8[j];
+            }
+            st8(qu_lds + rr * AT_LD + c, a);
+            st8(qv_lds + rr * AT_LD + c, c8);
+            st8(do_lds + rr * AT_LD + c, d8);
+            // delta: 8 consecutive threads hold the 8 column chunks of one row
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if ((idx % (AT_DP / 8)) == 0) {
+                st_lds[64 + rr] = part;
+                st_lds[rr] = (i < Tn) ? lse[((long long)b * H + h) * Tn + i] : 0.f;
+            }
+        }
+        const int r_first = j0 - i0 - (AT_KT - 1) + Tn - 1;  // band row R <-> r = r_first + R ; keys [j0,j0+128) x queries [i0,i0+64)
+        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, AT_BAND, Dh);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ib = i0 + 32 * sub;
+            if (ib >= Tn) break;
+            if (causal && ib + 31 < j0 + wave * AT_QW) continue;   // every query of the sub-block precedes every key of the wave
+            // S[i (regs), j (lane)] = (Q+u) . K^T ; dPd = dO . V^T
+            f32x16 s_acc = {0}, dpd = {0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qu_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb[s], s_acc, 0, 0, 0);
+                const bf16x8 da = *reinterpret_cast<const bf16x8 *>(do_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                dpd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vb[s], dpd, 0, 0, 0);
+            }
+            // G[i (regs), r (lane)] = (Q+v) . Pband^T over the 64 band rows base + [0,64)
+            const int base = 32 * wave - 32 * sub + 32;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 g_acc = {0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qv_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
+                    // B operand: lane (col = band row base + 32rb + r, hh) holds P[row][16s + 8hh + e]
+                    const bf16x8 pb = *reinterpret_cast<const bf16x8 *>(p_lds + (base + 32 * rb + r) * AT_LD + 16 * s + 8 * hh);
+                    g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, pb, g_acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh) * 64 + 32 * rb + r] = g_acc[g];
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf16x8 pdb[2], dsb[2];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int il = (g & 3) + 8 * (g >> 2) + 4 * hh;
+                const int i = ib + il;
+                const float bd = g_lds[il * 64 + (r - il + 31)];
+                const bool masked = (!k_live) || (i >= Tn) || (causal && jk > i);
+                const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - st_lds[32 * sub + il]);
+                float keep = 1.f;
+                if (pdrop > 0.f) {
+                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + i) * Tn) + jk;
+                    keep = (at_rng(idx, seed) >= thr) ? keep_scale : 0.f;
+                }
+                pdb[g >> 3][g & 7] = (bf16_t)(p * keep);
+                dsb[g >> 3][g & 7] = (bf16_t)(p * (dpd[g] * keep - st_lds[64 + 32 * sub + il]) * scale);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // dV^T += dO^T . Pd ; dK^T += (Q+u)^T . dSs   (A through the transposing read of the query-tile rows)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int off = (32 * sub + 16 * s + 4 * hh + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(do_lds + off));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(do_lds + off + 8 * AT_LD));
+                    bf16x8 a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3]; a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pdb[s], dv[db], 0, 0, 0);
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(qu_lds + off));
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(qu_lds + off + 8 * AT_LD));
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3]; a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[s], dk[db], 0, 0, 0);
+                }
+        }
+    }
+    if (jk < Tn) {
+        T *dkp = dqkv + ((long long)b * Tn + jk) * row_stride + (long long)h * 3 * Dh + Dh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                if (d < Dh) { st1(dkp + d, dk[db][g]); st1(dkp + Dh + d, dv[db][g]); }
+            }
+    }
+}
+
+__global__ void attn_uv_reduce_kernel(const float *__restrict__ slab, float *__restrict__ du, float *__restrict__ dv, int nparts,
+                                      int H, int Dh) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;  // (h, which, d)
+    if (c >= H * 128) return;
+    const int h = c / 128, which = (c % 128) / 64, d = c % 64;
+    if (d >= Dh) return;
+    float s = 0.f;
+    for (int n = 0; n < nparts; ++n)
+        for (int w = 0; w < 4; ++w) s += slab[(((size_t)n * H + h) * 4 + w) * 128 + which * 64 + d];
+    (which == 0 ? du : dv)[h * Dh + d] = s;
+}
+
 extern "C" {
 
 size_t tsasr_relpos_attn_lds_bytes(void) {
@@ -240,6 +596,47 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_fwd: bad io_dtype %d", io_dtype);
     }
     TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
+    return 0;
+}
+
+size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
+    return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256);
+}
+
+/* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh]
+ * reading of the parameter storage, dbd [H, 2T-1, B, T] in io_dtype = scale * dS shifted back to the (r, i) grid; it
+ * must be ZERO-FILLED by the caller (entries without a key are not touched) and d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] *
+ * (q[b,i,h,:] + v[h,:]) is then one library GEMM per head. */
+int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, float *d_bias_u,
+                          float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                          unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out && dout && lse && dqkv && dbd && d_bias_u && d_bias_v && workspace,
+                    "tsasr_relpos_attn_bwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_bwd: head dim %d not supported", Dh);
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), "tsasr_relpos_attn_bwd: workspace too small");
+    const size_t lds_q = tsasr_relpos_attn_lds_bytes();
+    const size_t lds_kv = (size_t)(3 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)(128 + 4 * 32 * 64) * sizeof(float);
+    const int nqt = cdiv(T, AT_QB);
+    dim3 grid(nqt, H, B);
+    hipStream_t st = (hipStream_t)stream;
+    float *slab = (float *)workspace;
+    if (io_dtype == TSASR_F32) {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        relpos_attn_bwd_q_kernel<float><<<grid, 256, lds_q, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, T, H, Dh, scale, causal, pdrop, seed);
+    } else if (io_dtype == TSASR_BF16) {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        relpos_attn_bwd_q_kernel<bf16_t><<<grid, 256, lds_q, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, Dh, scale, causal, pdrop, seed);
+    } else {
+        TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);
+    }
+    // slab rows [(b, qtile)][h][wave][2][64] -> sum over (b, qtile, wave) per (h, which, d)
+    attn_uv_reduce_kernel<<<cdiv(H * 128, 64), 64, 0, st>>>(slab, d_bias_u, d_bias_v, B * nqt, H, Dh);
+    TSASR_CHECK_LAUNCH("tsasr_relpos_attn_bwd");
     return 0;
 }
 

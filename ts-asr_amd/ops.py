@@ -19,7 +19,7 @@ STATUS = {
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
     "matmul": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
-    "sentence_norm": "GLUE", "relpos_attention": "GLUE",
+    "relpos_attention": "HIP (d(pk) finished by one library bmm)", "sentence_norm": "GLUE",
 }
 
 _seed_counter = [0]
@@ -333,21 +333,34 @@ class _RelPosAttnFn(torch.autograd.Function):
     def backward(ctx, dout):
         qkvc, pkc, pu, pv, key_lens, out, lse = ctx.saved_tensors
         H, scale, causal, pdrop, seed = ctx.cfg
-        if pdrop > 0:
-            raise RuntimeError("HIP attention backward with dropout is not wired yet")
-        with torch.enable_grad():  # interim: recompute with device glue ops and differentiate that
-            a, b_, c_, d_ = (t.detach().requires_grad_() for t in (qkvc, pkc, pu, pv))
-            o, _ = _relpos_attention_glue(a, b_, c_, d_, key_lens, H, scale, causal, 0.0, False)
-            ga, gb, gc, gd = torch.autograd.grad(o, (a, b_, c_, d_), dout)
-        return ga, gb, gc, gd, None, None, None, None, None, None
+        B, T, D3 = qkvc.shape
+        D = D3 // 3
+        Dh, R = D // H, 2 * T - 1
+        u = _f32(pu).reshape(-1).contiguous()
+        v = _f32(pv).reshape(-1).contiguous()
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkvc)
+        dbd = torch.zeros(H, R, B, T, dtype=qkvc.dtype, device=qkvc.device)
+        du, dv = torch.empty_like(u), torch.empty_like(v)
+        ws = _ws(C.lib().tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), qkvc.device)
+        with prof.region("relpos_attn_bwd"):
+            C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
+                                                  C.ptr(lse), C.ptr(dqkv), C.ptr(dbd), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
+                                                  pdrop, seed, C.io_dtype(qkvc), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                    "tsasr_relpos_attn_bwd")
+        # d(pk): parameter-like reduction over the batch = one library GEMM per head on the shifted-back score gradient
+        q = qkvc.view(B, T, H, 3 * Dh)[..., :Dh]
+        qv = (q + v.view(1, 1, H, Dh).to(q.dtype)).permute(2, 0, 1, 3).reshape(H, B * T, Dh)
+        dpk = torch.bmm(dbd.view(H, R, B * T), qv).permute(1, 0, 2).reshape(R, D)
+        return dqkv, dpk, du.view(pu.shape).to(pu.dtype), dv.view(pv.shape).to(pv.dtype), None, None, None, None, None, None
 
 
 def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights):
-    """Fused HIP kernel unless the caller wants the [B,H,T,T] weights back (plots only) or trains with attention dropout
-    while the HIP backward is not wired for it."""
-    if need_weights or dropout_p > 0:
+    """Fused HIP kernels (forward and backward) unless the caller wants the [B,H,T,T] weights back (plots only)."""
+    if need_weights:
         return _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights)
-    return _RelPosAttnFn.apply(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, 0.0, 0), None
+    p = float(dropout_p)
+    return _RelPosAttnFn.apply(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0), None
 
 
 def _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights):
