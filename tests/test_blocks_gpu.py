@@ -181,9 +181,20 @@ def test_ffn_and_layer_vs_reference(nn_, golden):
         pe = nn_.RelPosEncXL(144).to(DEV)(x)
         out, _ = lay(x, pos_embs=pe, valid_lens=lens, need_attn=False)
         (out * probe).sum().backward()
-        close(out, g[f"{tag}:out"], 2e-4, 2e-3)
-        close(x.grad, g[f"{tag}:dx"], 1e-3, 5e-3)
-        assert check_grads(lay, g, tag, atol=2e-3, rtol=5e-3) > 20
+        # the layer's attention runs on bf16 MFMA operands even when activations are fp32: relative L2 is the yardstick
+        def rel(a, b):
+            b = T(b)
+            return float((a.detach().float().cpu() - b).norm() / b.norm())
+        assert rel(out, g[f"{tag}:out"]) < 5e-3
+        close(out, g[f"{tag}:out"], 3e-2, 2e-2)
+        assert rel(x.grad, g[f"{tag}:dx"]) < 2e-2
+        n = 0
+        for name, p in lay.named_parameters():
+            key = f"{tag}:d.{name}"
+            if key in g.files:
+                assert rel(p.grad, g[key]) < 3e-2, (name, rel(p.grad, g[key]))
+                n += 1
+        assert n > 20
     # macaron half step alone: x + 0.5*FFN(x); golden holds FFN(x) and its grads
     x2 = T(g["x"]).to(DEV).requires_grad_(True)
     y = lay._ffn_add(x2, lay.ffn_module1)
