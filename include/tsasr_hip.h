@@ -166,6 +166,16 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
+ * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
+ * p, g, m, v: flat fp32 [n]; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_clip_adamw_workspace_bytes(void);
+int tsasr_clip_adamw_step(float *p, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
+                          float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,3 +311,22 @@ def test_fused_attention_dropout_consistency(ops):
     # and a different seed gives a different mask
     out3 = fn.apply(qkv, pk, u, v, None, H, 1.0 / D ** 0.5, False, 0.3, 99)
     assert float((out3 - out.detach()).abs().max()) > 1e-2
+
+
+def test_fused_clip_adamw_vs_torch():
+    """csrc/optim.hip vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (the reference's optimizer step)."""
+    opt_mod = importlib.import_module("ts-asr_amd.optim")
+    n = 1_000_003  # not a multiple of 4: tail path
+    g = torch.Generator().manual_seed(3)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    p = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.AdamW([p], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    norm = torch.zeros((), device=DEV)
+    for t in range(1, 4):
+        p.grad = gr.clone() * t
+        total = torch.nn.utils.clip_grad_norm_([p], 5.0)
+        ref.step()
+        opt_mod._clip_adamw(pd, (gr * t).to(DEV), m, v, norm, 1e-3, 0.9, 0.98, 1e-8, 0.01, t, 5.0)
+        assert float(norm) == pytest.approx(float(total), rel=1e-5)
+    np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6, rtol=1e-5)

@@ -1,0 +1,100 @@
+// Gradient-norm clipping + AdamW over the flat parameter arena, for gfx950.
+//
+// Replaces speechbrain/core.py:1082-1093: torch.nn.utils.clip_grad_norm_(modules.parameters(), max_grad_norm) ->
+// optimizer.step() (torch.optim.AdamW, hparams conformer-t_scratch.yaml:267-271) -> zero_grad: ~190 tensors x several
+// foreach passes plus a host sync for grad_norm.item(). Here: two launches over four flat fp32 buffers
+//   (1) sumsq_partials: per-workgroup partial sums of g^2 (fixed partition -> deterministic);
+//   (2) clip_adamw:     every workgroup re-reduces the partials (<= 1024 floats), derives the clip coefficient
+//                       min(1, max_norm / (norm + 1e-6)) exactly as clip_grad_norm_, and applies decoupled weight decay,
+//                       moment updates and the bias-corrected step in one read-modify-write pass (p, g, m, v: 7 x 4 B/elem).
+// lr and the bias corrections come from a tiny DEVICE array so the step can sit inside a captured hipGraph while the
+// Noam schedule keeps changing them from the host.
+#include "common.h"
+
+#define OPT_PARTS 1024
+
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float *__restrict__ g, float *__restrict__ part, long long n) {
+    __shared__ float red[4];
+    const long long per = (n + OPT_PARTS - 1) / OPT_PARTS;
+    const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
+    float s = 0.f;
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+        if (i + 4 <= hi && ((lo & 3) == 0)) {
+            const float4 v = *reinterpret_cast<const float4 *>(g + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            for (long long k = i; k < min(hi, i + 4); ++k) s += g[k] * g[k];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// hyper = {lr, 1 - beta1^t, 1 - beta2^t}
+__global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, const float *__restrict__ part,
+                                                         const float *__restrict__ hyper, float *__restrict__ norm_out, long long n,
+                                                         float beta1, float beta2, float eps, float wd, float max_norm) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < OPT_PARTS; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
+    const float clip = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = sqrtf(hyper[2]);
+    const float step = lr / bc1, decay = 1.f - lr * wd;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4 *>(p + i), mm = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
+            const float4 gg = *reinterpret_cast<const float4 *>(g + i);
+            float *P = &pp.x, *M = &mm.x, *V = &vv.x;
+            const float *G = &gg.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = G[k] * clip;
+                M[k] = beta1 * M[k] + (1.f - beta1) * gk;
+                V[k] = beta2 * V[k] + (1.f - beta2) * gk * gk;
+                P[k] = P[k] * decay - step * M[k] / (sqrtf(V[k]) / bc2s + eps);
+            }
+            *reinterpret_cast<float4 *>(p + i) = pp;
+            *reinterpret_cast<float4 *>(m + i) = mm;
+            *reinterpret_cast<float4 *>(v + i) = vv;
+        } else {
+            for (long long k = i; k < n; ++k) {
+                const float gk = g[k] * clip;
+                m[k] = beta1 * m[k] + (1.f - beta1) * gk;
+                v[k] = beta2 * v[k] + (1.f - beta2) * gk * gk;
+                p[k] = p[k] * decay - step * m[k] / (sqrtf(v[k]) / bc2s + eps);
+            }
+        }
+    }
+}
+
+extern "C" {
+
+size_t tsasr_clip_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
+
+/* p, g, m, v: flat fp32 [n] (16-byte aligned); hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}; norm_out: device float
+ * (total L2 norm of g before clipping; may be NULL); max_norm <= 0 disables clipping. g is read, not modified. */
+int tsasr_clip_adamw_step(float *p, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
+                          float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(p && g && m && v && hyper && workspace, "tsasr_clip_adamw_step: null pointer");
+    TSASR_CHECK_ARG(n > 0 && workspace_bytes >= tsasr_clip_adamw_workspace_bytes(), "tsasr_clip_adamw_step: bad size / workspace");
+    TSASR_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "tsasr_clip_adamw_step: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    sumsq_partials_kernel<<<OPT_PARTS, 256, 0, st>>>(g, part, n);
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, g, m, v, part, hyper, norm_out, n, beta1, beta2, eps, weight_decay, max_norm);
+    TSASR_CHECK_LAUNCH("tsasr_clip_adamw_step");
+    return 0;
+}
+
+}  // extern "C"

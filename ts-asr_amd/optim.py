@@ -11,6 +11,7 @@ import functools
 import torch
 
 from . import _capi as C
+from . import prof
 
 
 class FusedClipAdamW:
@@ -43,21 +44,21 @@ class FusedClipAdamW:
             {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
 
+_hyper, _ws = {}, {}
+
+
 def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm):
-    """GLUE version (flat torch ops); replaced by the HIP kernel when csrc/optim.hip is present in the library."""
-    fn = getattr(C, "clip_adamw_step", None)
-    if fn is not None:
-        return fn(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm)
-    C.require_gpu(p)
-    norm = torch.linalg.vector_norm(g)
-    norm_out.copy_(norm)
-    if max_norm > 0:
-        g.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
-    p.mul_(1.0 - lr * wd)
-    m.mul_(b1).add_(g, alpha=1.0 - b1)
-    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-    denom = (v.sqrt() / (1.0 - b2 ** t) ** 0.5).add_(eps)
-    p.addcdiv_(m, denom, value=-lr / (1.0 - b1 ** t))
+    """One HIP pass over the arena (csrc/optim.hip). lr / bias corrections travel through a 3-float device array."""
+    C.require_gpu(p, g, m, v)
+    dev = p.device
+    if dev not in _hyper:
+        _hyper[dev] = torch.empty(3, dtype=torch.float32, device=dev)
+        _ws[dev] = torch.empty(C.lib().tsasr_clip_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
+    _hyper[dev].copy_(torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32), non_blocking=True)
+    with prof.region("clip_adamw"):
+        C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(_hyper[dev]), C.ptr(norm_out), p.numel(),
+                                              float(b1), float(b2), float(eps), float(wd), float(max_norm), C.ptr(_ws[dev]),
+                                              _ws[dev].numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
 
 
 class _WrappedTorchOptimizer:
