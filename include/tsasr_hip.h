@@ -169,12 +169,23 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
  * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
- * p, g, m, v: flat fp32 [n]; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
+ * p, g, m, v: flat fp32 [n]; p_bf16 (may be NULL): bf16 shadow of p rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
  * ------------------------------------------------------------------------------------------ */
 size_t tsasr_clip_adamw_workspace_bytes(void);
-int tsasr_clip_adamw_step(float *p, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
+int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with the operand layouts of a Linear layer (replaces the library GEMMs behind torch.nn.functional.linear on
+ * SB/nnet/attention.py:549-553,581-583,635,820-836, Conformer.py:76-82,98, SB/nnet/linear.py:64-78):
+ *   C[M,N] (+)= op(A)[M,K] . op(B)[K,N];  transA=0: A [M,K], 1: A [K,M];  transB=0: B [N,K] (a Linear weight), 1: B [K,N].
+ *   out_dtype TSASR_BF16 | TSASR_F32; accumulate (fp32 only): C += result, used to add weight gradients straight into the
+ *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
+int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                    int transA, int transB, int out_dtype, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

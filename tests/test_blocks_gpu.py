@@ -331,3 +331,50 @@ def test_fused_clip_adamw_vs_torch():
         assert float(norm) == pytest.approx(float(gr.double().norm()) * t, rel=2e-6)   # fp64 yardstick (torch's fp32 CPU sum is off by 1e-5)
         assert float(norm) == pytest.approx(float(total), rel=1e-4)
     np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(8000, 2048, 256), (8000, 256, 2048), (250, 144, 144), (1000, 640, 256), (129, 72, 200), (2048, 256, 8000)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_bf16_layouts(ops, M, N, K, ta, tb):
+    """csrc/gemm.hip vs fp32 matmul of the same bf16 operands: every operand layout, ragged edges, split-K accumulate."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    A = (a.t().contiguous() if ta else a).to(DEV)      # [K,M] when transA
+    Bm = (b.t().contiguous() if tb else b).to(DEV)     # [K,N] when transB
+    if (M % 8 and ta) or (N % 8 and tb):
+        pytest.skip("transposed operands need 8-element rows")
+    lda, ldb = (M if ta else K), (N if tb else K)
+    out = ops.gemm_bf16(A, Bm, M, N, K, lda, ldb, ta, tb)
+    rel = float((out.float().cpu() - ref).norm() / ref.norm())
+    assert rel < 4e-3, rel                               # bf16 output rounding
+    acc = torch.ones(M, N, device=DEV)
+    ops.gemm_bf16(A, Bm, M, N, K, lda, ldb, ta, tb, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), (ref + 1).numpy(), atol=2e-3 * K ** 0.5, rtol=1e-4)
+    f32 = ops.gemm_bf16(A, Bm, M, N, K, lda, ldb, ta, tb, out_dtype=torch.float32)
+    np.testing.assert_allclose(f32.cpu().numpy(), ref.numpy(), atol=2e-3 * K ** 0.5, rtol=1e-4)
+
+
+def test_linear_fn_grad_sink(ops):
+    """_LinearFn: forward/dgrad/wgrad vs torch, and the weight gradient lands in a registered arena without autograd's help."""
+    dp = importlib.import_module("ts-asr_amd.dp")
+    lin = torch.nn.Linear(256, 512, bias=False).to(DEV)
+    mods = torch.nn.ModuleDict({"l": lin})
+    arena = dp.GradArena(mods)
+    ops.set_grad_sink(arena)
+    try:
+        x = torch.randn(4, 50, 256, device=DEV).to(torch.bfloat16).requires_grad_()
+        arena.begin_backward(False)
+        y = ops.matmul_nt(x, lin.weight)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        arena.finish_backward()
+        w16 = lin.weight.detach().to(torch.bfloat16).float()
+        close(y, x.detach().float() @ w16.t(), 3e-2, 2e-2)
+        close(x.grad, dy.float() @ w16, 6e-2, 2e-2)
+        ref_dw = dy.float().reshape(-1, 512).t() @ x.detach().float().reshape(-1, 256)
+        close(lin.weight.grad, ref_dw, 2e-2, 1e-3)
+        assert lin.weight.grad.data_ptr() == arena.grads[arena.offset[id(lin.weight)]:].data_ptr()
+    finally:
+        ops.set_grad_sink(None)

@@ -59,7 +59,9 @@ _PROTOS = {
     "tsasr_relpos_attn_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
     "tsasr_relpos_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_clip_adamw_workspace_bytes": (c_size_t, []),
-    "tsasr_clip_adamw_step": (c_int, [c_void_p] * 6 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_clip_adamw_step": (c_int, [c_void_p] * 7 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
+    "tsasr_gemm_bf16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -194,6 +194,8 @@ class Brain:
         # backward produces them (dp.GradArena docstring)
         self.arena = _dp.GradArena(self.modules, world_size=_dp.world_size() if self.distributed else 1)
         self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm)
+        from . import ops as _ops
+        _ops.set_grad_sink(self.arena)
 
     # ---- the training step (core.py:1032-1096) -----------------------------------------------------
     @contextlib.contextmanager
@@ -219,8 +221,8 @@ class Brain:
             loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
             self.check_gradients(loss)
             (loss / self.grad_accumulation_factor).backward()
+            self.arena.finish_backward()      # waits for the overlapped bucket all-reduces (if any), averages over ranks
             if should_step:
-                self.arena.finish_backward()  # waits for the overlapped bucket all-reduces, averages over ranks
                 self.optimizer.step()         # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
                 self.arena.zero_()
                 self.optimizer_step += 1

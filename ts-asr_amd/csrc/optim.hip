@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float *__rest
 }
 
 // hyper = {lr, 1 - beta1^t, 1 - beta2^t}
-__global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                         float *__restrict__ v, const float *__restrict__ part,
+__global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, bf16_t *__restrict__ p16, const float *__restrict__ g,
+                                                         float *__restrict__ m, float *__restrict__ v, const float *__restrict__ part,
                                                          const float *__restrict__ hyper, float *__restrict__ norm_out, long long n,
                                                          float beta1, float beta2, float eps, float wd, float max_norm) {
     __shared__ float red[4];
@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
                 P[k] = P[k] * decay - step * M[k] / (sqrtf(V[k]) / bc2s + eps);
             }
             *reinterpret_cast<float4 *>(p + i) = pp;
+            if (p16) {
+                bf16x4 h4;
+                h4[0] = (bf16_t)pp.x; h4[1] = (bf16_t)pp.y; h4[2] = (bf16_t)pp.z; h4[3] = (bf16_t)pp.w;
+                *reinterpret_cast<bf16x4 *>(p16 + i) = h4;
+            }
             *reinterpret_cast<float4 *>(m + i) = mm;
             *reinterpret_cast<float4 *>(v + i) = vv;
         } else {
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
                 m[k] = beta1 * m[k] + (1.f - beta1) * gk;
                 v[k] = beta2 * v[k] + (1.f - beta2) * gk * gk;
                 p[k] = p[k] * decay - step * m[k] / (sqrtf(v[k]) / bc2s + eps);
+                if (p16) p16[k] = (bf16_t)p[k];
             }
         }
     }
@@ -79,9 +85,9 @@ extern "C" {
 
 size_t tsasr_clip_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
 
-/* p, g, m, v: flat fp32 [n] (16-byte aligned); hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}; norm_out: device float
+/* p, g, m, v: flat fp32 [n] (16-byte aligned); p_bf16: optional bf16 shadow of p (GEMM operand copy), rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}; norm_out: device float
  * (total L2 norm of g before clipping; may be NULL); max_norm <= 0 disables clipping. g is read, not modified. */
-int tsasr_clip_adamw_step(float *p, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
+int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
                           size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(p && g && m && v && hyper && workspace, "tsasr_clip_adamw_step: null pointer");
@@ -92,7 +98,7 @@ int tsasr_clip_adamw_step(float *p, const float *g, float *m, float *v, const fl
     sumsq_partials_kernel<<<OPT_PARTS, 256, 0, st>>>(g, part, n);
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, g, m, v, part, hyper, norm_out, n, beta1, beta2, eps, weight_decay, max_norm);
+    clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, (bf16_t *)p_bf16, g, m, v, part, hyper, norm_out, n, beta1, beta2, eps, weight_decay, max_norm);
     TSASR_CHECK_LAUNCH("tsasr_clip_adamw_step");
     return 0;
 }

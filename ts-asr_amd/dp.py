@@ -59,6 +59,9 @@ class GradArena:
         self.numel = sum(p.numel() for p in params)
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=self.device)
+        # bf16 shadow of every parameter (MFMA GEMM operand copy); the fused optimizer rewrites it in the same pass
+        self.flat_params16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
+        self.in_backward = False
         self.sync_enabled = True
         self._sync_this_step = False
         self._order_seen, self._order_final = [], False
@@ -92,6 +95,7 @@ class GradArena:
             p.data = self.flat_params[o:o + n].view(p.shape)
             p.grad = self.grads[o:o + n].view(p.shape)
         self.params_ordered = list(params)
+        self.refresh_shadow()
         self.buckets, start, pend = [], 0, []
         limit = max(1, self.bucket_bytes // 4)
         for p in params:
@@ -104,8 +108,26 @@ class GradArena:
             self.buckets.append({"lo": start, "hi": self.numel, "ids": set(pend), "left": len(pend)})
         self.bucket_of = {i: b for b in self.buckets for i in b["ids"]}
 
+    def refresh_shadow(self):
+        """(Re)build the bf16 shadow and hand every parameter its view (``p._bf16``; valid while ``p._version`` is unchanged)."""
+        if self.flat_params16 is None:
+            return
+        self.flat_params16.copy_(self.flat_params)
+        for p in self.params_ordered:
+            o, n = self.offset[id(p)], p.numel()
+            p._bf16 = self.flat_params16[o:o + n].view(p.shape)
+            p._bf16_ver = p._version
+
+    # ---- gradient sink: kernels that add a weight gradient straight into the arena (ops._LinearFn) ---------
+    def accepts(self, p):
+        return self.in_backward and id(p) in self.offset and p.grad is not None
+
+    def mark_ready(self, p):
+        self._on_grad(p)
+
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):
+        self.in_backward = True
         self._sync_this_step = bool(will_sync) and self.sync_enabled and self.world_size > 1
         for b in self.buckets:
             b["left"], b["sent"] = len(b["ids"]), False
@@ -132,6 +154,7 @@ class GradArena:
             self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
     def finish_backward(self):
+        self.in_backward = False
         if self._sync_this_step:
             for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step
                 self._send(b)

@@ -18,7 +18,7 @@ STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
-    "matmul": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
+    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
     "relpos_attention": "HIP (d(pk) finished by one library bmm)", "sentence_norm": "GLUE",
 }
 
@@ -45,15 +45,100 @@ def _w(p, like):
 
 
 # ---------------------------------------------------------------------------------------------------------
+_GRAD_SINK = None
+
+
+def set_grad_sink(arena):
+    """The gradient arena that weight-gradient GEMMs may accumulate into directly (dp.GradArena protocol)."""
+    global _GRAD_SINK
+    _GRAD_SINK = arena
+
+
+def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=torch.bfloat16, accumulate=False, ldc=None):
+    """C[M,N] (+)= op(A).op(B) on the hand-written MFMA kernel (csrc/gemm.hip); see include/tsasr_hip.h for the layouts."""
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    od = C.F32 if out.dtype == torch.float32 else C.BF16
+    nws = C.lib().tsasr_gemm_bf16_workspace_bytes(M, N, K, od)
+    ws = _ws(nws, a.device) if nws else None
+    with prof.region("gemm_bf16"):
+        C.check(C.lib().tsasr_gemm_bf16(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, N if ldc is None else ldc, int(trans_a),
+                                        int(trans_b), od, int(accumulate), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                "tsasr_gemm_bf16")
+    return out
+
+
+def _bf16_weight(w):
+    sh = getattr(w, "_bf16", None)
+    if sh is not None and getattr(w, "_bf16_ver", -1) == w._version:
+        return sh
+    return w.detach().to(torch.bfloat16)
+
+
+def _gemm_ok(x, weight):
+    return (x.dtype == torch.bfloat16 and x.is_cuda and weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 8 == 0
+            and weight.shape[0] % 8 == 0 and weight.stride(0) % 8 == 0 and x.shape[-1] == weight.shape[1])
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x . W^T on the HIP GEMM; dgrad on the same kernel; the weight gradient is added straight into the fp32 gradient
+    arena when one is registered (no bf16->fp32 cast kernel, no separate accumulate kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        N, K = weight.shape
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w16 = _bf16_weight(weight)
+        if w16.stride(1) != 1 or w16.stride(0) % 8 != 0 or w16.data_ptr() % 16 != 0:
+            w16 = w16.contiguous()
+        M = x2.shape[0]
+        y = gemm_bf16(x2, w16, M, N, K, K, w16.stride(0), 0, 0)
+        ctx.save_for_backward(x2, w16)
+        ctx.weight = weight
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16 = ctx.saved_tensors
+        weight = ctx.weight
+        N, K = weight.shape
+        M = x2.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_bf16(dy2, w16, M, K, N, N, w16.stride(0), 0, 1).view(ctx.xshape)      # dy . W
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = _GRAD_SINK
+            if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
+                    and weight.grad.is_contiguous()):
+                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad, accumulate=True)     # grad += dy^T . x
+                sink.mark_ready(weight)
+            else:
+                dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype)
+        return dx, dw
+
+
 def matmul_nt(x, weight):
-    """x @ weight^T : plain library GEMM (hipBLASLt through PyTorch-ROCm), weight cast to the activation dtype."""
+    """x @ weight^T. bf16 activations: hand-written MFMA GEMM (csrc/gemm.hip); fp32 activations (parity runs): the exact fp32
+    library GEMM through PyTorch-ROCm."""
+    if _gemm_ok(x, weight):
+        return _LinearFn.apply(x, weight)
     return F.linear(x, _w(weight, x))
 
 
 def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
     """Library GEMM + ONE hand-written epilogue pass (bias, LeakyReLU, dropout); bias-only rows ride the GEMM epilogue."""
     if act_slope is None and not (training and dropout_p > 0):
-        return F.linear(x, _w(weight, x), _w(bias, x))
+        if bias is None:
+            return matmul_nt(x, weight)
+        if not _gemm_ok(x, weight):
+            return F.linear(x, _w(weight, x), _w(bias, x))
     return bias_act_dropout(matmul_nt(x, weight), bias, act_slope, dropout_p, training)
 
 

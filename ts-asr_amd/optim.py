@@ -34,7 +34,7 @@ class FusedClipAdamW:
         b1, b2 = g["betas"]
         a = self.arena
         _clip_adamw(a.flat_params, a.grads, self.exp_avg, self.exp_avg_sq, self.last_grad_norm, g["lr"], b1, b2, g["eps"],
-                    g["weight_decay"], self.t, self.max_grad_norm)
+                    g["weight_decay"], self.t, self.max_grad_norm, a.flat_params16)
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
@@ -47,7 +47,7 @@ class FusedClipAdamW:
 _hyper, _ws = {}, {}
 
 
-def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm):
+def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm, p16=None):
     """One HIP pass over the arena (csrc/optim.hip). lr / bias corrections travel through a 3-float device array."""
     C.require_gpu(p, g, m, v)
     dev = p.device
@@ -56,7 +56,7 @@ def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm):
         _ws[dev] = torch.empty(C.lib().tsasr_clip_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
     _hyper[dev].copy_(torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32), non_blocking=True)
     with prof.region("clip_adamw"):
-        C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(_hyper[dev]), C.ptr(norm_out), p.numel(),
+        C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(p16), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(_hyper[dev]), C.ptr(norm_out), p.numel(),
                                               float(b1), float(b2), float(eps), float(wd), float(max_norm), C.ptr(_ws[dev]),
                                               _ws[dev].numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
 
