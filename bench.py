@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ragged", action="store_true", help="lengths U(0.6,1) sorted ascending instead of all 1.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -131,12 +132,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    use_graph = (not args.eager) and args.accum == 1 and not args.ragged
+    if use_graph:
+        brain.enable_hip_graph(warmup_steps=min(3, max(2, args.warmup - 1)))
+    for i in range(max(args.warmup, 4 if use_graph else 0)):   # graph mode: >= 3 eager steps + the capture step are warm-up
         brain.fit_batch(batch)
         torch.cuda.synchronize()
-        log(f"warm-up step {i + 1}/{args.warmup} done")
+        log(f"warm-up step {i + 1} done" + (" (hipGraph captured)" if brain._graph is not None else ""))
     sync()
-    prof.ENABLED = True
+    graphed = brain._graph is not None
+    prof.ENABLED = not graphed          # HIP events cannot bracket kernels inside a replayed graph
     prof.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -145,6 +150,17 @@ def main():
     elapsed = time.perf_counter() - t0
     prof.ENABLED = False
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    loss = loss.clone()
+    if graphed:
+        # per-kernel durations: the same step, same process, run eagerly right after the timed region with HIP events
+        # around every hand-written kernel launch (the graph replays the very same kernels with the same arguments)
+        brain._graph_mode = False
+        prof.ENABLED = True
+        for _ in range(3):
+            brain.fit_batch(batch)
+        torch.cuda.synchronize()
+        prof.ENABLED = False
+        brain._graph_mode = True
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -174,7 +190,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: conformer-t_scratch 12L d256 (+6L speaker encoder), mel [32,1000,80] + "
                                    "enrollment mel [32,500,80] + tokens [32,120], injection cat, dropout 0.1, lens "
                                    + ("U(0.6,1) ascending" if args.ragged else "1.0"),
-                       "global_batch": world * B_LOCAL, "grad_accumulation_factor": args.accum, "parallelism": f"dp{world}"},
+                       "global_batch": world * B_LOCAL, "grad_accumulation_factor": args.accum, "parallelism": f"dp{world}",
+                       "hip_graph": brain._graph is not None},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 1),
             "rnnt_joint_loss_ms": round(rnnt_ms, 4),
             "loss": round(float(loss), 4), "nonfinite_steps": nonfinite,

@@ -89,25 +89,30 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
                         const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
                         int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Dropout masks are a pure function of (seed + *seed_dev, element index); seed_dev (device uint64, may be NULL) is advanced once per
+ * training step by tsasr_seed_advance so that a captured hipGraph still draws fresh masks every replay. */
+int tsasr_seed_advance(unsigned long long *seed_dev, unsigned long long increment, void *stream);
+
 /* y = dropout_p(act(x + bias))  - the Linear-bias + activation() + Dropout chain of PositionalwiseFeedForward
  * (SB/nnet/attention.py:820-836). bias may be NULL; act_slope < 0 = no activation; the dropout mask is a pure function
  * of (seed, element index) and is regenerated by the backward (never stored). dbias may be NULL. N % 8 == 0. */
 int tsasr_bias_act_dropout_fwd(const void *x, const float *bias, void *y, long long M, int N, float act_slope, float p,
-                               unsigned long long seed, int io_dtype, void *stream);
+                               unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream);
 size_t tsasr_colpart_workspace_bytes(long long M, int N);
 int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, long long M, int N, float act_slope,
-                               float p, unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes,
-                               void *stream);
+                               float p, unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* out = res + alpha * timemask(dropout_p(x + bias)) - the "Dropout -> 0.5*x + residual" and
  * "Dropout -> masked_fill_(pad) -> + residual" tails of ConformerEncoderLayer / ConvolutionModule
  * (Conformer.py:113-114,239-259). rows = [B, Trows] flattened; valid_lens (int32 [B], may be NULL) zeroes frames
  * t >= valid_lens[b] of the x branch. res may be NULL. Backward gives dx (dres = dout needs no kernel). */
 int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
-                          float p, unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *stream);
+                          float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                          int io_dtype, void *stream);
 int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
-                          unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, int io_dtype,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -156,7 +161,7 @@ int tsasr_frontend_col2im(const void *dA, const void *dR, void *dx, int B, int T
 size_t tsasr_relpos_attn_lds_bytes(void);
 int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
-                          unsigned long long seed, int io_dtype, void *stream);
+                          unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream);
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H);
 /* Backward: dqkv [B,T,H,3*Dh] fully written; d_bias_u/d_bias_v fp32 [H*Dh] ([H,Dh] reading of the parameter storage);
  * dbd [H, 2T-1, B, T] (io_dtype) = scale * dS shifted back onto the (r, i) grid - ZERO-FILL it before the call; the host gets
@@ -164,7 +169,8 @@ size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H);
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
-                          unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+                          unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
@@ -186,6 +192,17 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                     int transA, int transB, int out_dtype, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LSTM cell steps of the prediction network (replaces torch.nn.LSTM behind SB/nnet/RNN.py:244-278; gate order i,f,g,o).
+ * gates [B,U,4H] fp32: pre-activations (x W_ih^T + biases + h_{t-1} W_hh^T, the last term added by tsasr_gemm_bf16 with
+ * accumulate) in, ACTIVATED gates out; c [B,U,H] fp32; h [B,U,H] io_dtype. One launch per time step; step t reads step t-1.
+ * bwd: dout [B,U,H] (gradient of the layer output), dh_rec [B,H] fp32 (= dgates_{t+1} . W_hh, ignored at t = U-1),
+ * dc_io [B,H] fp32 carried between steps, dgates [B,U,4H] io_dtype out (operand of the dh / dW GEMMs).
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_lstm_cell_fwd(float *gates, float *c, void *h, int B, int U, int H, int t, int io_dtype, void *stream);
+int tsasr_lstm_cell_bwd(const float *gates, const float *c, const void *dout, const float *dh_rec, float *dc_io, void *dgates, int B,
+                        int U, int H, int t, int io_dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -378,3 +378,24 @@ def test_linear_fn_grad_sink(ops):
         assert lin.weight.grad.data_ptr() == arena.grads[arena.offset[id(lin.weight)]:].data_ptr()
     finally:
         ops.set_grad_sink(None)
+
+
+def test_lstm_hip_path_vs_oracle(ops):
+    """bf16 predictor LSTM (HIP cell kernels + HIP GEMMs) vs the oracle's explicit recurrence (oracle/tsasr_ref.lstm), fwd + bwd."""
+    from oracle import tsasr_ref as R
+    B, U, I, H = 8, 21, 28, 128
+    g = torch.Generator().manual_seed(9)
+    rnn = torch.nn.LSTM(I, H, batch_first=True).to(DEV)
+    tok = torch.randint(0, 29, (B, U), generator=g)
+    x = R.one_hot_embedding(tok, 29, 0)
+    dout = torch.randn(B, U, H, generator=g)
+    sd = {"rnn." + k: v.detach().cpu().clone().requires_grad_() for k, v in rnn.state_dict().items()}
+    ref, _ = R.lstm(x, sd, "")
+    ref.backward(dout)
+    xg = x.to(DEV).to(torch.bfloat16)
+    out, _ = ops.lstm(xg, rnn)
+    out.backward(dout.to(DEV).to(torch.bfloat16))
+    assert float((out.float().cpu() - ref.detach()).norm() / ref.detach().norm()) < 1e-2
+    for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        a, r_ = getattr(rnn, k).grad.cpu(), sd["rnn." + k].grad
+        assert float((a - r_).norm() / r_.norm()) < 3e-2, k

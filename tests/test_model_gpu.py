@@ -163,3 +163,25 @@ def test_bf16_step_close_to_fp32_oracle_and_updates_weights():
     assert brain.optimizer_step == 1
     assert not torch.equal(w_before, brain.modules.encoder_proj.w.weight)  # AdamW moved the (arena-backed) weights
     assert brain.flush_nonfinite() == 0
+
+
+def test_hip_graph_replay_equals_eager():
+    """The captured hipGraph step (forward, loss, backward, clip+AdamW) must reproduce the eager steps bit for bit
+    (dropout = 0 in this config; every kernel is deterministic), including the Noam schedule acting through device memory."""
+    inp = golden_inputs()
+    losses = {}
+    for mode in ("eager", "graph"):
+        brain, h = entry._config1_brain(DEV, "bf16")
+        brain.modules.train()
+        if mode == "graph":
+            brain.enable_hip_graph(warmup_steps=2)
+        batch = make_batch(inp).to(DEV)
+        ls = []
+        for _ in range(6):
+            ls.append(float(brain.fit_batch(batch)))
+        losses[mode] = ls
+        assert brain.optimizer_step == 6
+        if mode == "graph":
+            assert brain._graph is not None
+    assert losses["eager"][0] > losses["eager"][-1]            # it trains
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)

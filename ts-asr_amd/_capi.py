@@ -40,11 +40,12 @@ _PROTOS = {
     "tsasr_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_ll, c_int, c_float, c_float, c_int, c_void_p]),
     "tsasr_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
     "tsasr_layernorm_bwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
-    "tsasr_bias_act_dropout_fwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_int, c_void_p]),
+    "tsasr_seed_advance": (c_int, [c_void_p, c_ull, c_void_p]),
+    "tsasr_bias_act_dropout_fwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_void_p]),
     "tsasr_colpart_workspace_bytes": (c_size_t, [c_ll, c_int]),
-    "tsasr_bias_act_dropout_bwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_int, c_void_p, c_size_t, c_void_p]),
-    "tsasr_dropout_add_fwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p]),
-    "tsasr_dropout_add_bwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_bias_act_dropout_bwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_dropout_add_fwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "tsasr_dropout_add_bwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_convmod_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_int, c_void_p]),
     "tsasr_convmod_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_convmod_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),
@@ -55,13 +56,15 @@ _PROTOS = {
     "tsasr_frontend_im2col": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "tsasr_frontend_col2im": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "tsasr_relpos_attn_lds_bytes": (c_size_t, []),
-    "tsasr_relpos_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_int, c_void_p]),
+    "tsasr_relpos_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p]),
     "tsasr_relpos_attn_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
-    "tsasr_relpos_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_relpos_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_clip_adamw_workspace_bytes": (c_size_t, []),
     "tsasr_clip_adamw_step": (c_int, [c_void_p] * 7 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_gemm_bf16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_lstm_cell_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "tsasr_lstm_cell_bwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
 }
 
 

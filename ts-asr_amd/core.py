@@ -150,6 +150,8 @@ class Brain:
         self.grad_norm_epoch = []
         self.optimizer = None
         self.arena = None
+        self._graph_mode, self._graph, self._graph_warmup, self._eager_steps = False, None, 3, 0
+        self._static_batch = self._static_loss = None
         self.rank = int(os.environ.get("RANK", 0))
         self.distributed = bool(self.distributed_launch) and _dp.is_initialized()
 
@@ -215,31 +217,90 @@ class Brain:
             self.on_fit_start()
         self.valid_step += 1
         should_step = (self.valid_step % self.grad_accumulation_factor) == 0
-        with self.no_sync(not should_step):
-            self.arena.begin_backward(should_step)
-            outputs = self.compute_forward(batch, Stage.TRAIN)
-            loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
-            self.check_gradients(loss)
-            (loss / self.grad_accumulation_factor).backward()
-            self.arena.finish_backward()      # waits for the overlapped bucket all-reduces (if any), averages over ranks
+        if self._graph_mode and self.grad_accumulation_factor == 1:
+            loss, outputs = self._fit_batch_graph(batch), None
+        else:
+            with self.no_sync(not should_step):
+                loss, outputs = self._device_step(batch, should_step, comm=True)
             if should_step:
-                self.optimizer.step()         # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
-                self.arena.zero_()
                 self.optimizer_step += 1
         self.on_fit_batch_end(batch, outputs, loss, should_step)
-        return loss.detach()
+        return loss
+
+    def _device_step(self, batch, should_step, comm):
+        """Everything of one micro-batch that runs on the GPU; no host synchronisation, no host->device copies: capturable."""
+        from . import ops as _ops
+        _ops.begin_step(self.device)
+        self.arena.begin_backward(should_step and comm)
+        outputs = self.compute_forward(batch, Stage.TRAIN)
+        loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+        self.check_gradients(loss)
+        (loss / self.grad_accumulation_factor).backward()
+        self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
+        if should_step and (comm or not self.distributed):
+            if comm:
+                self.optimizer.prepare()
+            self.optimizer.launch()           # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
+            self.arena.zero_()
+        return loss.detach(), outputs
+
+    # ---- hipGraph replay of the whole step (HIP streams and graphs instead of a tracing compiler) -----------------
+    def enable_hip_graph(self, warmup_steps=3):
+        """After ``warmup_steps`` eager steps (allocator warm, arena laid out in backward order) the step is captured once and
+        replayed: ~3000 launches collapse into one graph launch. Needs fixed batch shapes; with more than one rank the
+        gradient all-reduce runs between two graphs (forward+backward | optimizer)."""
+        self._graph_mode, self._graph_warmup = True, int(warmup_steps)
+
+    def _fit_batch_graph(self, batch):
+        if self._graph is None:
+            if self._eager_steps < self._graph_warmup:
+                self._eager_steps += 1
+                loss, _ = self._device_step(batch, True, comm=True)
+                self.optimizer_step += 1
+                return loss
+            self._capture(batch)
+        else:
+            self._copy_batch(batch)
+        self.optimizer.prepare()
+        self._graph.replay()
+        if self.distributed:                    # one big averaged all-reduce between the two halves of the step
+            self.arena.allreduce_all()
+            self.optimizer.launch()
+            self.arena.zero_()
+        self.optimizer_step += 1
+        return self._static_loss
+
+    def _capture(self, batch):
+        self._static_batch = batch.to(self.device)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_loss, _ = self._device_step(self._static_batch, True, comm=False)
+        self._graph = g
+
+    def _copy_batch(self, batch):
+        if batch is self._static_batch:
+            return
+        for k in self._static_batch._keys:
+            dst, src = getattr(self._static_batch, k), getattr(batch, k)
+            if isinstance(dst, tuple):
+                for d, s_ in zip(dst, src):
+                    if d.shape != s_.shape:
+                        raise ValueError("hip-graph mode needs fixed batch shapes; call with enable_hip_graph off for ragged batches")
+                    d.copy_(s_, non_blocking=True)
 
     def check_gradients(self, loss):
         """Counts non-finite losses on the device (reference: counted, the step is NOT skipped; core.py:1115-1150)."""
-        bad = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(())
-        self._nonfinite_dev = bad if self._nonfinite_dev is None else self._nonfinite_dev + bad
+        if self._nonfinite_dev is None:
+            self._nonfinite_dev = torch.zeros((), dtype=torch.int32, device=loss.device)
+        self._nonfinite_dev.add_((~torch.isfinite(loss.detach())).to(torch.int32).reshape(()))
         return True
 
     def flush_nonfinite(self):
         """One host read for all the steps since the last flush; raises like the reference when patience is exhausted."""
         if self._nonfinite_dev is not None:
             self.nonfinite_count += int(self._nonfinite_dev.item())
-            self._nonfinite_dev = None
+            self._nonfinite_dev.zero_()
         if self.nonfinite_count > self.nonfinite_patience:
             raise ValueError("Loss is not finite and patience is exhausted.")
         return self.nonfinite_count

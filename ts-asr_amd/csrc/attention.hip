@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
                                                               const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                               const int32_t *__restrict__ key_lens, T *__restrict__ out,
                                                               float *__restrict__ lse, int Tn, int H, int Dh, float scale,
-                                                              int causal, float pdrop, unsigned long long seed) {
+                                                              int causal, float pdrop, unsigned long long seed,
+                                                              const unsigned long long *__restrict__ seed_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (seed_dev) seed += *seed_dev;
     bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);             // [AT_KT][AT_LD]
     bf16_t *v_lds = k_lds + AT_KT * AT_LD;                        // [AT_KT][AT_LD]
     bf16_t *p_lds = v_lds + AT_KT * AT_LD;                        // [AT_BAND][AT_LD]
@@ -230,8 +232,9 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
                                                                 T *__restrict__ dqkv, T *__restrict__ dbd, float *__restrict__ slab_uv,
                                                                 int Bn, int Tn, int H, int Dh, float scale, int causal, float pdrop,
-                                                                unsigned long long seed) {
+                                                                unsigned long long seed, const unsigned long long *__restrict__ seed_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (seed_dev) seed += *seed_dev;
     bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);
     bf16_t *v_lds = k_lds + AT_KT * AT_LD;
     bf16_t *p_lds = v_lds + AT_KT * AT_LD;
@@ -404,8 +407,10 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                                                                  const int32_t *__restrict__ key_lens, const T *__restrict__ out,
                                                                  const T *__restrict__ dout, const float *__restrict__ lse,
                                                                  T *__restrict__ dqkv, int Tn, int H, int Dh, float scale, int causal,
-                                                                 float pdrop, unsigned long long seed) {
+                                                                 float pdrop, unsigned long long seed,
+                                                                 const unsigned long long *__restrict__ seed_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (seed_dev) seed += *seed_dev;
     bf16_t *qu_lds = reinterpret_cast<bf16_t *>(smem);      // [64][LD]  Q + u
     bf16_t *qv_lds = qu_lds + AT_KT * AT_LD;                // [64][LD]  Q + v
     bf16_t *do_lds = qv_lds + AT_KT * AT_LD;                // [64][LD]  dO
@@ -579,7 +584,7 @@ size_t tsasr_relpos_attn_lds_bytes(void) {
  * Dh <= 64; dropout mask is a pure function of (seed, b, h, i, j). */
 int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
-                          unsigned long long seed, int io_dtype, void *stream) {
+                          unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream) {
     TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out, "tsasr_relpos_attn_fwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_fwd: head dim %d not supported (1..%d)", Dh, AT_DP);
     TSASR_CHECK_ARG(pdrop >= 0.f && pdrop < 1.f, "tsasr_relpos_attn_fwd: bad dropout %f", pdrop);
@@ -588,10 +593,10 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else if (io_dtype == TSASR_BF16) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_fwd: bad io_dtype %d", io_dtype);
     }
@@ -610,7 +615,8 @@ size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
-                          unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+                          unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
+                          void *stream) {
     TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out && dout && lse && dqkv && dbd && d_bias_u && d_bias_v && workspace,
                     "tsasr_relpos_attn_bwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_bwd: head dim %d not supported", Dh);
@@ -624,13 +630,13 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
     if (io_dtype == TSASR_F32) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        relpos_attn_bwd_q_kernel<float><<<grid, 256, lds_q, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed);
-        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_bwd_q_kernel<float><<<grid, 256, lds_q, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else if (io_dtype == TSASR_BF16) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        relpos_attn_bwd_q_kernel<bf16_t><<<grid, 256, lds_q, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed);
-        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, Dh, scale, causal, pdrop, seed);
+        relpos_attn_bwd_q_kernel<bf16_t><<<grid, 256, lds_q, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);
     }

@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ p
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
                                                                    T *__restrict__ y, long long total, int Ncols, float slope,
-                                                                   float p, unsigned long long seed) {
+                                                                   float p, unsigned long long seed, const unsigned long long *__restrict__ seed_dev) {
     constexpr int N = Vec<T>::N;
+    if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
@@ -280,9 +281,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ y,
                                                                    T *__restrict__ dx, float *__restrict__ part, long long M,
                                                                    int Ncols, float slope, float p, unsigned long long seed,
-                                                                   int rows_per_wg) {
+                                                                   const unsigned long long *__restrict__ seed_dev, int rows_per_wg) {
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float cred[];  // [slots][Ncols] when slots > 1 and part != NULL
+    if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
@@ -340,8 +342,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
                                                               const T *__restrict__ res, T *__restrict__ out, long long total,
                                                               int Ncols, float alpha, float p, unsigned long long seed,
+                                                              const unsigned long long *__restrict__ seed_dev,
                                                               const int32_t *__restrict__ valid_lens, int Trows) {
     constexpr int N = Vec<T>::N;
+    if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
@@ -366,9 +370,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restrict__ dout, T *__restrict__ dx,
                                                               float *__restrict__ part, long long M, int Ncols, float alpha,
                                                               float p, unsigned long long seed,
+                                                              const unsigned long long *__restrict__ seed_dev,
                                                               const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float cred[];
+    if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_threshold(p);
     const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
@@ -466,7 +472,18 @@ static int launch_ln_bwd(const void *dy, const void *x, const float *g, const fl
     return 0;
 }
 
+__global__ void seed_advance_kernel(unsigned long long *s, unsigned long long inc) { *s += inc; }
+
 extern "C" {
+
+/* *seed_dev += increment: one launch at the start of every training step (inside the captured graph), so that the
+ * counter-based dropout masks change from step to step although every kernel argument is frozen by the capture. */
+int tsasr_seed_advance(unsigned long long *seed_dev, unsigned long long increment, void *stream) {
+    TSASR_CHECK_ARG(seed_dev, "tsasr_seed_advance: null pointer");
+    seed_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(seed_dev, increment);
+    TSASR_CHECK_LAUNCH("tsasr_seed_advance");
+    return 0;
+}
 
 int tsasr_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
                         long long M, int D, float eps, float act_slope, int io_dtype, void *stream) {
@@ -518,14 +535,14 @@ static unsigned ew_grid(long long total, int N) {
 }
 
 int tsasr_bias_act_dropout_fwd(const void *x, const float *bias, void *y, long long M, int N, float act_slope, float p,
-                               unsigned long long seed, int io_dtype, void *stream) {
+                               unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream) {
     TSASR_CHECK_ARG(x && y, "tsasr_bias_act_dropout_fwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_bias_act_dropout_fwd: bad shape/p (M=%lld N=%d p=%f)", M, N, p);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        bias_act_dropout_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (float *)y, M * N, N, act_slope, p, seed);
+        bias_act_dropout_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (float *)y, M * N, N, act_slope, p, seed, seed_dev);
     else if (io_dtype == TSASR_BF16)
-        bias_act_dropout_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (bf16_t *)y, M * N, N, act_slope, p, seed);
+        bias_act_dropout_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (bf16_t *)y, M * N, N, act_slope, p, seed, seed_dev);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_fwd");
     return 0;
@@ -537,8 +554,8 @@ size_t tsasr_colpart_workspace_bytes(long long M, int N) {
 }
 
 int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, long long M, int N, float act_slope,
-                               float p, unsigned long long seed, int io_dtype, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+                               float p, unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace,
+                               size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(dy && dx && (act_slope < 0.f || y), "tsasr_bias_act_dropout_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "tsasr_bias_act_dropout_bwd: bad shape");
     TSASR_CHECK_ARG(!dbias || (workspace && workspace_bytes >= tsasr_colpart_workspace_bytes(M, N)), "tsasr_bias_act_dropout_bwd: workspace too small");
@@ -547,9 +564,9 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
     float *part = dbias ? (float *)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        bias_act_dropout_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dy, (const float *)y, (float *)dx, part, M, N, act_slope, p, seed, rpw);
+        bias_act_dropout_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dy, (const float *)y, (float *)dx, part, M, N, act_slope, p, seed, seed_dev, rpw);
     else if (io_dtype == TSASR_BF16)
-        bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, rpw);
+        bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, seed_dev, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_bwd");
@@ -557,23 +574,24 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
 }
 
 int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
-                          float p, unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *stream) {
+                          float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                          int io_dtype, void *stream) {
     TSASR_CHECK_ARG(x && out, "tsasr_dropout_add_fwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_dropout_add_fwd: bad shape/p");
     TSASR_CHECK_ARG(!valid_lens || (Trows > 0 && M % Trows == 0), "tsasr_dropout_add_fwd: rows %lld not a multiple of T=%d", M, Trows);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        dropout_add_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (const float *)res, (float *)out, M * N, N, alpha, p, seed, valid_lens, Trows);
+        dropout_add_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (const float *)res, (float *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows);
     else if (io_dtype == TSASR_BF16)
-        dropout_add_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)out, M * N, N, alpha, p, seed, valid_lens, Trows);
+        dropout_add_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_fwd");
     return 0;
 }
 
 int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
-                          unsigned long long seed, const int32_t *valid_lens, int Trows, int io_dtype, void *workspace,
-                          size_t workspace_bytes, void *stream) {
+                          unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, int io_dtype,
+                          void *workspace, size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(dout && dx, "tsasr_dropout_add_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "tsasr_dropout_add_bwd: bad shape");
     TSASR_CHECK_ARG(!dbias || (workspace && workspace_bytes >= tsasr_colpart_workspace_bytes(M, N)), "tsasr_dropout_add_bwd: workspace too small");
@@ -582,9 +600,9 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     float *part = dbias ? (float *)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        dropout_add_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
     else if (io_dtype == TSASR_BF16)
-        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");

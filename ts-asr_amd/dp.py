@@ -185,5 +185,16 @@ class GradArena:
             self._layout(order)
             self._order_final, self._reorder_pending, self._order_seen = True, False, []
 
+    def allreduce_all(self):
+        """Average the whole arena over the ranks in bucket-sized collectives (graph mode: between the two captured halves)."""
+        if self.world_size <= 1:
+            return
+        nccl = dist.get_backend(self.group) == "nccl"
+        for b in self.buckets:
+            chunk = self.grads[b["lo"]:b["hi"]]
+            dist.all_reduce(chunk, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
+            if not nccl:
+                chunk.div_(self.world_size)
+
     def grad_norm(self):
         return torch.linalg.vector_norm(self.grads)

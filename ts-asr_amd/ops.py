@@ -18,17 +18,34 @@ STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
-    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
+    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm(bf16 training)": "HIP cell kernels + HIP GEMM per step", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
     "relpos_attention": "HIP (d(pk) finished by one library bmm)", "sentence_norm": "GLUE",
 }
 
 _seed_counter = [0]
+_seed_dev = {}
 
 
 def next_seed():
-    """Fresh 64-bit dropout seed per call: torch's global seed + a call counter (so torch.manual_seed makes runs repeatable)."""
+    """Per-call dropout stream id: torch's global seed mixed with the index of the call WITHIN the step. The per-step part lives
+    in device memory (``seed_state``) and is advanced by ``begin_step`` - so the ids may be frozen into a captured hipGraph."""
     _seed_counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0] * 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+
+
+def seed_state(device):
+    """Device-resident uint64 step counter added to every dropout seed by the kernels (int64 storage, wraps harmlessly)."""
+    key = str(device)
+    if key not in _seed_dev:
+        _seed_dev[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _seed_dev[key]
+
+
+def begin_step(device):
+    """Call once at the start of a training step: restarts the per-step call index and advances the device seed counter."""
+    _seed_counter[0] = 0
+    if torch.device(device).type == "cuda":
+        C.check(C.lib().tsasr_seed_advance(C.ptr(seed_state(device)), 0x9E3779B97F4A7C15, C.stream_ptr()), "tsasr_seed_advance")
 
 
 def _ws(nbytes, device):
@@ -142,8 +159,72 @@ def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
     return bias_act_dropout(matmul_nt(x, weight), bias, act_slope, dropout_p, training)
 
 
+class _LstmFn(torch.autograd.Function):
+    """Single-layer LSTM over [B,U,I] in bf16: input projection = library GEMM (K = 28 one-hot rows), recurrence = per-step
+    HIP GEMM (accumulate into the gate buffer) + HIP cell kernel; backward mirrors it; the two weight gradients are single
+    GEMMs over all (b,t). Every launch is graph-capturable."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        B, U, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        gates = F.linear(x.float(), w_ih.float(), (b_ih + b_hh).float()).contiguous()       # [B,U,4H] fp32
+        c = torch.empty(B, U, H, dtype=torch.float32, device=dev)
+        h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
+        whh16 = _bf16_weight(w_hh).contiguous()
+        lib, st = C.lib(), C.stream_ptr()
+        nws = lib.tsasr_gemm_bf16_workspace_bytes(B, 4 * H, H, C.F32)
+        ws = _ws(nws, dev) if nws else None
+        with prof.region("lstm_fwd"):
+            for t in range(U):
+                if t > 0:   # gates[:, t] += h[:, t-1] . W_hh^T
+                    C.check(lib.tsasr_gemm_bf16(C.ptr(h[:, t - 1]), C.ptr(whh16), C.ptr(gates[:, t]), B, 4 * H, H, U * H, H, U * 4 * H,
+                                                0, 0, C.F32, 1, C.ptr(ws), nws, st), "tsasr_gemm_bf16")
+                C.check(lib.tsasr_lstm_cell_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), B, U, H, t, C.BF16, st), "tsasr_lstm_cell_fwd")
+        ctx.save_for_backward(x, gates, c, h, whh16)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gates, c, h, whh16 = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        B, U, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        dout = dout.contiguous()
+        dgates = torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=dev)
+        dh_rec = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        dc = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        lib, st = C.lib(), C.stream_ptr()
+        nws = lib.tsasr_gemm_bf16_workspace_bytes(B, H, 4 * H, C.F32)
+        ws = _ws(nws, dev) if nws else None
+        with prof.region("lstm_bwd"):
+            for t in range(U - 1, -1, -1):
+                C.check(lib.tsasr_lstm_cell_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dh_rec), C.ptr(dc), C.ptr(dgates), B, U, H, t,
+                                                C.BF16, st), "tsasr_lstm_cell_bwd")
+                if t > 0:   # dh_rec = dgates[:, t] . W_hh
+                    C.check(lib.tsasr_gemm_bf16(C.ptr(dgates[:, t]), C.ptr(whh16), C.ptr(dh_rec), B, H, 4 * H, U * 4 * H, H, H, 0, 1,
+                                                C.F32, 0, C.ptr(ws), nws, st), "tsasr_gemm_bf16")
+        dg2 = dgates.view(B * U, 4 * H)
+        h_prev = torch.zeros_like(h)
+        h_prev[:, 1:] = h[:, :-1]
+        dw_hh = gemm_bf16(dg2, h_prev.view(B * U, H), 4 * H, H, B * U, 4 * H, H, 1, 1, out_dtype=torch.float32)
+        dg32 = dg2.float()
+        dw_ih = dg32.t() @ x.reshape(B * U, I).float()
+        db = dg32.sum(0)
+        dx = (dg32 @ w_ih.float()).view(B, U, I).to(x.dtype) if ctx.needs_input_grad[0] else None
+        return dx, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db.to(b_ih.dtype), db.to(b_hh.dtype)
+
+
 def lstm(x, rnn, hx=None):
-    # MIOpen's LSTM runs in fp32 here (tiny: 28 -> 512, 121 steps); output returned in the activation dtype
+    """bf16 training path: HIP cell kernels + HIP GEMM per step. Stepwise decoding (hx given) and fp32 parity runs keep the
+    library LSTM (MIOpen through PyTorch-ROCm)."""
+    if (hx is None and x.dtype == torch.bfloat16 and rnn.num_layers == 1 and not rnn.bidirectional and rnn.hidden_size % 8 == 0
+            and x.shape[1] > 1):
+        out = _LstmFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+        return out, None
     out, hn = rnn(x.float(), hx) if hx is not None else rnn(x.float())
     return out.to(x.dtype), hn
 
@@ -203,7 +284,7 @@ class _BiasActDropoutFn(torch.autograd.Function):
         y = torch.empty_like(xc)
         with prof.region("bias_act_dropout_fwd"):
             C.check(C.lib().tsasr_bias_act_dropout_fwd(C.ptr(xc), C.ptr(b), C.ptr(y), M, N, float(slope), float(p), seed,
-                                                       C.io_dtype(xc), C.stream_ptr()), "tsasr_bias_act_dropout_fwd")
+                                                       C.ptr(seed_state(xc.device)), C.io_dtype(xc), C.stream_ptr()), "tsasr_bias_act_dropout_fwd")
         ctx.save_for_backward(y)
         ctx.cfg = (float(slope), float(p), seed, bias is not None, None if bias is None else bias.dtype)
         return y
@@ -219,7 +300,8 @@ class _BiasActDropoutFn(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=y.device) if has_bias else None
         ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), y.device) if has_bias else None
         with prof.region("bias_act_dropout_bwd"):
-            C.check(C.lib().tsasr_bias_act_dropout_bwd(C.ptr(dy), C.ptr(y), C.ptr(dx), C.ptr(db), M, N, slope, p, seed, C.io_dtype(y),
+            C.check(C.lib().tsasr_bias_act_dropout_bwd(C.ptr(dy), C.ptr(y), C.ptr(dx), C.ptr(db), M, N, slope, p, seed,
+                                                       C.ptr(seed_state(y.device)), C.io_dtype(y),
                                                        C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
                     "tsasr_bias_act_dropout_bwd")
         return dx, (db.to(bdtype) if has_bias else None), None, None, None
@@ -245,7 +327,7 @@ class _DropoutAddFn(torch.autograd.Function):
         out = torch.empty_like(xc)
         with prof.region("dropout_add_fwd"):
             C.check(C.lib().tsasr_dropout_add_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(out), M, N, float(alpha), float(p), seed,
-                                                  C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()), "tsasr_dropout_add_fwd")
+                                                  C.ptr(seed_state(xc.device)), C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()), "tsasr_dropout_add_fwd")
         ctx.save_for_backward(valid_lens)
         ctx.cfg = (float(alpha), float(p), seed, int(trows), bias is not None, None if bias is None else bias.dtype,
                    None if res is None else res.shape, xc.shape)
@@ -262,7 +344,8 @@ class _DropoutAddFn(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=dout.device) if has_bias else None
         ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), dout.device) if has_bias else None
         with prof.region("dropout_add_bwd"):
-            C.check(C.lib().tsasr_dropout_add_bwd(C.ptr(dout), C.ptr(dx), C.ptr(db), M, N, alpha, p, seed, C.ptr(valid_lens), trows,
+            C.check(C.lib().tsasr_dropout_add_bwd(C.ptr(dout), C.ptr(dx), C.ptr(db), M, N, alpha, p, seed,
+                                                  C.ptr(seed_state(dout.device)), C.ptr(valid_lens), trows,
                                                   C.io_dtype(dout), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
                     "tsasr_dropout_add_bwd")
         dres = None
@@ -408,7 +491,8 @@ class _RelPosAttnFn(torch.autograd.Function):
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkvc.device)
         with prof.region("relpos_attn_fwd"):
             C.check(C.lib().tsasr_relpos_attn_fwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(lse),
-                                                  B, T, H, Dh, float(scale), int(bool(causal)), float(pdrop), seed, C.io_dtype(qkvc),
+                                                  B, T, H, Dh, float(scale), int(bool(causal)), float(pdrop), seed,
+                                                  C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc),
                                                   C.stream_ptr()), "tsasr_relpos_attn_fwd")
         ctx.save_for_backward(qkvc, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
         ctx.cfg = (H, float(scale), bool(causal), float(pdrop), seed)
@@ -431,7 +515,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         with prof.region("relpos_attn_bwd"):
             C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
                                                   C.ptr(lse), C.ptr(dqkv), C.ptr(dbd), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
-                                                  pdrop, seed, C.io_dtype(qkvc), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                                                  pdrop, seed, C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc), C.ptr(ws), ws.numel(), C.stream_ptr()),
                     "tsasr_relpos_attn_bwd")
         # d(pk): parameter-like reduction over the batch = one library GEMM per head on the shifted-back score gradient
         q = qkvc.view(B, T, H, 3 * Dh)[..., :Dh]

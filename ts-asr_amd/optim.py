@@ -27,14 +27,36 @@ class FusedClipAdamW:
         arena.companions += [self.exp_avg, self.exp_avg_sq]  # follow the arena's one-time re-layout
         self.t = 0
         self.last_grad_norm = torch.zeros((), device=arena.device)  # device scalar, never synced in the step
+        self._hyper_host = self._hyper_dev = self._ws = None
 
-    def step(self):
+    def prepare(self):
+        """Host half of a step: advance t and ship {lr, 1-b1^t, 1-b2^t} to the device (pinned staging -> async copy). Kept
+        outside any captured hipGraph so that the Noam schedule keeps acting on replays."""
         g = self.param_groups[0]
         self.t += 1
         b1, b2 = g["betas"]
+        if self._hyper_host is None:
+            self._hyper_host = torch.empty(3, dtype=torch.float32).pin_memory() if self.arena.device.type == "cuda" else torch.empty(3)
+            self._hyper_dev = torch.empty(3, dtype=torch.float32, device=self.arena.device)
+            self._ws = torch.empty(max(256, C.lib().tsasr_clip_adamw_workspace_bytes()), dtype=torch.uint8, device=self.arena.device)
+        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = g["lr"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def launch(self):
+        """Device half: two kernel launches over the arena (graph-capturable)."""
+        g = self.param_groups[0]
         a = self.arena
-        _clip_adamw(a.flat_params, a.grads, self.exp_avg, self.exp_avg_sq, self.last_grad_norm, g["lr"], b1, b2, g["eps"],
-                    g["weight_decay"], self.t, self.max_grad_norm, a.flat_params16)
+        b1, b2 = g["betas"]
+        C.require_gpu(a.flat_params)
+        with prof.region("clip_adamw"):
+            C.check(C.lib().tsasr_clip_adamw_step(C.ptr(a.flat_params), C.ptr(a.flat_params16), C.ptr(a.grads), C.ptr(self.exp_avg),
+                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self.last_grad_norm), a.numel,
+                                                  float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.max_grad_norm,
+                                                  C.ptr(self._ws), self._ws.numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
+
+    def step(self):
+        self.prepare()
+        self.launch()
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
@@ -44,21 +66,14 @@ class FusedClipAdamW:
             {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
 
-_hyper, _ws = {}, {}
-
-
 def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm, p16=None):
-    """One HIP pass over the arena (csrc/optim.hip). lr / bias corrections travel through a 3-float device array."""
+    """Stand-alone call of csrc/optim.hip on explicit buffers (unit tests)."""
     C.require_gpu(p, g, m, v)
-    dev = p.device
-    if dev not in _hyper:
-        _hyper[dev] = torch.empty(3, dtype=torch.float32, device=dev)
-        _ws[dev] = torch.empty(C.lib().tsasr_clip_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
-    _hyper[dev].copy_(torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32), non_blocking=True)
-    with prof.region("clip_adamw"):
-        C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(p16), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(_hyper[dev]), C.ptr(norm_out), p.numel(),
-                                              float(b1), float(b2), float(eps), float(wd), float(max_norm), C.ptr(_ws[dev]),
-                                              _ws[dev].numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
+    hyper = torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32).to(p.device)
+    ws = torch.empty(max(256, C.lib().tsasr_clip_adamw_workspace_bytes()), dtype=torch.uint8, device=p.device)
+    C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(p16), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(hyper), C.ptr(norm_out), p.numel(),
+                                          float(b1), float(b2), float(eps), float(wd), float(max_norm), C.ptr(ws), ws.numel(),
+                                          C.stream_ptr()), "tsasr_clip_adamw_step")
 
 
 class _WrappedTorchOptimizer:
@@ -69,12 +84,18 @@ class _WrappedTorchOptimizer:
         self.param_groups = opt.param_groups
         self.last_grad_norm = torch.zeros((), device=arena.device)
 
-    def step(self):
+    def prepare(self):
+        pass
+
+    def launch(self):
         norm = self.arena.grad_norm()
         self.last_grad_norm.copy_(norm)
         if self.max_grad_norm > 0:
             self.arena.grads.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
         self.opt.step()
+
+    def step(self):
+        self.launch()
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
