@@ -172,11 +172,25 @@ def main():
         frames = world * B_LOCAL * T_MEL * args.steps
         ms_step = elapsed / args.steps * 1e3
         ab = algorithmic_bytes()
-        fam = {k: {"launches": n, "avg_ms": round(ms, 4), "algorithmic_GBps": round(ab[k] / (ms * 1e-3) / 1e9, 1) if k in ab and ms > 0 else None}
-               for k, (n, ms) in kern.items()}
-        dom = max((k for k in fam if k in ab), key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)
+        wk = prof.work()
+        fam = {}
+        for k, (n, ms) in kern.items():
+            e = {"launches": n, "avg_ms": round(ms, 4)}
+            if k in ab and ms > 0:
+                e["algorithmic_GBps"] = round(ab[k] / (ms * 1e-3) / 1e9, 1)
+            if wk.get(k, 0) > 0 and ms > 0:
+                e["avg_GFLOP_per_launch"] = round(wk[k] / n / 1e9, 3)
+                e["TFLOPps"] = round(wk[k] / n / (ms * 1e-3) / 1e12, 1)
+            fam[k] = e
+        # dominant hand-written kernel = largest share of the step among the instrumented launches
+        dom = max(fam, key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)
         roof = None
-        if dom is not None:
+        if dom is not None and "TFLOPps" in fam[dom]:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": fam[dom]["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fam[dom]["TFLOPps"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops_per_launch": fam[dom]["avg_GFLOP_per_launch"] * 1e9, "avg_launch_ms": fam[dom]["avg_ms"],
+                    "note": "2*M*N*K of every launch of this template instantiation / its HIP-event duration, averaged over the launches of the instrumented steps"}
+        elif dom is not None and dom in ab:
             ach = ab[dom] / (fam[dom]["avg_ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,

@@ -78,7 +78,16 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
     od = C.F32 if out.dtype == torch.float32 else C.BF16
     nws = C.lib().tsasr_gemm_bf16_workspace_bytes(M, N, K, od)
     ws = _ws(nws, a.device) if nws else None
-    with prof.region("gemm_bf16"):
+    if prof.ENABLED:  # label = the kernel template instantiation rocprofv3 will show (mirror of plan() in csrc/gemm.hip)
+        big = ((M + 127) // 128) * ((N + 127) // 128) >= 192
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) if big else ((M + 63) // 64) * ((N + 63) // 64)
+        split = od == C.F32 and tiles < 256 and K >= 1024 and min(32, K // 256, (512 + tiles - 1) // tiles) > 1
+        mode = 1 if (split or (od == C.F32 and not accumulate)) else (2 if accumulate else 0)
+        tile = "128, 128" if big else "64, 64"
+        label = f"gemm_bf16_kernel<{tile}, {'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}, {mode}>"
+    else:
+        label = "gemm"
+    with prof.region(label, 2.0 * M * N * K):
         C.check(C.lib().tsasr_gemm_bf16(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, N if ldc is None else ldc, int(trans_a),
                                         int(trans_b), od, int(accumulate), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
                 "tsasr_gemm_bf16")

@@ -7,10 +7,12 @@ import torch
 
 ENABLED = False
 _records = {}
+_work = {}
 
 
 @contextlib.contextmanager
-def region(name):
+def region(name, work=0.0):
+    """``work`` = algorithmic FLOPs (or bytes) of this launch; summed per name so that achieved rate = work / time."""
     if not ENABLED:
         yield
         return
@@ -21,6 +23,11 @@ def region(name):
     finally:
         b.record()
         _records.setdefault(name, []).append((a, b))
+        _work[name] = _work.get(name, 0.0) + float(work)
+
+
+def work():
+    return dict(_work)
 
 
 def collect():
@@ -34,3 +41,4 @@ def collect():
 
 def reset():
     _records.clear()
+    _work.clear()
