@@ -204,6 +204,19 @@ int tsasr_lstm_cell_fwd(float *gates, float *c, void *h, int B, int U, int H, in
 int tsasr_lstm_cell_bwd(const float *gates, const float *c, const void *dout, const float *dh_rec, float *dc_io, void *dgates, int B,
                         int U, int H, int t, int io_dtype, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A1 Fbank: replaces SB/lobes/features.py:130-147 = STFT (SB/processing/features.py:134-178; n_fft 512, periodic Hamming 512,
+ * center=True zero padding, one-sided) + spectral_magnitude power=1 (:317-348) + Filterbank (:482-552) + _amplitude_to_DB
+ * (:683-704; floor at per-utterance max - top_db over ALL frames incl. padding).  wav [B,L] fp32 -> out [B,T=1+L/hop,n_mels].
+ * A2 InputNormalization(norm_type="sentence"): SB/processing/features.py:1012-1025,1107-1132 (mean / unbiased std over the
+ * first lens[b] frames per feature bin, applied to the whole padded row; eps clamps the std).
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_fbank_workspace_bytes(int B, int T, int n_mels);
+int tsasr_fbank_fwd(const float *wav, const float *window, const float *melmat, void *out, int B, int L, int T, int n_mels, int hop,
+                    float top_db, float amin, int out_dtype, void *workspace, size_t workspace_bytes, void *stream);
+int tsasr_sentence_norm_fwd(const void *x, const int32_t *lens, void *y, int B, int T, int F, float eps, int in_dtype, int out_dtype,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,3 +399,28 @@ def test_lstm_hip_path_vs_oracle(ops):
     for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
         a, r_ = getattr(rnn, k).grad.cpu(), sd["rnn." + k].grad
         assert float((a - r_).norm() / r_.norm()) < 3e-2, k
+
+
+def test_fbank_and_sentence_norm_known_answers(nn_, ops):
+    """Reference known answers (vendor/speechbrain/tests/unittests/test_features.py:57-113) on the HIP kernels + oracle parity."""
+    from oracle import tsasr_ref as R
+    fb = nn_.Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32).to(DEV)
+    # silence -> every bin at amin -> -100 dB (and the top_db floor leaves it there)
+    z = fb(torch.zeros(2, 3200, device=DEV))
+    assert z.shape == (2, 21, 80) and torch.all(z == -100.0)
+    # random waveforms incl. a ragged length (L not a multiple of the hop) vs the oracle
+    g = torch.Generator().manual_seed(4)
+    wav = torch.randn(3, 16000 + 77, generator=g) * 0.1
+    wav[1, 9000:] = 0
+    out = fb(wav.to(DEV))
+    ref = R.fbank(wav)
+    assert out.shape == ref.shape
+    close(out, ref, 3e-3, 1e-4)          # dB scale; fp32 FFT vs rocFFT/pocketfft summation order
+    # InputNormalization known answer: [1,2,3,0,0,0] with relative length 0.5 -> [-1,0,1,-2,-2,-2]
+    norm = nn_.InputNormalization(norm_type="sentence")
+    x = torch.tensor([1.0, 2, 3, 0, 0, 0], device=DEV).view(1, 6, 1)
+    assert torch.equal(norm(x, torch.tensor([0.5], device=DEV)).squeeze().cpu(), torch.tensor([-1.0, 0, 1, -2, -2, -2]))
+    lens = torch.tensor([1.0, 0.6, 0.33])
+    close(norm(out, lens.to(DEV)), R.sentence_norm(ref, lens), 2e-3, 1e-3)
+    xb = torch.randn(2, 50, 144, generator=g)       # feature width that does not divide 256
+    close(ops.sentence_norm(xb.to(DEV), torch.tensor([50, 20], device=DEV), 1e-10), R.sentence_norm(xb, torch.tensor([1.0, 0.4])), 1e-5)

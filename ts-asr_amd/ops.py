@@ -18,8 +18,8 @@ STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
-    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm(bf16 training)": "HIP cell kernels + HIP GEMM per step", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank.stft": "GLUE(rocFFT)",
-    "relpos_attention": "HIP (d(pk) finished by one library bmm)", "sentence_norm": "GLUE",
+    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm(bf16 training)": "HIP cell kernels + HIP GEMM per step", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank": "HIP", "sentence_norm": "HIP",
+    "relpos_attention": "HIP (d(pk) finished by one library bmm)",
 }
 
 _seed_counter = [0]
@@ -376,23 +376,35 @@ def mask_time(x, valid_lens):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def fbank(wav, window, fbank_matrix, n_fft, hop, win, top_db, amin):
-    st = torch.stft(wav, n_fft, hop, win, window.to(wav.device), center=True, pad_mode="constant", normalized=False,
-                    onesided=True, return_complex=True)
-    power = (st.real ** 2 + st.imag ** 2).transpose(1, 2)
-    mel = power @ fbank_matrix.to(wav.device)
-    x_db = 10.0 * torch.log10(torch.clamp(mel, min=amin))
-    return torch.maximum(x_db, x_db.amax(dim=(-2, -1), keepdim=True) - top_db)
+def fbank(wav, window, fbank_matrix, n_fft, hop, win, top_db, amin, out_dtype=torch.float32):
+    """wav [B,L] -> log-mel [B, 1+L//hop, n_mels]: HIP kernel (in-LDS FFT-512 + power + mel + dB + per-utterance floor).
+    Features carry no gradient on this path (the reference's Fbank is frozen: requires_grad=False)."""
+    C.require_gpu(wav)
+    if n_fft != 512 or win != 512:
+        raise NotImplementedError("ts-asr_amd.Fbank: n_fft = win_length = 512 samples (all TS-ASR YAMLs: n_fft 512, 32 ms at 16 kHz)")
+    w = wav.detach().float().contiguous()
+    B, L = w.shape
+    T = 1 + L // hop
+    n_mels = fbank_matrix.shape[1]
+    out = torch.empty(B, T, n_mels, dtype=out_dtype, device=w.device)
+    ws = _ws(C.lib().tsasr_fbank_workspace_bytes(B, T, n_mels), w.device)
+    with prof.region("fbank"):
+        C.check(C.lib().tsasr_fbank_fwd(C.ptr(w), C.ptr(window.float().contiguous()), C.ptr(fbank_matrix.float().contiguous()), C.ptr(out),
+                                        B, L, T, n_mels, int(hop), float(top_db), float(amin), C.io_dtype(out), C.ptr(ws), ws.numel(),
+                                        C.stream_ptr()), "tsasr_fbank_fwd")
+    return out
 
 
-def sentence_norm(x, abs_lens, eps):
-    """Per-utterance mean / unbiased std over the first abs_lens[b] frames, applied to the whole padded row."""
-    T = x.shape[1]
-    m = (torch.arange(T, device=x.device)[None, :] < abs_lens[:, None]).unsqueeze(-1).to(x.dtype)
-    n = abs_lens.to(x.dtype).view(-1, 1, 1)
-    mean = (x * m).sum(1, keepdim=True) / n
-    var = (((x - mean) * m) ** 2).sum(1, keepdim=True) / (n - 1)
-    return (x - mean) / torch.clamp(var.sqrt(), min=eps)
+def sentence_norm(x, abs_lens, eps, out_dtype=None):
+    """Per-utterance mean / unbiased std over the first abs_lens[b] frames, applied to the whole padded row (HIP kernel)."""
+    C.require_gpu(x, abs_lens)
+    xc = x.detach().contiguous()
+    B, T, Fq = xc.shape
+    y = torch.empty(B, T, Fq, dtype=out_dtype or xc.dtype, device=xc.device)
+    with prof.region("sentence_norm"):
+        C.check(C.lib().tsasr_sentence_norm_fwd(C.ptr(xc), C.ptr(abs_lens.to(torch.int32).contiguous()), C.ptr(y), B, T, Fq, float(eps),
+                                                C.io_dtype(xc), C.io_dtype(y), C.stream_ptr()), "tsasr_sentence_norm_fwd")
+    return y
 
 
 def _out_len(n):
