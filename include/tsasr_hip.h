@@ -177,6 +177,8 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
  * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
  * p, g, m, v: flat fp32 [n]; p_bf16 (may be NULL): bf16 shadow of p rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
  * ------------------------------------------------------------------------------------------ */
+/* dst[i] += src[i] for `count` small fp32 vectors in one launch; table (DEVICE) = [count src ptrs][count dst ptrs][count int32 lengths]. */
+int tsasr_accumulate_many(const void *table, int count, void *stream);
 size_t tsasr_clip_adamw_workspace_bytes(void);
 int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,

@@ -132,6 +132,7 @@ def test_training_gradients_fp32_vs_oracle():
     out = brain.compute_forward(batch, core.Stage.TRAIN)
     loss = brain.compute_objectives(out, batch, core.Stage.TRAIN)
     loss.backward()
+    brain.arena.finish_backward()   # flushes the batched small-gradient accumulation into the arena
     logits_o = R.compute_forward({k: T(v) for k, v in inp.items()}, sd, CFG1, "cat")
     loss_o = RR.transducer_loss_ref_torch(logits_o, T(inp["tokens"]), T(inp["mixed_lens"]), T(inp["tokens_lens"]), 0, "mean")
     loss_o.backward()

@@ -81,7 +81,29 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
     }
 }
 
+// dst[i][0..n[i]) += src[i][0..n[i])  for `count` small fp32 vectors: one workgroup per vector
+__global__ __launch_bounds__(256) void accumulate_many_kernel(const float *const *__restrict__ src, float *const *__restrict__ dst,
+                                                              const int *__restrict__ n) {
+    const float *s = src[blockIdx.x];
+    float *d = dst[blockIdx.x];
+    const int len = n[blockIdx.x];
+    for (int i = threadIdx.x; i < len; i += 256) d[i] += s[i];
+}
+
 extern "C" {
+
+/* Adds `count` small fp32 gradient vectors into their slots of the gradient arena with ONE launch (replaces one
+ * AccumulateGrad add kernel per parameter: ~460 per step for LayerNorm weights, biases, conv filters, ...).
+ * table: DEVICE memory laid out as [count src pointers][count dst pointers][count int32 lengths]. */
+int tsasr_accumulate_many(const void *table, int count, void *stream) {
+    TSASR_CHECK_ARG(table && count > 0, "tsasr_accumulate_many: bad arguments");
+    const float *const *src = (const float *const *)table;
+    float *const *dst = (float *const *)((const char *)table + (size_t)count * sizeof(void *));
+    const int *n = (const int *)((const char *)table + (size_t)2 * count * sizeof(void *));
+    accumulate_many_kernel<<<count, 256, 0, (hipStream_t)stream>>>(src, dst, n);
+    TSASR_CHECK_LAUNCH("tsasr_accumulate_many");
+    return 0;
+}
 
 size_t tsasr_clip_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
 

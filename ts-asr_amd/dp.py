@@ -67,6 +67,7 @@ class GradArena:
         self._order_seen, self._order_final = [], False
         self._handles = []
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
+        self._deferred, self._keepalive, self._defer_host, self._defer_dev, self._defer_key = [], None, None, None, None
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -125,6 +126,38 @@ class GradArena:
     def mark_ready(self, p):
         self._on_grad(p)
 
+    def defer_add(self, p, g):
+        """Small fp32 parameter gradients are collected and added into the arena by ONE kernel at the end of backward
+        (instead of one AccumulateGrad add kernel each). Not used on steps that overlap the all-reduce with backward
+        (a bucket may only be sent once all its gradients are in)."""
+        if self._sync_this_step or not self.accepts(p) or g.dtype != torch.float32 or not g.is_cuda or g.numel() != p.numel():
+            return False
+        self._deferred.append((g.contiguous(), p))
+        return True
+
+    def _flush_deferred(self):
+        if not self._deferred:
+            return
+        import numpy as np
+        from . import _capi as C
+        n = len(self._deferred)
+        if self._defer_host is None or self._defer_host.numel() < n * 20:
+            cap = max(1024, 2 * n) * 20
+            self._defer_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._defer_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        tab = np.empty(n * 20, np.uint8)
+        tab[:n * 8].view(np.uint64)[:] = [g.data_ptr() for g, _ in self._deferred]
+        tab[n * 8:n * 16].view(np.uint64)[:] = [p.grad.data_ptr() for _, p in self._deferred]
+        tab[n * 16:].view(np.int32)[:] = [g.numel() for g, _ in self._deferred]
+        key = tab.tobytes()
+        if key != self._defer_key:          # same pointers as last step (always true under graph replay): skip the upload
+            self._defer_host[:n * 20].copy_(torch.from_numpy(tab))
+            self._defer_dev[:n * 20].copy_(self._defer_host[:n * 20], non_blocking=True)
+            self._defer_key = key
+        C.check(C.lib().tsasr_accumulate_many(C.ptr(self._defer_dev), n, C.stream_ptr()), "tsasr_accumulate_many")
+        self._keepalive = self._deferred    # the temporaries must outlive the launch
+        self._deferred = []
+
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):
         self.in_backward = True
@@ -154,6 +187,7 @@ class GradArena:
             self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
     def finish_backward(self):
+        self._flush_deferred()
         self.in_backward = False
         if self._sync_this_step:
             for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step

@@ -71,6 +71,18 @@ def set_grad_sink(arena):
     _GRAD_SINK = arena
 
 
+def _pgrad(param, g, shape=None):
+    """Return value for a parameter gradient slot of an autograd.Function.backward: None when the gradient arena takes the
+    fp32 temporary itself (one batched add at the end of backward), else the tensor autograd should accumulate."""
+    if g is None or param is None:
+        return None
+    sink = _GRAD_SINK
+    if sink is not None and isinstance(param, torch.nn.Parameter) and sink.defer_add(param, g):
+        return None
+    g = g.view(shape if shape is not None else param.shape)
+    return g if g.dtype == param.dtype else g.to(param.dtype)
+
+
 def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=torch.bfloat16, accumulate=False, ldc=None):
     """C[M,N] (+)= op(A).op(B) on the hand-written MFMA kernel (csrc/gemm.hip); see include/tsasr_hip.h for the layouts."""
     if out is None:
@@ -253,7 +265,7 @@ class _LayerNormFn(torch.autograd.Function):
             C.check(C.lib().tsasr_layernorm_fwd(C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(y), C.ptr(mean), C.ptr(rstd), M, D, float(eps),
                                                 float(slope), C.io_dtype(xc), C.stream_ptr()), "tsasr_layernorm_fwd")
         ctx.save_for_backward(xc, g, b, mean, rstd)
-        ctx.slope, ctx.wshape, ctx.wdtype = float(slope), weight.shape, weight.dtype
+        ctx.slope, ctx.params = float(slope), (weight, bias)
         return y
 
     @staticmethod
@@ -269,7 +281,7 @@ class _LayerNormFn(torch.autograd.Function):
             C.check(C.lib().tsasr_layernorm_bwd(C.ptr(dy), C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(mean), C.ptr(rstd), C.ptr(dx), C.ptr(dg),
                                                 C.ptr(db), M, D, ctx.slope, C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()),
                     "tsasr_layernorm_bwd")
-        return dx, dg.view(ctx.wshape).to(ctx.wdtype), db.view(ctx.wshape).to(ctx.wdtype), None, None
+        return dx, _pgrad(ctx.params[0], dg), _pgrad(ctx.params[1], db), None, None
 
 
 def layer_norm(x, weight, bias, eps, act_slope=None):
@@ -295,13 +307,13 @@ class _BiasActDropoutFn(torch.autograd.Function):
             C.check(C.lib().tsasr_bias_act_dropout_fwd(C.ptr(xc), C.ptr(b), C.ptr(y), M, N, float(slope), float(p), seed,
                                                        C.ptr(seed_state(xc.device)), C.io_dtype(xc), C.stream_ptr()), "tsasr_bias_act_dropout_fwd")
         ctx.save_for_backward(y)
-        ctx.cfg = (float(slope), float(p), seed, bias is not None, None if bias is None else bias.dtype)
+        ctx.cfg = (float(slope), float(p), seed, bias is not None, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
-        slope, p, seed, has_bias, bdtype = ctx.cfg
+        slope, p, seed, has_bias, bias_param = ctx.cfg
         N = y.shape[-1]
         M = y.numel() // N
         dy = dy.contiguous()
@@ -313,7 +325,7 @@ class _BiasActDropoutFn(torch.autograd.Function):
                                                        C.ptr(seed_state(y.device)), C.io_dtype(y),
                                                        C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
                     "tsasr_bias_act_dropout_bwd")
-        return dx, (db.to(bdtype) if has_bias else None), None, None, None
+        return dx, (_pgrad(bias_param, db) if has_bias else None), None, None, None
 
 
 def bias_act_dropout(x, bias, act_slope, p, training):
@@ -338,14 +350,14 @@ class _DropoutAddFn(torch.autograd.Function):
             C.check(C.lib().tsasr_dropout_add_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(out), M, N, float(alpha), float(p), seed,
                                                   C.ptr(seed_state(xc.device)), C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()), "tsasr_dropout_add_fwd")
         ctx.save_for_backward(valid_lens)
-        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias is not None, None if bias is None else bias.dtype,
+        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias is not None, bias,
                    None if res is None else res.shape, xc.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (valid_lens,) = ctx.saved_tensors
-        alpha, p, seed, trows, has_bias, bdtype, rshape, xshape = ctx.cfg
+        alpha, p, seed, trows, has_bias, bias_param, rshape, xshape = ctx.cfg
         dout = dout.contiguous()
         N = xshape[-1]
         M = dout.numel() // N
@@ -360,7 +372,7 @@ class _DropoutAddFn(torch.autograd.Function):
         dres = None
         if rshape is not None:
             dres = dout if tuple(rshape) == tuple(xshape) else dout.sum_to_size(rshape)
-        return dx, (db.to(bdtype) if has_bias else None), dres, None, None, None, None, None
+        return dx, (_pgrad(bias_param, db) if has_bias else None), dres, None, None, None, None, None
 
 
 def dropout_add(x, bias=None, res=None, alpha=1.0, p=0.0, training=False, valid_lens=None):
@@ -427,21 +439,21 @@ class _FrontendC1Fn(torch.autograd.Function):
             C.check(C.lib().tsasr_frontend_c1_fwd(C.ptr(xc), C.ptr(f(w1)), C.ptr(f(b1)), C.ptr(f(w2)), C.ptr(f(b2)), C.ptr(y1), C.ptr(y2),
                                                   B, T, Fq, Co, int(causal), C.io_dtype(xc), C.stream_ptr()), "tsasr_frontend_c1_fwd")
         ctx.save_for_backward(xc)
-        ctx.cfg = (bool(causal), Co, w1.shape, w2.shape, [t.dtype for t in (w1, b1, w2, b2)])
+        ctx.cfg = (bool(causal), Co, (w1, b1, w2, b2))
         return y1, y2
 
     @staticmethod
     def backward(ctx, dy1, dy2):
         (xc,) = ctx.saved_tensors
-        causal, Co, s1, s2, dts = ctx.cfg
+        causal, Co, prm = ctx.cfg
         B, T, Fq = xc.shape
         dpar = torch.empty(Co * 12, dtype=torch.float32, device=xc.device)
         ws = _ws(C.lib().tsasr_frontend_c1_bwd_workspace_bytes(Co), xc.device)
         with prof.region("frontend_c1_bwd"):
             C.check(C.lib().tsasr_frontend_c1_bwd(C.ptr(xc), C.ptr(dy1.contiguous()), C.ptr(dy2.contiguous()), C.ptr(dpar), B, T, Fq, Co,
                                                   int(causal), C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_frontend_c1_bwd")
-        return (None, dpar[:Co * 9].view(s1).to(dts[0]), dpar[Co * 9:Co * 10].to(dts[1]), dpar[Co * 10:Co * 11].view(s2).to(dts[2]),
-                dpar[Co * 11:].to(dts[3]), None)
+        return (None, _pgrad(prm[0], dpar[:Co * 9]), _pgrad(prm[1], dpar[Co * 9:Co * 10]), _pgrad(prm[2], dpar[Co * 10:Co * 11]),
+                _pgrad(prm[3], dpar[Co * 11:]), None)
 
 
 class _FrontendConvFn(torch.autograd.Function):
@@ -542,7 +554,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         q = qkvc.view(B, T, H, 3 * Dh)[..., :Dh]
         qv = (q + v.view(1, 1, H, Dh).to(q.dtype)).permute(2, 0, 1, 3).reshape(H, B * T, Dh)
         dpk = torch.bmm(dbd.view(H, R, B * T), qv).permute(1, 0, 2).reshape(R, D)
-        return dqkv, dpk, du.view(pu.shape).to(pu.dtype), dv.view(pv.shape).to(pv.dtype), None, None, None, None, None, None
+        return dqkv, dpk, _pgrad(pu, du), _pgrad(pv, dv), None, None, None, None, None, None
 
 
 def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights):
@@ -596,14 +608,13 @@ class _ConvModCoreFn(torch.autograd.Function):
                                               C.ptr(mean), C.ptr(rstd), B, T, D, K, int(bool(causal)), float(eps), float(slope),
                                               C.io_dtype(y2c), C.stream_ptr()), "tsasr_convmod_fwd")
         ctx.save_for_backward(y2c, b2f, cw, g, be, c_save, mean, rstd)
-        ctx.cfg = (bool(causal), float(slope), b2 is not None, conv_w.shape, [t.dtype for t in (conv_w, conv_b, ln_w, ln_b)],
-                   None if b2 is None else b2.dtype)
+        ctx.cfg = (bool(causal), float(slope), b2 is not None, conv_w.shape, (conv_w, conv_b, ln_w, ln_b), b2)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         y2c, b2f, cw, g, be, c_save, mean, rstd = ctx.saved_tensors
-        causal, slope, has_b2, wshape, dts, b2dt = ctx.cfg
+        causal, slope, has_b2, wshape, prm, b2p = ctx.cfg
         B, T, D2 = y2c.shape
         D, K = D2 // 2, cw.shape[-1]
         dz = dz.contiguous()
@@ -615,8 +626,8 @@ class _ConvModCoreFn(torch.autograd.Function):
                                               C.ptr(rstd), C.ptr(dy2), C.ptr(dpar), B, T, D, K, int(causal), slope, C.io_dtype(y2c),
                                               C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_convmod_bwd")
         dg, dbe, dcb, db2, dcw = dpar[:D], dpar[D:2 * D], dpar[2 * D:3 * D], dpar[3 * D:5 * D], dpar[5 * D:]
-        return (dy2, db2.to(b2dt) if has_b2 else None, dcw.view(wshape).to(dts[0]), dcb.to(dts[1]), dg.to(dts[2]), dbe.to(dts[3]),
-                None, None, None)
+        return (dy2, _pgrad(b2p, db2) if has_b2 else None, _pgrad(prm[0], dcw), _pgrad(prm[1], dcb), _pgrad(prm[2], dg),
+                _pgrad(prm[3], dbe), None, None, None)
 
 
 def convmod_core(y2, b2, conv_w, conv_b, ln_w, ln_b, causal, eps, slope):

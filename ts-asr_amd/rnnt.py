@@ -35,7 +35,7 @@ class _JointLogitsFn(torch.autograd.Function):
                                             C.io_dtype(enc), float(slope), C.stream_ptr()), "tsasr_joint_fwd")
         ctx.save_for_backward(enc, dec, w32, tlen, ulen)
         ctx.slope, ctx.V = float(slope), V
-        ctx.wdtype, ctx.bdtype = weight.dtype, bias.dtype
+        ctx.params = (weight, bias)
         return buf[..., :V]
 
     @staticmethod
@@ -53,7 +53,8 @@ class _JointLogitsFn(torch.autograd.Function):
             C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
                                             C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), C.io_dtype(enc), ctx.slope,
                                             C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_bwd")
-        return denc, ddec, dW.to(ctx.wdtype), db.to(ctx.bdtype), None, None, None
+        from .ops import _pgrad
+        return denc, ddec, _pgrad(ctx.params[0], dW), _pgrad(ctx.params[1], db), None, None, None
 
 
 def _as_padded_rows(x, V):
