@@ -191,6 +191,7 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
  *   out_dtype TSASR_BF16 | TSASR_F32; accumulate (fp32 only): C += result, used to add weight gradients straight into the
  *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
  * ------------------------------------------------------------------------------------------ */
+void tsasr_gemm_set_ring(int on); /* 1 (default): LDS-DMA ring main loop when K % 64 == 0; 0: register-staged loop (A/B tests) */
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                     int transA, int transB, int out_dtype, int accumulate, void *workspace, size_t workspace_bytes, void *stream);

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of csrc/gemm.hip at the model's shapes vs the library GEMM (interleaved rounds, one process)."""
+import importlib, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ops = importlib.import_module("ts-asr_amd.ops")
+DEV = "cuda"
+SHAPES = [  # (M, N, K, tA, tB, out f32?)
+    (8000, 2048, 256, 0, 0, 0), (8000, 256, 2048, 0, 0, 0), (8000, 768, 256, 0, 0, 0), (8000, 512, 256, 0, 0, 0),
+    (8000, 256, 256, 0, 0, 0), (8000, 256, 2560, 0, 0, 0), (8000, 640, 256, 0, 0, 0),
+    (8000, 256, 2048, 0, 1, 0), (8000, 2048, 256, 0, 1, 0), (8000, 256, 768, 0, 1, 0), (8000, 256, 256, 0, 1, 0),
+    (2048, 256, 8000, 1, 1, 1), (256, 2048, 8000, 1, 1, 1), (768, 256, 8000, 1, 1, 1), (256, 256, 8000, 1, 1, 1),
+    (160000, 128, 1152, 0, 0, 0), (128, 1152, 160000, 1, 1, 1), (160000, 1152, 128, 0, 1, 0),
+]
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+for (M, N, K, ta, tb, f32) in SHAPES:
+    A = torch.randn((K, M) if ta else (M, K), device=DEV).to(torch.bfloat16)
+    B = torch.randn((K, N) if tb else (N, K), device=DEV).to(torch.bfloat16)
+    out = torch.zeros(M, N, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+    mine = lambda: ops.gemm_bf16(A, B, M, N, K, M if ta else K, N if tb else K, ta, tb, out=out, accumulate=bool(f32))
+    lib = lambda: torch.matmul(A.t() if ta else A, B if tb else B.t())
+    C = importlib.import_module("ts-asr_amd._capi")
+    best = {"ring": 1e9, "reg": 1e9, "lib": 1e9}
+    for rnd in range(5):   # interleaved rounds in one process; report the minimum
+        C.lib().tsasr_gemm_set_ring(2); best["ring"] = min(best["ring"], timeit(mine))
+        C.lib().tsasr_gemm_set_ring(0); best["reg"] = min(best["reg"], timeit(mine))
+        best["lib"] = min(best["lib"], timeit(lib))
+    C.lib().tsasr_gemm_set_ring(1)
+    fl = 2.0 * M * N * K
+    print(f"M={M:6d} N={N:5d} K={K:6d} tA={ta} tB={tb} f32={f32}: ring {best['ring']:6.1f} us {fl/best['ring']/1e6:6.1f} TF | reg {best['reg']:6.1f} us {fl/best['reg']/1e6:6.1f} TF | lib {best['lib']:6.1f} us {fl/best['lib']/1e6:6.1f} TF")

@@ -30,7 +30,9 @@ struct GemmSmem {
     static constexpr int A_ELEMS = AT ? GB_K * A_LD : BM * A_LD;
     static constexpr int B_ELEMS = BT ? GB_K * B_LD : BN * B_LD;
     static constexpr int STAGE = A_ELEMS + B_ELEMS;
-    static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(bf16_t);
+    static constexpr size_t PIPE_BYTES = (size_t)2 * STAGE * sizeof(bf16_t);
+    static constexpr size_t EPI_BYTES = (size_t)BM * (BN + 4) * sizeof(float);   // fp32 epilogue tile (the bf16 one is smaller)
+    static constexpr size_t BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
 };
 
 // one 16-byte chunk (8 bf16) of an operand tile per (thread, iteration): global -> registers
@@ -88,9 +90,184 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t *lds, int LD, int blk0, int 
     return o;
 }
 
+// accumulators -> LDS tile (row-major, padded) -> 16-byte coalesced row stores (the register layout alone would give 2- or
+// 4-byte stores strided by a row: store-issue bound at the model's short K). Caller guarantees all k-tile LDS reads are done.
+template <int BM, int BN, int OUT_MODE>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], char *smem, void *__restrict__ Cv, int M, int N,
+                                              long long ldc, long long slab_stride, int m0, int n0, int wm, int wn, int lane) {
+    constexpr int RB = BM / 64, CB = BN / 64;
+    bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
+    const int r = lane & 31, hh = lane >> 5;
+    if (OUT_MODE == 0) {
+        constexpr int LDT = BN + 8;
+        bf16_t *tile = lds;  // BM x LDT bf16 <= smem (all k-tile reads are behind the loop's last barrier)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    tile[(wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * (BN / 2) + 32 * j + r] = (bf16_t)acc[i][j][g];
+        __syncthreads();
+        bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
+        const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
+        for (int c = threadIdx.x; c < BM * (BN / 8); c += 256) {
+            const int rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+            const int m = m0 + rr, n = n0 + cc;
+            if (m >= M || n >= N) continue;
+            if (vec && n + 8 <= N) *reinterpret_cast<uint4 *>(Cb + (long long)m * ldc + n) = *reinterpret_cast<const uint4 *>(tile + rr * LDT + cc);
+            else
+                for (int e = 0; e < 8 && n + e < N; ++e) Cb[(long long)m * ldc + n + e] = tile[rr * LDT + cc + e];
+        }
+    } else {
+        constexpr int LDT = BN + 4;
+        float *tile = reinterpret_cast<float *>(smem);  // BM x LDT fp32 <= smem for both tile sizes
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    tile[(wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * (BN / 2) + 32 * j + r] = acc[i][j][g];
+        __syncthreads();
+        float *Cf = reinterpret_cast<float *>(Cv) + (OUT_MODE == 1 ? (long long)blockIdx.z * slab_stride : 0);
+        const bool vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cf) & 15) == 0);
+        for (int c = threadIdx.x; c < BM * (BN / 4); c += 256) {
+            const int rr = c / (BN / 4), cc = (c % (BN / 4)) * 4;
+            const int m = m0 + rr, n = n0 + cc;
+            if (m >= M || n >= N) continue;
+            float *dst = Cf + (long long)m * ldc + n;
+            const float4 v = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc);
+            if (vec && n + 4 <= N) {
+                if (OUT_MODE == 2) {
+                    float4 o = *reinterpret_cast<float4 *>(dst);
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    *reinterpret_cast<float4 *>(dst) = o;
+                } else *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int e = 0; e < 4 && n + e < N; ++e) {
+                    if (OUT_MODE == 2) dst[e] += vv[e];
+                    else dst[e] = vv[e];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 main loop: 3-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging), counted vmcnt + ONE raw
+// s_barrier per k-tile, two tiles in flight behind the MFMAs. The DMA writes 1 KiB per wave-instruction linearly
+// (base + lane*16), so rows are unpadded and bank conflicts are removed by a XOR swizzle applied to the per-lane SOURCE
+// address and to the fragment reads alike (guide 5.4 rule 21). Requires K % 64 == 0 (no zero-fill path in a DMA).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ROWS, bool TR>
+struct RingTile {
+    static constexpr int ROW_BYTES = TR ? ROWS * 2 : GB_K * 2;          // bytes per LDS row
+    static constexpr int NROWS = TR ? GB_K : ROWS;                       // LDS rows
+    static constexpr int NCH = ROW_BYTES / 16;                           // 16-byte chunks per row
+    static constexpr int BYTES = NROWS * ROW_BYTES;
+    static constexpr int INSTR = BYTES / 4096;                           // wave-instructions per wave (4 waves x 1 KiB)
+    __device__ static __forceinline__ int swz(int row, int ch) { return ch ^ (row & 7); }
+    // issue this wave's share of one tile; rows/cols beyond the matrix are clamped (their results are never stored)
+    __device__ static __forceinline__ void issue(const bf16_t *__restrict__ src, long long ld, int row0, int nrows, int k0, char *slot,
+                                                 int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < INSTR; ++i) {
+            const int piece = i * 4 + wave;                              // 1 KiB piece index inside the tile
+            const int byte = piece * 1024 + lane * 16;
+            const int lrow = byte / ROW_BYTES, pos = (byte % ROW_BYTES) / 16;
+            const int ch = swz(lrow, pos);                               // global chunk that lands in this LDS slot
+            const bf16_t *g;
+            if (!TR) g = src + (long long)min(row0 + lrow, nrows - 1) * ld + k0 + ch * 8;
+            else g = src + (long long)(k0 + lrow) * ld + min(row0 + ch * 8, nrows - 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, 0);
+        }
+    }
+    __device__ static __forceinline__ bf16x8 frag(const char *slot, int blk0, int s, int lane) {
+        const int r = lane & 31, hh = lane >> 5;
+        if (!TR) {
+            const int row = blk0 + r;
+            return *reinterpret_cast<const bf16x8 *>(slot + row * ROW_BYTES + swz(row, 2 * s + hh) * 16);
+        }
+        const int mhalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = blk0 + 16 * mhalf + 4 * p4;                      // element column of this lane's 8-byte piece
+        const int row_lo = 16 * s + 8 * hh + q4, row_hi = row_lo + 4;
+        const char *a_lo = slot + row_lo * ROW_BYTES + swz(row_lo, col >> 3) * 16 + (col & 7) * 2;
+        const char *a_hi = slot + row_hi * ROW_BYTES + swz(row_hi, col >> 3) * 16 + (col & 7) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a_lo));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(a_hi));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+    }
+};
+
+#define RING_STAGES 3
+template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
+                                                                int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
+                                                                long long slab_stride) {
+    using TA = RingTile<BM, AT>;
+    using TB = RingTile<BN, BT>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;       // LDS-DMA instructions per wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RB = BM / 64, CB = BN / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / GB_K;
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
+#pragma unroll
+    for (int t = 0; t < RING_STAGES - 1; ++t)
+        if (t < nk) {
+            TA::issue(A, lda, m0, M, kbeg + t * GB_K, smem + t * SLOT, wave, lane);
+            TB::issue(B, ldb, n0, N, kbeg + t * GB_K, smem + t * SLOT + TA::BYTES, wave, lane);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of tile kt have landed once at most the next tile's LPT instructions are outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1)%3
+        if (kt + RING_STAGES - 1 < nk) {
+            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
+            TA::issue(A, lda, m0, M, kbeg + (kt + RING_STAGES - 1) * GB_K, slot, wave, lane);
+            TB::issue(B, ldb, n0, N, kbeg + (kt + RING_STAGES - 1) * GB_K, slot + TA::BYTES, wave, lane);
+        }
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+#pragma unroll
+        for (int s = 0; s < GB_K / 16; ++s) {
+            bf16x8 af[RB], bfr[CB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) af[i] = TA::frag(as, wm * (BM / 2) + 32 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bfr[j] = TB::frag(bs, wn * (BN / 2) + 32 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int BN, bool AT, bool BT>
+struct RingSmem {
+    static constexpr size_t PIPE = (size_t)RING_STAGES * (RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES);
+    static constexpr size_t EPI = (size_t)BM * (BN + 4) * sizeof(float);
+    static constexpr size_t BYTES = PIPE > EPI ? PIPE : EPI;
+};
+
 // OUT_MODE: 0 = bf16 store, 1 = fp32 store (slab or plain), 2 = fp32 accumulate (C += acc)
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
                                                         long long slab_stride) {
     using S = GemmSmem<BM, BN, AT, BT>;
@@ -142,23 +319,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t *__restrict
         }
         __syncthreads();
     }
-    // epilogue: acc[i][j][g] -> C[m0 + wm*BM/2 + 32i + row(g)][n0 + wn*BN/2 + 32j + (lane&31)]
-    const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            const int n = n0 + wn * (BN / 2) + 32 * j + r;
-            if (n >= N) continue;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int m = m0 + wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                if (m >= M) continue;
-                if (OUT_MODE == 0) reinterpret_cast<bf16_t *>(Cv)[(long long)m * ldc + n] = (bf16_t)acc[i][j][g];
-                else if (OUT_MODE == 1) reinterpret_cast<float *>(Cv)[(long long)blockIdx.z * slab_stride + (long long)m * ldc + n] = acc[i][j][g];
-                else reinterpret_cast<float *>(Cv)[(long long)m * ldc + n] += acc[i][j][g];
-            }
-        }
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane);
 }
 
 // C[m][n] (+)= sum_z slab[z][m*N + n]   (fixed order)
@@ -177,13 +338,26 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__re
     else { c[0] = s.x; c[1] = s.y; c[2] = s.z; c[3] = s.w; }
 }
 
+static int g_use_ring = 1;
+
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
                    int kchunk, long long slab_stride, hipStream_t st) {
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    // measured (tools/gemm_bench.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles; the
+    // register-staged loop wins on the short-K projections (K = 256: 4 k-tiles, prologue-bound)
+    const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024) &&
+                      (AT ? M >= 8 : true) && (BT ? N >= 8 : true);
+    if (ring) {
+        using R = RingSmem<BM, BN, AT, BT>;
+        auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE>;
+        if (R::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::BYTES);
+        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride);
+        return;
+    }
     using S = GemmSmem<BM, BN, AT, BT>;
     auto kern = gemm_bf16_kernel<BM, BN, AT, BT, OUT_MODE>;
     if (S::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
     kern<<<grid, 256, S::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride);
 }
 
@@ -196,12 +370,13 @@ static void launch_t(int tA, int tB, const void *A, const void *B, void *C, int 
     else launch<BM, BN, true, false, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
 }
 
-struct GemmPlan { int big; int splits; int kchunk; };
+struct GemmPlan { int tile; int splits; int kchunk; };   // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
 static GemmPlan plan(int M, int N, int K, int out_f32) {
     GemmPlan p;
-    const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128), t64 = (long long)cdiv(M, 64) * cdiv(N, 64);
-    p.big = t128 >= 192;                       // enough 128x128 tiles to cover the chip; otherwise 64x64 tiles
-    const long long tiles = p.big ? t128 : t64;
+    const long long t0 = (long long)cdiv(M, 128) * cdiv(N, 128), t1 = (long long)cdiv(M, 128) * cdiv(N, 64),
+                    t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
+    p.tile = t0 >= 192 ? 0 : (t1 >= 192 ? 1 : 2);   // the largest macro-tile whose grid still covers the 256 CUs
+    const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
     if (out_f32 && tiles < 256 && K >= 1024) {  // weight gradients: few output tiles, long inner dimension -> split it
         int s = (int)((512 + tiles - 1) / tiles);
@@ -216,7 +391,18 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
     return p;
 }
 
+template <int OUT_MODE>
+static void launch_tile(int tile, int tA, int tB, const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb,
+                        long long ldc, int splits, int kchunk, long long slab_stride, hipStream_t st) {
+    if (tile == 0) launch_t<128, 128, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
+    else if (tile == 1) launch_t<128, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
+    else launch_t<64, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
+}
+
 extern "C" {
+
+/* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: ring whenever K % 64 == 0; 0: register-staged loop only (A/B tests). */
+void tsasr_gemm_set_ring(int on) { g_use_ring = on; }
 
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype) {
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
@@ -242,18 +428,14 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
         TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_gemm_bf16_workspace_bytes(M, N, K, out_dtype), "tsasr_gemm_bf16: workspace too small");
         TSASR_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "tsasr_gemm_bf16: split-K output needs N, ldc multiples of 4");
         const long long ss = (long long)M * N;
-        if (p.big) launch_t<128, 128, 1>(transA, transB, A, B, workspace, M, N, K, lda, ldb, N, p.splits, p.kchunk, ss, st);
-        else launch_t<64, 64, 1>(transA, transB, A, B, workspace, M, N, K, lda, ldb, N, p.splits, p.kchunk, ss, st);
+        launch_tile<1>(p.tile, transA, transB, A, B, workspace, M, N, K, lda, ldb, N, p.splits, p.kchunk, ss, st);
         gemm_slab_reduce_kernel<<<(unsigned)cdiv((int)((ss + 3) / 4), 256), 256, 0, st>>>((const float *)workspace, (float *)C, M, N, ldc, p.splits, ss, accumulate);
     } else if (out_dtype == TSASR_BF16) {
-        if (p.big) launch_t<128, 128, 0>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
-        else launch_t<64, 64, 0>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
+        launch_tile<0>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     } else if (accumulate) {
-        if (p.big) launch_t<128, 128, 2>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
-        else launch_t<64, 64, 2>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
+        launch_tile<2>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     } else {
-        if (p.big) launch_t<128, 128, 1>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
-        else launch_t<64, 64, 1>(transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
+        launch_tile<1>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     }
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16");
     return 0;
