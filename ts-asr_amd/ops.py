@@ -470,28 +470,41 @@ class _FrontendConvFn(torch.autograd.Function):
         with prof.region("frontend_im2col"):
             C.check(C.lib().tsasr_frontend_im2col(C.ptr(xc), C.ptr(A), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
                     "tsasr_frontend_im2col")
-        wm = w1.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype)   # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]
-        w2m = w2.reshape(Co, Ci).to(xc.dtype)
+        wm = w1.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype).contiguous()   # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]
+        w2m = w2.reshape(Co, Ci).to(xc.dtype).contiguous()
         centre = 7 if causal else 4                                      # the tap that reads x[2t', 2f']
-        Ac = A.view(P, 9, Ci)[:, centre, :]
-        y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
-        y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
+        hip = xc.dtype == torch.bfloat16 and Ci % 8 == 0 and Co % 8 == 0
+        if hip:   # HIP GEMMs: y1 = A . wm^T ; y2 = A[:, centre tap] . w2m^T (strided rows, lda = 9*Ci)
+            y1 = gemm_bf16(A, wm, P, Co, 9 * Ci, 9 * Ci, 9 * Ci, 0, 0)
+            y2 = gemm_bf16(A[:, centre * Ci:], w2m, P, Co, Ci, 9 * Ci, Ci, 0, 0)
+            y1 = bias_act_dropout(y1, b1, None, 0.0, False).view(B, To, Fo, Co)
+            y2 = bias_act_dropout(y2, b2, None, 0.0, False).view(B, To, Fo, Co)
+        else:
+            Ac = A.view(P, 9, Ci)[:, centre, :]
+            y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
+            y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
         ctx.save_for_backward(A, wm, w2m)
-        ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape)
+        ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape, hip)
         return y1, y2
 
     @staticmethod
     def backward(ctx, dy1, dy2):
         A, wm, w2m = ctx.saved_tensors
-        causal, (B, T, Fq, Ci), Co, centre, dw1t, db1t, dw2t, db2t, w2shape = ctx.cfg
+        causal, (B, T, Fq, Ci), Co, centre, dw1t, db1t, dw2t, db2t, w2shape, hip = ctx.cfg
         P = A.shape[0]
-        g1, g2 = dy1.reshape(P, Co), dy2.reshape(P, Co)
-        dwm = g1.t() @ A                                                 # [Co, 9Ci]
+        g1, g2 = dy1.reshape(P, Co).contiguous(), dy2.reshape(P, Co).contiguous()
+        if hip:
+            dwm = gemm_bf16(g1, A, Co, 9 * Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32)              # g1^T . A
+            dw2 = gemm_bf16(g2, A[:, centre * Ci:], Co, Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32).view(w2shape).to(dw2t)
+            dA = gemm_bf16(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)                                         # g1 . wm
+            dR = gemm_bf16(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
+        else:
+            dwm = g1.t() @ A
+            dw2 = (g2.t() @ A.view(P, 9, Ci)[:, centre, :]).view(w2shape).to(dw2t)
+            dA = g1 @ wm
+            dR = g2 @ w2m
         dw1 = dwm.view(Co, 3, 3, Ci).permute(0, 3, 2, 1).to(dw1t)
-        dw2 = (g2.t() @ A.view(P, 9, Ci)[:, centre, :]).view(w2shape).to(dw2t)
         db1, db2 = g1.sum(0, dtype=torch.float32).to(db1t), g2.sum(0, dtype=torch.float32).to(db2t)
-        dA = g1 @ wm
-        dR = g2 @ w2m
         dx = torch.empty(B, T, Fq, Ci, dtype=A.dtype, device=A.device)
         with prof.region("frontend_col2im"):
             C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(A), C.stream_ptr()),
