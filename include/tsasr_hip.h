@@ -195,6 +195,15 @@ void tsasr_gemm_set_ring(int on); /* 1 (default): LDS-DMA ring main loop when K 
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                     int transA, int transB, int out_dtype, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* Same GEMM (bf16 out) with a fused elementwise epilogue - the Linear + activation() + Dropout of PositionalwiseFeedForward
+ * (SB/nnet/attention.py:820-836) without a separate pass over the [M, d_ffn] hidden activation:
+ *   epi_mode 1: C = dropout_p(LeakyReLU_slope(A.B + bias[n]));   epi_mode 2 (its backward on the dgrad GEMM):
+ *   C = (A.B) * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]) and dbias[n] = column sums of C.  Masks: counter-based, (seed + *seed_dev, m*N+n). */
+size_t tsasr_gemm_bf16_fused_workspace_bytes(int M, int N);
+int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                          int transA, int transB, int epi_mode, const float *bias, const void *y, long long ldy, float slope, float p,
+                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * LSTM cell steps of the prediction network (replaces torch.nn.LSTM behind SB/nnet/RNN.py:244-278; gate order i,f,g,o).

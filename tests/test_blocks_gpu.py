@@ -424,3 +424,33 @@ def test_fbank_and_sentence_norm_known_answers(nn_, ops):
     close(norm(out, lens.to(DEV)), R.sentence_norm(ref, lens), 2e-3, 1e-3)
     xb = torch.randn(2, 50, 144, generator=g)       # feature width that does not divide 256
     close(ops.sentence_norm(xb.to(DEV), torch.tensor([50, 20], device=DEV), 1e-10), R.sentence_norm(xb, torch.tensor([1.0, 0.4])), 1e-5)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_ffn_core(ops, p):
+    """_FFNFn (two HIP GEMMs with fused bias/LeakyReLU/dropout epilogues) vs the unfused composition of already-tested ops
+    sharing the same counter-based dropout stream, forward and every gradient."""
+    M, D, F1 = 777, 256, 2048
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, M // 3, D, generator=g).to(torch.bfloat16)
+    w1, b1 = torch.randn(F1, D, generator=g) / D ** 0.5, torch.randn(F1, generator=g) * 0.1
+    w2 = torch.randn(D, F1, generator=g) / F1 ** 0.5
+    do = torch.randn(3, M // 3, D, generator=g).to(torch.bfloat16)
+    outs = []
+    for fused in (True, False):
+        xs = x.to(DEV).requires_grad_()
+        ps = [t.to(DEV).requires_grad_() for t in (w1, b1, w2)]
+        ops._seed_counter[0] = 100            # same per-call dropout stream id for both variants
+        if fused:
+            o = ops.ffn_core(xs, ps[0], ps[1], ps[2], 0.01, p, True)
+        else:
+            hmid = ops.bias_act_dropout(ops.matmul_nt(xs, ps[0]), ps[1], 0.01, p, True)
+            o = ops.matmul_nt(hmid, ps[2])
+        o.backward(do.to(DEV))
+        outs.append([o.detach().float().cpu(), xs.grad.float().cpu()] + [t.grad.float().cpu() for t in ps])
+    for a, b_, name in zip(outs[0], outs[1], ("out", "dx", "dw1", "db1", "dw2")):
+        rel = float((a - b_).norm() / b_.norm())
+        assert rel < (6e-3 if name == "out" else 1.5e-2), (name, rel)   # the fused epilogues round to bf16 once instead of twice
+    if p == 0.0:  # and against plain fp32 math
+        ref = torch.nn.functional.leaky_relu(x.float() @ w1.to(torch.bfloat16).float().t() + b1, 0.01).to(torch.bfloat16).float() @ w2.to(torch.bfloat16).float().t()
+        assert float((outs[0][0] - ref).norm() / ref.norm()) < 6e-3

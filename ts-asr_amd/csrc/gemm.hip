@@ -22,6 +22,28 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
+// Fused epilogues of the bf16-output GEMM (mode 0 = plain store):
+//   1: C = dropout_p(LeakyReLU(acc + bias[n]))                       - Linear + activation + Dropout of the macaron FFN
+//   2: C = acc * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]) ; colsum -> dbias - the same chain's backward applied to the dgrad GEMM
+// The dropout mask is the counter-based one of elementwise.hip (index m*N + n, seed + *seed_dev).
+struct EpiArgs {
+    int mode;
+    const float *bias;
+    const bf16_t *y;
+    long long ldy;
+    float slope, p;
+    unsigned long long seed;
+    const unsigned long long *seed_dev;
+    float *colpart;   // [gridDim.y][N] partial column sums (mode 2)
+};
+
+__device__ __forceinline__ unsigned gemm_rng_bits(unsigned long long idx, unsigned long long seed) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
 template <int BM, int BN, bool AT, bool BT>
 struct GemmSmem {
     // non-transposed operand tile: [rows][GB_K + 8]; transposed: [GB_K][rows + 8]
@@ -94,9 +116,71 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t *lds, int LD, int blk0, int 
 // 4-byte stores strided by a row: store-issue bound at the model's short K). Caller guarantees all k-tile LDS reads are done.
 template <int BM, int BN, int OUT_MODE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], char *smem, void *__restrict__ Cv, int M, int N,
-                                              long long ldc, long long slab_stride, int m0, int n0, int wm, int wn, int lane) {
+                                              long long ldc, long long slab_stride, int m0, int n0, int wm, int wn, int lane,
+                                              const EpiArgs &ep) {
     constexpr int RB = BM / 64, CB = BN / 64;
     bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
+    if (OUT_MODE == 0 && ep.mode != 0) {   // fused elementwise epilogue: fp32 tile, one rounding at the end
+        const int r = lane & 31, hh = lane >> 5;
+        constexpr int LDT = BN + 4;
+        float *tile = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    tile[(wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * (BN / 2) + 32 * j + r] = acc[i][j][g];
+        __syncthreads();
+        unsigned long long seed = ep.seed;
+        if (ep.seed_dev) seed += *ep.seed_dev;
+        const unsigned thr = (unsigned)fminf(ep.p * 4294967296.0f, 4294967295.0f);
+        const float ks = ep.p > 0.f ? 1.f / (1.f - ep.p) : 1.f;
+        bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
+        for (int c = threadIdx.x; c < BM * (BN / 8); c += 256) {
+            const int rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+            const int m = m0 + rr, n = n0 + cc;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[rr * LDT + cc + e];
+            if (m < M && n + 8 <= N) {
+                const unsigned long long idx = (unsigned long long)m * N + n;
+                if (ep.mode == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = v[e] + (ep.bias ? ep.bias[n + e] : 0.f);
+                        if (ep.slope >= 0.f) t = lrelu(t, ep.slope);
+                        if (ep.p > 0.f) t = (gemm_rng_bits(idx + e, seed) >= thr) ? t * ks : 0.f;
+                        v[e] = t;
+                    }
+                } else {
+                    float yv[8];
+                    ld8(ep.y + (long long)m * ep.ldy + n, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = v[e];
+                        if (ep.p > 0.f) t = (gemm_rng_bits(idx + e, seed) >= thr) ? t * ks : 0.f;
+                        if (ep.slope >= 0.f && yv[e] < 0.f) t *= ep.slope;
+                        v[e] = t;
+                        tile[rr * LDT + cc + e] = t;
+                    }
+                }
+                st8(Cb + (long long)m * ldc + n, v);
+            } else if (ep.mode == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tile[rr * LDT + cc + e] = 0.f;   // rows/cols outside the matrix do not count
+            }
+        }
+        if (ep.mode == 2 && ep.colpart) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < BN; t += 256) {
+                float sum = 0.f;
+                for (int rr = 0; rr < BM; ++rr) sum += tile[rr * LDT + t];
+                if (n0 + t < N) ep.colpart[(long long)blockIdx.y * N + n0 + t] = sum;
+            }
+        }
+        return;
+    }
     const int r = lane & 31, hh = lane >> 5;
     if (OUT_MODE == 0) {
         constexpr int LDT = BN + 8;
@@ -208,7 +292,7 @@ struct RingTile {
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
-                                                                long long slab_stride) {
+                                                                long long slab_stride, EpiArgs ep) {
     using TA = RingTile<BM, AT>;
     using TB = RingTile<BN, BT>;
     constexpr int SLOT = TA::BYTES + TB::BYTES;
@@ -255,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
         }
     }
     __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
-    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane);
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep);
 }
 
 template <int BM, int BN, bool AT, bool BT>
@@ -269,7 +353,7 @@ struct RingSmem {
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
-                                                        long long slab_stride) {
+                                                        long long slab_stride, EpiArgs ep) {
     using S = GemmSmem<BM, BN, AT, BT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
@@ -319,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t *__restr
         }
         __syncthreads();
     }
-    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane);
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep);
 }
 
 // C[m][n] (+)= sum_z slab[z][m*N + n]   (fixed order)
@@ -342,7 +426,7 @@ static int g_use_ring = 1;
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
-                   int kchunk, long long slab_stride, hipStream_t st) {
+                   int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep) {
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
     // measured (tools/gemm_bench.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles; the
     // register-staged loop wins on the short-K projections (K = 256: 4 k-tiles, prologue-bound)
@@ -352,22 +436,22 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         using R = RingSmem<BM, BN, AT, BT>;
         auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE>;
         if (R::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::BYTES);
-        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride);
+        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, ep);
         return;
     }
     using S = GemmSmem<BM, BN, AT, BT>;
     auto kern = gemm_bf16_kernel<BM, BN, AT, BT, OUT_MODE>;
     if (S::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);
-    kern<<<grid, 256, S::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride);
+    kern<<<grid, 256, S::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, ep);
 }
 
 template <int BM, int BN, int OUT_MODE>
 static void launch_t(int tA, int tB, const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
-                     int splits, int kchunk, long long slab_stride, hipStream_t st) {
-    if (!tA && !tB) launch<BM, BN, false, false, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
-    else if (!tA && tB) launch<BM, BN, false, true, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
-    else if (tA && tB) launch<BM, BN, true, true, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
-    else launch<BM, BN, true, false, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
+                     int splits, int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep) {
+    if (!tA && !tB) launch<BM, BN, false, false, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+    else if (!tA && tB) launch<BM, BN, false, true, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+    else if (tA && tB) launch<BM, BN, true, true, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+    else launch<BM, BN, true, false, OUT_MODE>(A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
 }
 
 struct GemmPlan { int tile; int splits; int kchunk; };   // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
@@ -393,10 +477,29 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
 
 template <int OUT_MODE>
 static void launch_tile(int tile, int tA, int tB, const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb,
-                        long long ldc, int splits, int kchunk, long long slab_stride, hipStream_t st) {
-    if (tile == 0) launch_t<128, 128, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
-    else if (tile == 1) launch_t<128, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
-    else launch_t<64, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st);
+                        long long ldc, int splits, int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep = EpiArgs{}) {
+    if (tile == 0) launch_t<128, 128, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+    else if (tile == 1) launch_t<128, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+    else launch_t<64, 64, OUT_MODE>(tA, tB, A, B, C, M, N, K, lda, ldb, ldc, splits, kchunk, slab_stride, st, ep);
+}
+
+static int tile_bm(int tile) { return tile == 2 ? 64 : 128; }
+
+// out[n] = sum_parts part[p][n]
+__global__ __launch_bounds__(256) void gemm_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int nparts, int N) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = blockIdx.x * 16 + cl;
+    float s0 = 0.f;
+    if (col < N)
+        for (int n = slice; n < nparts; n += 16) s0 += part[(size_t)n * N + col];
+    red[slice][cl] = s0;
+    __syncthreads();
+    if (slice == 0 && col < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        out[col] = s;
+    }
 }
 
 extern "C" {
@@ -438,6 +541,33 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
         launch_tile<1>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     }
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16");
+    return 0;
+}
+
+size_t tsasr_gemm_bf16_fused_workspace_bytes(int M, int N) { return align_up((size_t)cdiv(M, 64) * N * sizeof(float), 256); }
+
+/* bf16-output GEMM with a fused elementwise epilogue (no split-K):
+ *   epi_mode 1: C = dropout_p(LeakyReLU_slope(op(A).op(B) + bias[n]))           (slope < 0: no activation; bias may be NULL)
+ *   epi_mode 2: C = (op(A).op(B)) * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]); dbias[n] = column sums of C (dbias may be NULL)
+ * y [M,N] bf16 (row stride ldy) is the saved output of the mode-1 call with the same (p, seed): the mask is regenerated. */
+int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                          int transA, int transB, int epi_mode, const float *bias, const void *y, long long ldy, float slope, float p,
+                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(A && B && C, "tsasr_gemm_bf16_fused: null pointer");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && ldc % 8 == 0, "tsasr_gemm_bf16_fused: N and ldc must be multiples of 8");
+    TSASR_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && (transA ? M : K) % 8 == 0 && (transB ? N : K) % 8 == 0, "tsasr_gemm_bf16_fused: rows must be multiples of 8 bf16");
+    TSASR_CHECK_ARG(epi_mode == 1 || (epi_mode == 2 && y && ldy % 8 == 0), "tsasr_gemm_bf16_fused: bad epilogue mode %d", epi_mode);
+    TSASR_CHECK_ARG(p >= 0.f && p < 1.f, "tsasr_gemm_bf16_fused: bad dropout %f", p);
+    TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
+    GemmPlan pl = plan(M, N, K, 0);
+    hipStream_t st = (hipStream_t)stream;
+    EpiArgs ep{};
+    ep.mode = epi_mode; ep.bias = bias; ep.y = (const bf16_t *)y; ep.ldy = ldy; ep.slope = slope; ep.p = p; ep.seed = seed; ep.seed_dev = seed_dev;
+    ep.colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;
+    launch_tile<0>(pl.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, pl.kchunk, 0, st, ep);
+    if (ep.colpart) gemm_colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(ep.colpart, dbias, cdiv(M, tile_bm(pl.tile)), N);
+    TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_fused");
     return 0;
 }
 

@@ -394,8 +394,7 @@ class ConformerEncoderLayer(nn.Module):
         """x + 0.5 * Dropout(PFF(LN(x)))  - macaron half-step (Conformer.py:243,258)."""
         ln, pff = mod[0], mod[1].ffn
         y = ops.layer_norm(x, ln.weight, ln.bias, 1e-5)
-        y = ops.linear(y, pff[0].weight, pff[0].bias, self.slope, self.dropout, self.training)   # GEMM + bias/LeakyReLU/dropout pass
-        y = ops.matmul_nt(y, pff[3].weight)
+        y = ops.ffn_core(y, pff[0].weight, pff[0].bias, pff[3].weight, self.slope, self.dropout, self.training)   # two GEMMs, fused epilogues
         return ops.dropout_add(y, pff[3].bias, x, 0.5, self.dropout, self.training)
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True):

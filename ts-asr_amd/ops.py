@@ -161,6 +161,75 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw
 
 
+def gemm_bf16_fused(a, b, M, N, K, lda, ldb, trans_a, trans_b, mode, bias=None, y=None, slope=-1.0, p=0.0, seed=0, dbias=None):
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    ws = _ws(C.lib().tsasr_gemm_bf16_fused_workspace_bytes(M, N), a.device) if dbias is not None else None
+    with prof.region(f"gemm_bf16_fused<{mode}>", 2.0 * M * N * K):
+        C.check(C.lib().tsasr_gemm_bf16_fused(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, N, int(trans_a), int(trans_b), int(mode),
+                                              C.ptr(bias), C.ptr(y), 0 if y is None else y.stride(0), float(slope), float(p), seed,
+                                              C.ptr(seed_state(a.device)), C.ptr(dbias), C.ptr(ws), 0 if ws is None else ws.numel(),
+                                              C.stream_ptr()), "tsasr_gemm_bf16_fused")
+    return out
+
+
+class _FFNFn(torch.autograd.Function):
+    """PositionalwiseFeedForward core (SB/nnet/attention.py:820-836): Linear(D->F) + bias + LeakyReLU + Dropout + Linear(F->D),
+    as two HIP GEMMs: the first with the bias/activation/dropout epilogue, the second plain. Backward: dgrad of the second
+    GEMM carries the activation/dropout backward (and the bias-gradient column sums) in ITS epilogue; both weight gradients
+    are added straight into the gradient arena. The [M, F] hidden activation is written once and read twice - no
+    elementwise pass over it in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, slope, p, seed):
+        F1, D = w1.shape
+        x2 = x.reshape(-1, D)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        w1h, w2h = _bf16_weight(w1).contiguous(), _bf16_weight(w2).contiguous()
+        b1f = None if b1 is None else _f32(b1).contiguous()
+        h = gemm_bf16_fused(x2, w1h, M, F1, D, D, D, 0, 0, 1, bias=b1f, slope=slope, p=p, seed=seed)
+        o = gemm_bf16(h, w2h, M, w2.shape[0], F1, F1, F1, 0, 0)
+        ctx.save_for_backward(x2, h, w1h, w2h)
+        ctx.cfg = (float(slope), float(p), seed, (w1, b1, w2), x.shape)
+        return o.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, do):
+        x2, h, w1h, w2h = ctx.saved_tensors
+        slope, p, seed, (w1, b1, w2), xshape = ctx.cfg
+        F1, D = w1.shape
+        Dout = w2.shape[0]
+        M = x2.shape[0]
+        do2 = do.reshape(M, Dout)
+        if not do2.is_contiguous():
+            do2 = do2.contiguous()
+        db1 = torch.empty(F1, dtype=torch.float32, device=x2.device) if b1 is not None else None
+        # dh_pre = (do . W2) * dropout/activation backward, + column sums -> db1
+        dh = gemm_bf16_fused(do2, w2h, M, F1, Dout, Dout, F1, 0, 1, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
+        dx = gemm_bf16(dh, w1h, M, D, F1, F1, D, 0, 1).view(xshape) if ctx.needs_input_grad[0] else None
+        sink = _GRAD_SINK
+
+        def wgrad(w, g, a, n_out, k_in):
+            if sink is not None and w.is_leaf and sink.accepts(w) and w.grad.dtype == torch.float32 and w.grad.is_contiguous():
+                gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out=w.grad, accumulate=True)
+                sink.mark_ready(w)
+                return None
+            return gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out_dtype=torch.float32).to(w.dtype)
+
+        dw2 = wgrad(w2, do2, h, Dout, F1)
+        dw1 = wgrad(w1, dh, x2, F1, D)
+        return dx, dw1, _pgrad(b1, db1), dw2, None, None, None
+
+
+def ffn_core(x, w1, b1, w2, slope, p, training):
+    """Linear(w1,b1) -> LeakyReLU -> Dropout -> Linear(w2) (bias of the second Linear is applied by the caller's fused tail)."""
+    p = float(p) if training else 0.0
+    if _gemm_ok(x, w1) and _gemm_ok(x.new_empty(0, w2.shape[1]), w2) and w1.shape[0] % 8 == 0:
+        return _FFNFn.apply(x, w1, b1, w2, -1.0 if slope is None else slope, p, next_seed() if p > 0 else 0)
+    return matmul_nt(linear(x, w1, b1, slope, p, training), w2)
+
+
 def matmul_nt(x, weight):
     """x @ weight^T. bf16 activations: hand-written MFMA GEMM (csrc/gemm.hip); fp32 activations (parity runs): the exact fp32
     library GEMM through PyTorch-ROCm."""
