@@ -213,6 +213,10 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
  * dc_io [B,H] fp32 carried between steps, dgates [B,U,4H] io_dtype out (operand of the dh / dW GEMMs).
  * ------------------------------------------------------------------------------------------ */
 int tsasr_lstm_cell_fwd(float *gates, float *c, void *h, int B, int U, int H, int t, int io_dtype, void *stream);
+/* Fused variants: recurrent product (MFMA, K split over the waves) + cell update in one launch per step; whh bf16 [4H,H], whhT bf16 [H,4H]. */
+int tsasr_lstm_step_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, int H, int t, int io_dtype, void *stream);
+int tsasr_lstm_step_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, float *dc_io, int B, int U,
+                        int H, int t, int io_dtype, void *stream);
 int tsasr_lstm_cell_bwd(const float *gates, const float *c, const void *dout, const float *dh_rec, float *dc_io, void *dgates, int B,
                         int U, int H, int t, int io_dtype, void *stream);
 

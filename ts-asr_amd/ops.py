@@ -263,14 +263,9 @@ class _LstmFn(torch.autograd.Function):
         h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
         whh16 = _bf16_weight(w_hh).contiguous()
         lib, st = C.lib(), C.stream_ptr()
-        nws = lib.tsasr_gemm_bf16_workspace_bytes(B, 4 * H, H, C.F32)
-        ws = _ws(nws, dev) if nws else None
         with prof.region("lstm_fwd"):
-            for t in range(U):
-                if t > 0:   # gates[:, t] += h[:, t-1] . W_hh^T
-                    C.check(lib.tsasr_gemm_bf16(C.ptr(h[:, t - 1]), C.ptr(whh16), C.ptr(gates[:, t]), B, 4 * H, H, U * H, H, U * 4 * H,
-                                                0, 0, C.F32, 1, C.ptr(ws), nws, st), "tsasr_gemm_bf16")
-                C.check(lib.tsasr_lstm_cell_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), B, U, H, t, C.BF16, st), "tsasr_lstm_cell_fwd")
+            for t in range(U):   # one fused launch per step: gates[:, t] += h[:, t-1] . W_hh^T, then the cell update
+                C.check(lib.tsasr_lstm_step_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh16), B, U, H, t, C.BF16, st), "tsasr_lstm_step_fwd")
         ctx.save_for_backward(x, gates, c, h, whh16)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
         return h
@@ -284,18 +279,13 @@ class _LstmFn(torch.autograd.Function):
         dev = x.device
         dout = dout.contiguous()
         dgates = torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=dev)
-        dh_rec = torch.zeros(B, H, dtype=torch.float32, device=dev)
         dc = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        whhT = whh16.t().contiguous()
         lib, st = C.lib(), C.stream_ptr()
-        nws = lib.tsasr_gemm_bf16_workspace_bytes(B, H, 4 * H, C.F32)
-        ws = _ws(nws, dev) if nws else None
         with prof.region("lstm_bwd"):
-            for t in range(U - 1, -1, -1):
-                C.check(lib.tsasr_lstm_cell_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dh_rec), C.ptr(dc), C.ptr(dgates), B, U, H, t,
-                                                C.BF16, st), "tsasr_lstm_cell_bwd")
-                if t > 0:   # dh_rec = dgates[:, t] . W_hh
-                    C.check(lib.tsasr_gemm_bf16(C.ptr(dgates[:, t]), C.ptr(whh16), C.ptr(dh_rec), B, H, 4 * H, U * 4 * H, H, H, 0, 1,
-                                                C.F32, 0, C.ptr(ws), nws, st), "tsasr_gemm_bf16")
+            for t in range(U - 1, -1, -1):   # one fused launch per step: dh = dout[:, t] + dgates[:, t+1] . W_hh, cell backward
+                C.check(lib.tsasr_lstm_step_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), C.ptr(dc), B, U, H, t,
+                                                C.BF16, st), "tsasr_lstm_step_bwd")
         dg2 = dgates.view(B * U, 4 * H)
         h_prev = torch.zeros_like(h)
         h_prev[:, 1:] = h[:, :-1]
@@ -310,7 +300,7 @@ class _LstmFn(torch.autograd.Function):
 def lstm(x, rnn, hx=None):
     """bf16 training path: HIP cell kernels + HIP GEMM per step. Stepwise decoding (hx given) and fp32 parity runs keep the
     library LSTM (MIOpen through PyTorch-ROCm)."""
-    if (hx is None and x.dtype == torch.bfloat16 and rnn.num_layers == 1 and not rnn.bidirectional and rnn.hidden_size % 8 == 0
+    if (hx is None and x.dtype == torch.bfloat16 and rnn.num_layers == 1 and not rnn.bidirectional and rnn.hidden_size % 16 == 0
             and x.shape[1] > 1):
         out = _LstmFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
         return out, None
