@@ -71,18 +71,25 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float *__restrict__ 
         const int ks = H / 16, per = (ks + 3) / 4;
         const int brow = min(b0 + r, B - 1);
         const T *hrow = h + ((long long)brow * U + (t - 1)) * H;
-        for (int s = wave * per; s < min(ks, (wave + 1) * per); ++s) {
-            float a8[8];
-            ld8(hrow + 16 * s + 8 * hh, a8);
-            bf16x8 af;
+        const int s_end = min(ks, (wave + 1) * per);
+        for (int sb = wave * per; sb < s_end; sb += 8) {   // issue 8 k-steps of operand loads, then their 16 MFMAs (one L2 latency per chunk)
+            bf16x8 af[8], bf0[8], bf1[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = (bf16_t)a8[j];
+            for (int q = 0; q < 8; ++q) {
+                const int s = min(sb + q, s_end - 1);
+                float a8[8];
+                ld8(hrow + 16 * s + 8 * hh, a8);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int g = 2 * cb + (r >> 4), j = r & 15;
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(whh + ((long long)g * H + u0 + j) * H + 16 * s + 8 * hh);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[cb], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) af[q][j] = (bf16_t)a8[j];
+                bf0[q] = *reinterpret_cast<const bf16x8 *>(whh + ((long long)(r >> 4) * H + u0 + (r & 15)) * H + 16 * s + 8 * hh);
+                bf1[q] = *reinterpret_cast<const bf16x8 *>(whh + ((long long)(2 + (r >> 4)) * H + u0 + (r & 15)) * H + 16 * s + 8 * hh);
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (sb + q < s_end) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bf0[q], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bf1[q], acc[1], 0, 0, 0);
+                }
         }
     }
 #pragma unroll
@@ -121,14 +128,21 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
         const int brow = min(b0 + r, B - 1);
         const T *drow = dgates + ((long long)brow * U + (t + 1)) * K4;
         const bf16_t *wrow = whhT + (long long)(u0 + (r & 15)) * K4;
-        for (int s = wave * per; s < min(ks, (wave + 1) * per); ++s) {
-            float a8[8];
-            ld8(drow + 16 * s + 8 * hh, a8);
-            bf16x8 af;
+        const int s_end = min(ks, (wave + 1) * per);
+        for (int sb = wave * per; sb < s_end; sb += 8) {
+            bf16x8 af[8], bfr[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = (bf16_t)a8[j];
-            const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s + 8 * hh);   // columns 16..31 duplicate 0..15 (unused)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                const int s = min(sb + q, s_end - 1);
+                float a8[8];
+                ld8(drow + 16 * s + 8 * hh, a8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) af[q][j] = (bf16_t)a8[j];
+                bfr[q] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s + 8 * hh);   // columns 16..31 duplicate 0..15 (unused)
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (sb + q < s_end) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q], bfr[q], acc, 0, 0, 0);
         }
     }
 #pragma unroll
