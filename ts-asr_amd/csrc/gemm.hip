@@ -57,6 +57,19 @@ struct GemmSmem {
     static constexpr size_t BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
 };
 
+// XCD-aware workgroup -> tile mapping (guide T1, bijective form): hardware deals workgroups round-robin over the 8 XCDs, each
+// with a private 4 MiB L2; remapping the linear id so that one XCD receives a CONTIGUOUS run of tiles (same row panel,
+// consecutive column tiles, then the next row panel) keeps operand panels hot in that XCD's L2 instead of fetching every panel
+// into all eight (rocprofv3 FETCH_SIZE showed 3.5x the algorithmic bytes on the weight-gradient GEMMs without it).
+__device__ __forceinline__ void tile_coords(int nx, int ny, int nz, int &tx, int &ty, int &tz) {
+    const int nwg = nx * ny * nz, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    tx = id % nx;
+    ty = (id / nx) % ny;
+    tz = id / (nx * ny);
+}
+
 // one 16-byte chunk (8 bf16) of an operand tile per (thread, iteration): global -> registers
 template <int ROWS, bool TR>
 struct TileLoader {
@@ -117,7 +130,7 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t *lds, int LD, int blk0, int 
 template <int BM, int BN, int OUT_MODE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], char *smem, void *__restrict__ Cv, int M, int N,
                                               long long ldc, long long slab_stride, int m0, int n0, int wm, int wn, int lane,
-                                              const EpiArgs &ep) {
+                                              const EpiArgs &ep, int tile_y, int tile_z) {
     constexpr int RB = BM / 64, CB = BN / 64;
     bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
     if (OUT_MODE == 0 && ep.mode != 0) {   // fused elementwise epilogue: fp32 tile, one rounding at the end
@@ -176,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
             for (int t = threadIdx.x; t < BN; t += 256) {
                 float sum = 0.f;
                 for (int rr = 0; rr < BM; ++rr) sum += tile[rr * LDT + t];
-                if (n0 + t < N) ep.colpart[(long long)blockIdx.y * N + n0 + t] = sum;
+                if (n0 + t < N) ep.colpart[(long long)tile_y * N + n0 + t] = sum;
             }
         }
         return;
@@ -214,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
                 for (int g = 0; g < 16; ++g)
                     tile[(wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * (BN / 2) + 32 * j + r] = acc[i][j][g];
         __syncthreads();
-        float *Cf = reinterpret_cast<float *>(Cv) + (OUT_MODE == 1 ? (long long)blockIdx.z * slab_stride : 0);
+        float *Cf = reinterpret_cast<float *>(Cv) + (OUT_MODE == 1 ? (long long)tile_z * slab_stride : 0);
         const bool vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cf) & 15) == 0);
         for (int c = threadIdx.x; c < BM * (BN / 4); c += 256) {
             const int rr = c / (BN / 4), cc = (c % (BN / 4)) * 4;
@@ -292,7 +305,7 @@ struct RingTile {
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
-                                                                long long slab_stride, EpiArgs ep) {
+                                                                long long slab_stride, int nsplit, EpiArgs ep) {
     using TA = RingTile<BM, AT>;
     using TB = RingTile<BN, BT>;
     constexpr int SLOT = TA::BYTES + TB::BYTES;
@@ -300,8 +313,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RB = BM / 64, CB = BN / 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    int tx, ty, tz;
+    tile_coords((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int kbeg = tz * kchunk, kend = min(K, kbeg + kchunk);
     const int nk = (kend - kbeg) / GB_K;
     f32x16 acc[RB][CB];
 #pragma unroll
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
         }
     }
     __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
-    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep);
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep, ty, tz);
 }
 
 template <int BM, int BN, bool AT, bool BT>
@@ -353,14 +368,16 @@ struct RingSmem {
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
-                                                        long long slab_stride, EpiArgs ep) {
+                                                        long long slab_stride, int nsplit, EpiArgs ep) {
     using S = GemmSmem<BM, BN, AT, BT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
     constexpr int RB = BM / 64, CB = BN / 64;  // 32x32 blocks per wave in each direction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    int tx, ty, tz;
+    tile_coords((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit, tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN;
+    const int kbeg = tz * kchunk, kend = min(K, kbeg + kchunk);
     f32x16 acc[RB][CB];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t *__restr
         }
         __syncthreads();
     }
-    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep);
+    gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep, ty, tz);
 }
 
 // C[m][n] (+)= sum_z slab[z][m*N + n]   (fixed order)
@@ -427,7 +444,7 @@ static int g_use_ring = 1;
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
                    int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep) {
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 grid((unsigned)(cdiv(N, BN) * cdiv(M, BM) * splits));   // 1-D: tile coordinates come from the XCD-aware remap
     // measured (tools/gemm_bench.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles; the
     // register-staged loop wins on the short-K projections (K = 256: 4 k-tiles, prologue-bound)
     const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024) &&
@@ -436,13 +453,13 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         using R = RingSmem<BM, BN, AT, BT>;
         auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE>;
         if (R::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::BYTES);
-        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, ep);
+        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
         return;
     }
     using S = GemmSmem<BM, BN, AT, BT>;
     auto kern = gemm_bf16_kernel<BM, BN, AT, BT, OUT_MODE>;
     if (S::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);
-    kern<<<grid, 256, S::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, ep);
+    kern<<<grid, 256, S::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
 }
 
 template <int BM, int BN, int OUT_MODE>
