@@ -233,6 +233,19 @@ int tsasr_fbank_fwd(const float *wav, const float *window, const float *melmat, 
 int tsasr_sentence_norm_fwd(const void *x, const int32_t *lens, void *y, int B, int T, int F, float eps, int in_dtype, int out_dtype,
                             void *stream);
 
+/* Fused seam between two Conformer sub-blocks: s = res + alpha*timemask(dropout_p(x + bias)); y = LayerNorm(s)
+ * (Dropout -> [0.5*]x + residual -> masked_fill_ -> nn.LayerNorm; Conformer.py:113-114,194-217,239-259) and its backward
+ * (dres = LN_bwd(dy) + dout; dx = alpha*timemask*dropmask/(1-p)*dres; dgamma, dbeta, dbias). D % 8 == 0, D <= 2048. */
+int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, void *s, void *y, float *mean, float *rstd,
+                            const float *gamma, const float *beta, long long M, int D, float alpha, float p, unsigned long long seed,
+                            const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, float eps, int io_dtype,
+                            void *stream);
+size_t tsasr_add_layernorm_bwd_workspace_bytes(long long M, int D);
+int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, const float *gamma, const float *mean, const float *rstd,
+                            void *dres, void *dx, float *dgamma, float *dbeta, float *dbias, long long M, int D, float alpha, float p,
+                            unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                            int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,45 @@ def test_dropout_add_and_time_mask(ops):
     close(r1.grad, torch.full((B, 1, N), float(Tn)), 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,p,lens", [(256, 0.0, True), (256, 0.1, True), (144, 0.1, False), (1024, 0.0, False)])
+def test_add_layer_norm_equals_dropout_add_then_layernorm(ops, dtype, D, p, lens):
+    """The fused seam (s, LN(s)) against the two tested single kernels run with the same dropout seed, forward and backward."""
+    B, Tn = 3, 21
+    g = torch.Generator().manual_seed(D)
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    x, res, b, gam, bet = mk(B, Tn, D), mk(B, Tn, D), mk(D), 1 + 0.1 * mk(D), 0.1 * mk(D)
+    ds, dy = mk(B, Tn, D), mk(B, Tn, D)
+    vl = torch.tensor([21, 9, 1], dtype=torch.int32).to(DEV) if lens else None
+    trows = Tn if lens else 0
+    seed = 1234 if p > 0 else 0
+
+    def leaves():
+        return [t.to(DEV).to(dtype if i < 2 else torch.float32).requires_grad_() for i, t in enumerate((x, res, b, gam, bet))]
+
+    a = leaves()
+    s1, y1 = ops._AddLayerNormFn.apply(a[0], a[2], a[1], a[3], a[4], 0.5, p, seed, vl, trows, 1e-5)
+    torch.autograd.backward([s1, y1], [ds.to(DEV).to(dtype), dy.to(DEV).to(dtype)])
+    r = leaves()
+    s2 = ops._DropoutAddFn.apply(r[0], r[2], r[1], 0.5, p, seed, vl, trows)
+    y2 = ops._LayerNormFn.apply(s2, r[3], r[4], 1e-5, -1.0)
+    torch.autograd.backward([s2, y2], [ds.to(DEV).to(dtype), dy.to(DEV).to(dtype)])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    close(s1, s2, 0 if dtype == torch.float32 else tol)
+    close(y1, y2, tol)
+    for u, v, name in zip(a, r, ("dx", "dres", "dbias", "dgamma", "dbeta")):
+        scale = max(1.0, float(v.grad.abs().max()))
+        close(u.grad, v.grad, tol * scale, rtol=1e-4 if dtype == torch.float32 else 2e-2)
+    # y unused downstream (last seam of a layer returns only LN(s)): gradient flows through y alone
+    a = leaves()
+    _, y3 = ops._AddLayerNormFn.apply(a[0], a[2], a[1], a[3], a[4], 0.5, p, seed, vl, trows, 1e-5)
+    y3.backward(dy.to(DEV).to(dtype))
+    r = leaves()
+    y4 = ops._LayerNormFn.apply(ops._DropoutAddFn.apply(r[0], r[2], r[1], 0.5, p, seed, vl, trows), r[3], r[4], 1e-5, -1.0)
+    y4.backward(dy.to(DEV).to(dtype))
+    close(a[1].grad, r[1].grad, tol, rtol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
 # ---------------------------------------------------------------------------------------------- blocks vs reference golden
 @pytest.mark.parametrize("tag,causal", [("conv", False), ("conv_causal", True)])
 def test_convolution_module_vs_reference(nn_, golden, tag, causal):

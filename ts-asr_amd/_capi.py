@@ -74,6 +74,9 @@ _PROTOS = {
     "tsasr_fbank_workspace_bytes": (c_size_t, [c_int] * 3),
     "tsasr_fbank_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_sentence_norm_fwd": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_int, c_int, c_void_p]),
+    "tsasr_add_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "tsasr_add_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
+    "tsasr_add_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 

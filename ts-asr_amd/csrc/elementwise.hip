@@ -424,6 +424,186 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fused residual tail + LayerNorm (the seam between two Conformer sub-blocks):
+//   s = res + alpha * timemask(dropout_p(x + bias)) ;  y = LayerNorm(s) * gamma + beta        (one wave per row)
+// replaces Dropout -> (0.5*)x + residual -> [masked_fill_] -> nn.LayerNorm, Conformer.py:113-114,239-259 + :73,194-217.
+// Backward: d_s = LayerNorm_bwd(dy) + dout (gradient arriving through the residual path);  dres = d_s ;
+//           dx = alpha * timemask * dropmask/(1-p) * d_s ;  column partials for dgamma, dbeta, dbias.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
+                                                                const T *__restrict__ res, T *__restrict__ s_out, T *__restrict__ y,
+                                                                float *__restrict__ mean, float *__restrict__ rstd,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                long long M, int D, float alpha, float p, unsigned long long seed,
+                                                                const unsigned long long *__restrict__ seed_dev,
+                                                                const int32_t *__restrict__ valid_lens, int Trows, float eps) {
+    constexpr int N = Vec<T>::N;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (row >= M) return;
+    if (seed_dev) seed += *seed_dev;
+    const unsigned thr = drop_threshold(p);
+    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+    float v[ITERS][N];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + l) * N;
+        if (c < D) {
+            float xv[N], rv[N];
+            ldv<T, N>(x + row * D + c, xv);
+            ldv<T, N>(res + row * D + c, rv);
+            const unsigned long long idx = (unsigned long long)row * D + c;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t = xv[j] + (bias ? bias[c + j] : 0.f);
+                if (p > 0.f) t = (rng_bits(idx + j, seed) >= thr) ? t * ks : 0.f;
+                t = live ? t * alpha : 0.f;
+                t += rv[j];
+                if (sizeof(T) == 2) t = (float)(bf16_t)t;   // statistics of the STORED (rounded) row, as a separate LN would see
+                v[it][j] = t;
+                sum += t;
+            }
+            stv<T, N>(s_out + row * D + c, v[it]);
+        }
+    }
+    const float mu = wave_sum(sum) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const float d = v[it][j] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + l) * N;
+        if (c < D) {
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu) * rs * gamma[c + j] + beta[c + j];
+            stv<T, N>(y + row * D + c, o);
+        }
+    }
+}
+
+// part rows per workgroup: [dgamma D | dbeta D | dbias D]
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ dout,
+                                                                const T *__restrict__ s_in, const float *__restrict__ gamma,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                T *__restrict__ dres, T *__restrict__ dx, float *__restrict__ part,
+                                                                long long M, int D, float alpha, float p, unsigned long long seed,
+                                                                const unsigned long long *__restrict__ seed_dev,
+                                                                const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [4 waves][3][D]
+    if (seed_dev) seed += *seed_dev;
+    const unsigned thr = drop_threshold(p);
+    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float ag[ITERS][N], abt[ITERS][N], abx[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = abx[it][j] = 0.f;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    for (int rr = wave; rr < rows_per_wg; rr += 4) {
+        const long long row = r0 + rr;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+        float xh[ITERS][N], gd[ITERS][N];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + l) * N;
+            if (c < D) {
+                float sv[N], dv[N];
+                ldv<T, N>(s_in + row * D + c, sv);
+                ldv<T, N>(dy + row * D + c, dv);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float h = (sv[j] - mu) * rs;
+                    xh[it][j] = h;
+                    ag[it][j] += dv[j] * h;
+                    abt[it][j] += dv[j];
+                    const float g = dv[j] * gamma[c + j];
+                    gd[it][j] = g;
+                    s1 += g;
+                    s2 += g * h;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) xh[it][j] = gd[it][j] = 0.f;
+            }
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + l) * N;
+            if (c < D) {
+                float ds[N], dxv[N], dov[N];
+                if (dout) ldv<T, N>(dout + row * D + c, dov);
+                const unsigned long long idx = (unsigned long long)row * D + c;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float d = rs * (gd[it][j] - m1 - xh[it][j] * m2) + (dout ? dov[j] : 0.f);
+                    ds[j] = d;
+                    float g = live ? d * alpha : 0.f;
+                    if (p > 0.f) g = (rng_bits(idx + j, seed) >= thr) ? g * ks : 0.f;
+                    dxv[j] = g;
+                    abx[it][j] += g;
+                }
+                stv<T, N>(dres + row * D + c, ds);
+                stv<T, N>(dx + row * D + c, dxv);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                colbuf[(wave * 3 + 0) * D + c + j] = ag[it][j];
+                colbuf[(wave * 3 + 1) * D + c + j] = abt[it][j];
+                colbuf[(wave * 3 + 2) * D + c + j] = abx[it][j];
+            }
+        }
+    }
+    __syncthreads();
+    float *pw = part + (size_t)blockIdx.x * 3 * D;
+    for (int i = threadIdx.x; i < 3 * D; i += 256) pw[i] = colbuf[i] + colbuf[3 * D + i] + colbuf[6 * D + i] + colbuf[9 * D + i];
+}
+
+// out3[k][c] = sum_parts part[n][k*D + c], k = 0..2 (dgamma, dbeta, dbias) ; any out pointer may be NULL
+__global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ part, float *__restrict__ o0, float *__restrict__ o1,
+                                                      float *__restrict__ o2, int nparts, int D) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = blockIdx.x * 16 + cl, W = 3 * D;
+    float s0 = 0.f;
+    if (col < W)
+        for (int n = slice; n < nparts; n += 16) s0 += part[(size_t)n * W + col];
+    red[slice][cl] = s0;
+    __syncthreads();
+    if (slice == 0 && col < W) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        float *o = col < D ? o0 : (col < 2 * D ? o1 : o2);
+        if (o) o[col % D] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
@@ -606,6 +786,63 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
+    return 0;
+}
+
+/* s = res + alpha * timemask(dropout_p(x + bias)) ; y = LayerNorm(s; gamma, beta, eps).  x, res, s, y: [M, D] io_dtype
+ * (D % 8 == 0, D <= 2048); mean, rstd fp32 [M] saved for the backward; valid_lens/Trows as tsasr_dropout_add_fwd. */
+int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, void *s, void *y, float *mean, float *rstd,
+                            const float *gamma, const float *beta, long long M, int D, float alpha, float p, unsigned long long seed,
+                            const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, float eps, int io_dtype,
+                            void *stream) {
+    TSASR_CHECK_ARG(x && res && s && y && mean && rstd && gamma && beta, "tsasr_add_layernorm_fwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_add_layernorm_fwd: bad shape/p");
+    TSASR_CHECK_ARG(!valid_lens || (Trows > 0 && M % Trows == 0), "tsasr_add_layernorm_fwd: rows not a multiple of T");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((M + 3) / 4);
+#define ALN_F(TT, IT) add_layernorm_fwd_kernel<TT, IT><<<grid, 256, 0, st>>>((const TT *)x, bias, (const TT *)res, (TT *)s, (TT *)y, mean, rstd, gamma, beta, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps)
+    if (io_dtype == TSASR_BF16) {
+        if (D <= 512) ALN_F(bf16_t, 1); else if (D <= 1024) ALN_F(bf16_t, 2); else if (D <= 2048) ALN_F(bf16_t, 4);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_fwd: D=%d too large", D);
+    } else if (io_dtype == TSASR_F32) {
+        if (D <= 256) ALN_F(float, 1); else if (D <= 512) ALN_F(float, 2); else if (D <= 1024) ALN_F(float, 4); else if (D <= 2048) ALN_F(float, 8);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_fwd: D=%d too large", D);
+    } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+#undef ALN_F
+    TSASR_CHECK_LAUNCH("tsasr_add_layernorm_fwd");
+    return 0;
+}
+
+size_t tsasr_add_layernorm_bwd_workspace_bytes(long long M, int D) {
+    const int rpw = pick_rows_per_wg(M, 16);
+    return align_up((size_t)((M + rpw - 1) / rpw) * 3 * D * sizeof(float), 256);
+}
+
+/* dres = LayerNorm_bwd(dy) + dout (dout may be NULL); dx = alpha * timemask * dropmask/(1-p) * dres; dgamma, dbeta, dbias fp32 [D]
+ * (any of the three may be NULL). s = the tensor written by the forward. */
+int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, const float *gamma, const float *mean, const float *rstd,
+                            void *dres, void *dx, float *dgamma, float *dbeta, float *dbias, long long M, int D, float alpha, float p,
+                            unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                            int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dy && s && gamma && mean && rstd && dres && dx && workspace, "tsasr_add_layernorm_bwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_add_layernorm_bwd: bad shape");
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_add_layernorm_bwd_workspace_bytes(M, D), "tsasr_add_layernorm_bwd: workspace too small");
+    const int rpw = pick_rows_per_wg(M, 16);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    const size_t lds = (size_t)12 * D * sizeof(float);
+#define ALN_B(TT, IT) add_layernorm_bwd_kernel<TT, IT><<<nwg, 256, lds, st>>>((const TT *)dy, (const TT *)dout, (const TT *)s, gamma, mean, rstd, (TT *)dres, (TT *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw)
+    if (io_dtype == TSASR_BF16) {
+        if (D <= 512) ALN_B(bf16_t, 1); else if (D <= 1024) ALN_B(bf16_t, 2); else if (D <= 2048) ALN_B(bf16_t, 4);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_bwd: D=%d too large", D);
+    } else if (io_dtype == TSASR_F32) {
+        if (D <= 256) ALN_B(float, 1); else if (D <= 512) ALN_B(float, 2); else if (D <= 1024) ALN_B(float, 4); else if (D <= 2048) ALN_B(float, 8);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_bwd: D=%d too large", D);
+    } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+#undef ALN_B
+    colsum3_kernel<<<cdiv(3 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, dbias, nwg, D);
+    TSASR_CHECK_LAUNCH("tsasr_add_layernorm_bwd");
     return 0;
 }
 

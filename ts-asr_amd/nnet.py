@@ -365,13 +365,16 @@ class ConvolutionModule(nn.Module):
             valid_lens = (~mask.squeeze(-1)).sum(-1).to(torch.int32)
         return self.forward_add(x, None, valid_lens)
 
-    def forward_add(self, x, res, valid_lens=None):
-        """res + module(x) with dropout, pad masking and the residual add fused into the last pass."""
-        y = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5)
+    def core(self, y):
+        """Everything between the module's LayerNorm and its last bias/dropout: y = LN(x) -> [.., D] (bias of after_conv[2] not added)."""
         y = ops.matmul_nt(y, self.bottleneck[0].weight.squeeze(-1))                                # 1x1 conv D->2D (bias below)
         y = ops.convmod_core(y, self.bottleneck[0].bias, self.conv.weight, self.conv.bias, self.after_conv[0].weight,
                              self.after_conv[0].bias, self.causal, 1e-5, self.slope)                # bias+GLU+depthwise+LN+act
-        y = ops.matmul_nt(y, self.after_conv[2].weight)
+        return ops.matmul_nt(y, self.after_conv[2].weight)
+
+    def forward_add(self, x, res, valid_lens=None):
+        """res + module(x) with dropout, pad masking and the residual add fused into the last pass."""
+        y = self.core(ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5))
         return ops.dropout_add(y, self.after_conv[2].bias, res, 1.0, self.dropout, self.training, valid_lens)
 
 
@@ -399,12 +402,21 @@ class ConformerEncoderLayer(nn.Module):
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True):
         """Returns (x, attention weights [B,H,T,T] or None). The reference always materialises the weights
-        (Conformer.py:247-254); the encoder passes need_attn=False unless return_attn is requested."""
+        (Conformer.py:247-254); the encoder passes need_attn=False unless return_attn is requested.
+        Every ``residual + branch`` of Conformer.py:243-259 is fused with the LayerNorm that reads it (ops.add_layer_norm)."""
         if valid_lens is None and src_key_padding_mask is not None:
             valid_lens = (~src_key_padding_mask).sum(-1).to(torch.int32)
-        x = self._ffn_add(x, self.ffn_module1)
-        y = self.norm1(x)
-        x, attn = self.mha_layer.forward_add(y, x, pos_embs, valid_lens, self.causal or src_mask is not None, need_attn)
-        x = self.convolution_module.forward_add(x, x, valid_lens)
-        x = self.norm2(self._ffn_add(x, self.ffn_module2))
+        tr, p, conv, mha = self.training, self.dropout, self.convolution_module, self.mha_layer
+        ln1, pff1 = self.ffn_module1[0], self.ffn_module1[1].ffn
+        ln2, pff2 = self.ffn_module2[0], self.ffn_module2[1].ffn
+        x = _cd(x)
+        y = ops.layer_norm(x, ln1.weight, ln1.bias, 1e-5)
+        h = ops.ffn_core(y, pff1[0].weight, pff1[0].bias, pff1[3].weight, self.slope, p, tr)
+        x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
+        o, attn = mha._context(y, pos_embs, valid_lens, self.causal or src_mask is not None, need_attn)
+        x, y = ops.add_layer_norm(ops.matmul_nt(o, mha.out_proj.weight), mha.out_proj.bias, x, conv.layer_norm)   # + skip ; conv LN
+        c = conv.core(y)
+        x, y = ops.add_layer_norm(c, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)          # + conv ; ffn2 LN
+        h = ops.ffn_core(y, pff2[0].weight, pff2[0].bias, pff2[3].weight, self.slope, p, tr)
+        _, x = ops.add_layer_norm(h, pff2[3].bias, x, self.norm2.norm, 0.5, p, tr)                  # norm2(x + .5*drop(ffn2))
         return x, attn

@@ -440,6 +440,61 @@ def dropout_add(x, bias=None, res=None, alpha=1.0, p=0.0, training=False, valid_
     return _DropoutAddFn.apply(x, bias, res, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows)
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (res + alpha*timemask(dropout(x + bias)), LayerNorm(s)) - the seam between two Conformer sub-blocks in one pass;
+    the backward folds the residual-path gradient, the LayerNorm backward and the dropout/mask backward into one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, gamma, beta, alpha, p, seed, valid_lens, trows, eps):
+        C.require_gpu(x, res, gamma, beta)
+        xc, r = x.contiguous(), res.contiguous()
+        D = xc.shape[-1]
+        M = xc.numel() // D
+        b = None if bias is None else _f32(bias).contiguous()
+        g, bt = _f32(gamma).contiguous(), _f32(beta).contiguous()
+        s_out, y = torch.empty_like(xc), torch.empty_like(xc)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        with prof.region("add_layernorm_fwd"):
+            C.check(C.lib().tsasr_add_layernorm_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(s_out), C.ptr(y), C.ptr(mean), C.ptr(rstd),
+                                                    C.ptr(g), C.ptr(bt), M, D, float(alpha), float(p), seed, C.ptr(seed_state(xc.device)),
+                                                    C.ptr(valid_lens), int(trows), float(eps), C.io_dtype(xc), C.stream_ptr()),
+                    "tsasr_add_layernorm_fwd")
+        ctx.save_for_backward(s_out, g, mean, rstd, valid_lens)
+        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias, gamma, beta)
+        return s_out, y
+
+    @staticmethod
+    def backward(ctx, ds_in, dy):
+        s_out, g, mean, rstd, valid_lens = ctx.saved_tensors
+        alpha, p, seed, trows, bias_param, gamma, beta = ctx.cfg
+        D = s_out.shape[-1]
+        M = s_out.numel() // D
+        if dy is None:                                        # y unused downstream: only the residual tail has a gradient
+            dy = torch.zeros_like(s_out)
+        dy = dy.contiguous()
+        ds_in = None if ds_in is None else ds_in.contiguous()
+        dres, dx = torch.empty_like(s_out), torch.empty_like(s_out)
+        dg = torch.empty(D, dtype=torch.float32, device=s_out.device)
+        dbt = torch.empty_like(dg)
+        db = torch.empty_like(dg) if bias_param is not None else None
+        ws = _ws(C.lib().tsasr_add_layernorm_bwd_workspace_bytes(M, D), s_out.device)
+        with prof.region("add_layernorm_bwd"):
+            C.check(C.lib().tsasr_add_layernorm_bwd(C.ptr(dy), C.ptr(ds_in), C.ptr(s_out), C.ptr(g), C.ptr(mean), C.ptr(rstd), C.ptr(dres),
+                                                    C.ptr(dx), C.ptr(dg), C.ptr(dbt), C.ptr(db), M, D, alpha, p, seed,
+                                                    C.ptr(seed_state(s_out.device)), C.ptr(valid_lens), trows, C.io_dtype(s_out),
+                                                    C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_add_layernorm_bwd")
+        return (dx, (_pgrad(bias_param, db) if bias_param is not None else None), dres, _pgrad(gamma, dg), _pgrad(beta, dbt),
+                None, None, None, None, None, None)
+
+
+def add_layer_norm(x, bias, res, ln, alpha=1.0, p=0.0, training=False, valid_lens=None, eps=1e-5):
+    """Returns (s, LayerNorm(s)) with s = res + alpha * timemask(dropout_p(x + bias)); ``ln`` holds weight/bias [D]."""
+    p = float(p) if training else 0.0
+    trows = x.shape[-2] if valid_lens is not None else 0
+    return _AddLayerNormFn.apply(x, bias, res, ln.weight, ln.bias, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, eps)
+
+
 def mask_time(x, valid_lens):
     """Zero frames t >= valid_lens[b] of x [B,T,D] (ConvolutionModule's masked_fill_, Conformer.py:113-114)."""
     return dropout_add(x, None, None, 1.0, 0.0, False, valid_lens)
