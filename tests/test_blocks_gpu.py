@@ -109,6 +109,33 @@ def test_bias_act_dropout(ops, dtype):
     close(ops.bias_act_dropout(x.to(DEV), None, None, 0.1, False), x.float(), 0)
 
 
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_stream_statistics(ops, p):
+    """The counter-based mask (csrc/common.h drop_hash): keep rate, no correlation between neighbours, between the two halves of
+    one hash word, between rows, or between the streams of consecutive call seeds."""
+    M, N = 2048, 1024
+    ones = torch.ones(M, N, device=DEV, dtype=torch.float32)
+    masks = [(ops._BiasActDropoutFn.apply(ones, None, -1.0, p, seed) != 0).float() for seed in (1000, 1001, 1002 + (1 << 32))]
+    n = M * N
+    sig = (p * (1 - p) / n) ** 0.5
+    for m in masks:
+        assert abs(m.mean().item() - (1 - p)) < 5 * sig + 1e-5     # 1e-5: p is quantised to 1/65536
+        assert abs(m[:, 0::2].mean().item() - m[:, 1::2].mean().item()) < 8 * sig
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std()))
+
+    lim = 6 / n ** 0.5
+    m = masks[0]
+    assert abs(corr(m[:, :-1], m[:, 1:])) < lim          # neighbours (odd pairs share a hash word)
+    assert abs(corr(m[:, 0::2], m[:, 1::2])) < lim * 1.5
+    assert abs(corr(m[:-1], m[1:])) < lim                # rows
+    assert abs(corr(masks[0], masks[1])) < lim           # consecutive seeds
+    assert abs(corr(masks[1], masks[2])) < lim
+    assert abs(corr(masks[0][:, :-2], masks[1][:, 2:])) < lim   # shifted streams
+
+
 def test_dropout_add_and_time_mask(ops):
     B, Tn, N = 3, 17, 64
     g = torch.Generator().manual_seed(2)

@@ -33,13 +33,6 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-__device__ __forceinline__ unsigned at_rng(unsigned long long idx, unsigned long long seed) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (unsigned)((z ^ (z >> 31)) >> 32);
-}
-
 // stage `rows` rows of Dh elements (row r -> src + r*src_stride, or zeros when r is outside [lo,hi)) into lds[rows][AT_LD]
 template <typename T>
 __device__ __forceinline__ void stage_rows(bf16_t *lds, const T *src, long long src_stride, int first_row, int lo, int hi, int rows,
@@ -107,8 +100,9 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
     o_acc[0] = (f32x16){0};
     o_acc[1] = (f32x16){0};
     float m_run = -INFINITY, l_run = 0.f;
-    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
-    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const unsigned thr = drop_thr16(pdrop);
+    const float keep_scale = drop_scale16(thr);
+    const DropKey dkey = drop_key(seed);
 
     int j_end = len;
     if (causal) j_end = min(j_end, i0 + AT_QB);  // keys beyond the last query of the workgroup are never attended
@@ -171,7 +165,7 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
                 if (pdrop > 0.f) {
                     const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
                     const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                    p = (at_rng(idx, seed) >= thr) ? p * keep_scale : 0.f;
+                    p = drop_keep1(idx, dkey, thr) ? p * keep_scale : 0.f;
                 }
                 pb[g >> 3][g & 7] = (bf16_t)p;
             }
@@ -275,8 +269,9 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     const float lse_i = lse[((long long)b * H + h) * Tn + iqc];
     f32x16 dqu[2], dqv[2];
     dqu[0] = dqu[1] = dqv[0] = dqv[1] = (f32x16){0};
-    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
-    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const unsigned thr = drop_thr16(pdrop);
+    const float keep_scale = drop_scale16(thr);
+    const DropKey dkey = drop_key(seed);
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
     int j_end = len;
@@ -325,7 +320,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                 float dp = dpd[g];
                 if (pdrop > 0.f) {
                     const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                    dp = (at_rng(idx, seed) >= thr) ? dp * keep_scale : 0.f;
+                    dp = drop_keep1(idx, dkey, thr) ? dp * keep_scale : 0.f;
                 }
                 ds[g] = q_ok ? p * (dp - delta) * scale : 0.f;
             }
@@ -438,8 +433,9 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
         }
     f32x16 dk[2], dv[2];
     dk[0] = dk[1] = dv[0] = dv[1] = (f32x16){0};
-    const unsigned thr = (unsigned)fminf(pdrop * 4294967296.0f, 4294967295.0f);
-    const float keep_scale = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
+    const unsigned thr = drop_thr16(pdrop);
+    const float keep_scale = drop_scale16(thr);
+    const DropKey dkey = drop_key(seed);
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const bool vec_ok = (Dh % (16 / (int)sizeof(T))) == 0;
 
@@ -526,7 +522,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                 float keep = 1.f;
                 if (pdrop > 0.f) {
                     const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + i) * Tn) + jk;
-                    keep = (at_rng(idx, seed) >= thr) ? keep_scale : 0.f;
+                    keep = drop_keep1(idx, dkey, thr) ? keep_scale : 0.f;
                 }
                 pdb[g >> 3][g & 7] = (bf16_t)(p * keep);
                 dsb[g >> 3][g & 7] = (bf16_t)(p * (dpd[g] * keep - st_lds[64 + 32 * sub + il]) * scale);

@@ -12,17 +12,6 @@
 // backward regenerates it.
 #include "common.h"
 
-// ---------------------------------------------------------------------------------------------------
-// counter-based uniform bits (murmur3 finaliser over index ^ seed stream); keep iff bits >= threshold
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned rng_bits(unsigned long long idx, unsigned long long seed) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (unsigned)((z ^ (z >> 31)) >> 32);
-}
-__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
-
 template <typename T> struct Vec;  // 16-byte vector of T
 template <> struct Vec<float> { static constexpr int N = 4; };
 template <> struct Vec<bf16_t> { static constexpr int N = 8; };
@@ -257,17 +246,19 @@ __global__ __launch_bounds__(256) void bias_act_dropout_fwd_kernel(const T *__re
                                                                    float p, unsigned long long seed, const unsigned long long *__restrict__ seed_dev) {
     constexpr int N = Vec<T>::N;
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float keep_scale = drop_scale16(thr);
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
         float v[N];
         ldv<T, N>(x + i, v);
         const int c = (int)(i % Ncols);
+        const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float t = v[j] + (bias ? bias[c + j] : 0.f);
             if (slope >= 0.f) t = lrelu(t, slope);
-            if (p > 0.f) t = (rng_bits(i + j, seed) >= thr) ? t * keep_scale : 0.f;
+            if (p > 0.f) t = ((km >> j) & 1u) ? t * keep_scale : 0.f;
             v[j] = t;
         }
         stv<T, N>(y + i, v);
@@ -285,8 +276,9 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__re
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float cred[];  // [slots][Ncols] when slots > 1 and part != NULL
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float keep_scale = drop_scale16(thr);
     const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
     const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
@@ -303,10 +295,11 @@ __global__ __launch_bounds__(256) void bias_act_dropout_bwd_kernel(const T *__re
                 float d[N], yv[N];
                 ldv<T, N>(dy + i, d);
                 if (slope >= 0.f) ldv<T, N>(y + i, yv);
+                const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     float g = d[j];
-                    if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                    if (p > 0.f) g = ((km >> j) & 1u) ? g * keep_scale : 0.f;
                     if (slope >= 0.f && yv[j] < 0.f) g *= slope;  // sign(y) = sign(pre-activation) for kept elements
                     d[j] = g;
                     acc[j] += g;
@@ -346,8 +339,9 @@ __global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restric
                                                               const int32_t *__restrict__ valid_lens, int Trows) {
     constexpr int N = Vec<T>::N;
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float keep_scale = drop_scale16(thr);
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
         float v[N], r[N];
         ldv<T, N>(x + i, v);
@@ -355,10 +349,11 @@ __global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restric
         const long long row = i / Ncols;
         const int c = (int)(i - row * Ncols);
         const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+        const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float t = v[j] + (bias ? bias[c + j] : 0.f);
-            if (p > 0.f) t = (rng_bits(i + j, seed) >= thr) ? t * keep_scale : 0.f;
+            if (p > 0.f) t = ((km >> j) & 1u) ? t * keep_scale : 0.f;
             t = live ? t * alpha : 0.f;
             v[j] = (res ? r[j] : 0.f) + t;
         }
@@ -375,8 +370,9 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float cred[];
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float keep_scale = drop_scale16(thr);
     const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
     const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
@@ -393,10 +389,11 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
                 const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
                 float d[N];
                 ldv<T, N>(dout + i, d);
+                const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     float g = live ? d[j] * alpha : 0.f;
-                    if (p > 0.f) g = (rng_bits(i + j, seed) >= thr) ? g * keep_scale : 0.f;
+                    if (p > 0.f) g = ((km >> j) & 1u) ? g * keep_scale : 0.f;
                     d[j] = g;
                     acc[j] += g;
                 }
@@ -445,8 +442,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     const int l = threadIdx.x & 63;
     if (row >= M) return;
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
     const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
     float v[ITERS][N];
     float sum = 0.f;
@@ -458,10 +456,11 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
             ldv<T, N>(x + row * D + c, xv);
             ldv<T, N>(res + row * D + c, rv);
             const unsigned long long idx = (unsigned long long)row * D + c;
+            const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float t = xv[j] + (bias ? bias[c + j] : 0.f);
-                if (p > 0.f) t = (rng_bits(idx + j, seed) >= thr) ? t * ks : 0.f;
+                if (p > 0.f) t = ((km >> j) & 1u) ? t * ks : 0.f;
                 t = live ? t * alpha : 0.f;
                 t += rv[j];
                 if (sizeof(T) == 2) t = (float)(bf16_t)t;   // statistics of the STORED (rounded) row, as a separate LN would see
@@ -507,8 +506,9 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [4 waves][3][D]
     if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_threshold(p);
-    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     float ag[ITERS][N], abt[ITERS][N], abx[ITERS][N];
 #pragma unroll
@@ -554,12 +554,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
                 float ds[N], dxv[N], dov[N];
                 if (dout) ldv<T, N>(dout + row * D + c, dov);
                 const unsigned long long idx = (unsigned long long)row * D + c;
+                const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float d = rs * (gd[it][j] - m1 - xh[it][j] * m2) + (dout ? dov[j] : 0.f);
                     ds[j] = d;
                     float g = live ? d * alpha : 0.f;
-                    if (p > 0.f) g = (rng_bits(idx + j, seed) >= thr) ? g * ks : 0.f;
+                    if (p > 0.f) g = ((km >> j) & 1u) ? g * ks : 0.f;
                     dxv[j] = g;
                     abx[it][j] += g;
                 }

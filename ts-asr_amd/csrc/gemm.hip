@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 // Fused epilogues of the bf16-output GEMM (mode 0 = plain store):
 //   1: C = dropout_p(LeakyReLU(acc + bias[n]))                       - Linear + activation + Dropout of the macaron FFN
 //   2: C = acc * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]) ; colsum -> dbias - the same chain's backward applied to the dgrad GEMM
-// The dropout mask is the counter-based one of elementwise.hip (index m*N + n, seed + *seed_dev).
+// The dropout mask is the counter-based one of common.h (index m*N + n, seed + *seed_dev), as in elementwise.hip.
 struct EpiArgs {
     int mode;
     const float *bias;
@@ -36,13 +36,6 @@ struct EpiArgs {
     const unsigned long long *seed_dev;
     float *colpart;   // [gridDim.y][N] partial column sums (mode 2)
 };
-
-__device__ __forceinline__ unsigned gemm_rng_bits(unsigned long long idx, unsigned long long seed) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (unsigned)((z ^ (z >> 31)) >> 32);
-}
 
 template <int BM, int BN, bool AT, bool BT>
 struct GemmSmem {
@@ -147,23 +140,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
         __syncthreads();
         unsigned long long seed = ep.seed;
         if (ep.seed_dev) seed += *ep.seed_dev;
-        const unsigned thr = (unsigned)fminf(ep.p * 4294967296.0f, 4294967295.0f);
-        const float ks = ep.p > 0.f ? 1.f / (1.f - ep.p) : 1.f;
+        const unsigned thr = drop_thr16(ep.p);
+        const float ks = drop_scale16(thr);
+        const DropKey dk = drop_key(seed);
         bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
         for (int c = threadIdx.x; c < BM * (BN / 8); c += 256) {
             const int rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
             const int m = m0 + rr, n = n0 + cc;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tile[rr * LDT + cc + e];
+            const float4 v_lo = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc), v_hi = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc + 4);
+            float v[8] = {v_lo.x, v_lo.y, v_lo.z, v_lo.w, v_hi.x, v_hi.y, v_hi.z, v_hi.w};
             if (m < M && n + 8 <= N) {
-                const unsigned long long idx = (unsigned long long)m * N + n;
+                const unsigned long long idx = (unsigned long long)m * N + n;   // even: n % 8 == 0 and N % 8 == 0 on this path
+                const unsigned km = ep.p > 0.f ? drop_keep_mask<8>(idx, dk, thr) : ~0u;
                 if (ep.mode == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = v[e] + (ep.bias ? ep.bias[n + e] : 0.f);
                         if (ep.slope >= 0.f) t = lrelu(t, ep.slope);
-                        if (ep.p > 0.f) t = (gemm_rng_bits(idx + e, seed) >= thr) ? t * ks : 0.f;
+                        if (ep.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
                         v[e] = t;
                     }
                 } else {
@@ -172,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = v[e];
-                        if (ep.p > 0.f) t = (gemm_rng_bits(idx + e, seed) >= thr) ? t * ks : 0.f;
+                        if (ep.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
                         if (ep.slope >= 0.f && yv[e] < 0.f) t *= ep.slope;
                         v[e] = t;
                         tile[rr * LDT + cc + e] = t;
