@@ -43,3 +43,19 @@ for (M, N, K, ta, tb, f32) in SHAPES:
     by = 2.0 * (M * K + N * K) + (4.0 if f32 else 2.0) * M * N
     roof = max(by / 8e6, fl / 2.5e9)   # us: HBM 8 TB/s vs dense bf16 MFMA 2.5 PFLOP/s
     print(f"roof {roof:5.1f} us | M={M:6d} N={N:5d} K={K:6d} tA={ta} tB={tb} f32={f32}: ring {best['ring']:6.1f} us {fl/best['ring']/1e6:6.1f} TF | reg {best['reg']:6.1f} us {fl/best['reg']/1e6:6.1f} TF | lib {best['lib']:6.1f} us {fl/best['lib']/1e6:6.1f} TF")
+
+# fused epilogues at the FFN shapes (hot operands, graph-replayed): mode 1 = bias + LeakyReLU + dropout, mode 2 = mask/act' + colsum
+M, F1, D = 8000, 2048, 256
+x = torch.randn(M, D, device=DEV).to(torch.bfloat16); w1 = torch.randn(F1, D, device=DEV).to(torch.bfloat16)
+b1 = torch.randn(F1, device=DEV); h = torch.randn(M, F1, device=DEV).to(torch.bfloat16)
+do = torch.randn(M, D, device=DEV).to(torch.bfloat16); w2 = torch.randn(D, F1, device=DEV).to(torch.bfloat16)
+dbias = torch.zeros(F1, device=DEV)
+for name, fn in [
+    ("fwd plain   N=2048 K=256", lambda: ops.gemm_bf16(x, w1, M, F1, D, D, D, 0, 0)),
+    ("fwd fused<1> p=0.1      ", lambda: ops.gemm_bf16_fused(x, w1, M, F1, D, D, D, 0, 0, 1, bias=b1, slope=0.01, p=0.1, seed=5)),
+    ("fwd fused<1> p=0        ", lambda: ops.gemm_bf16_fused(x, w1, M, F1, D, D, D, 0, 0, 1, bias=b1, slope=0.01, p=0.0, seed=5)),
+    ("dgrad plain N=2048 K=256", lambda: ops.gemm_bf16(do, w2, M, F1, D, D, F1, 0, 1)),
+    ("dgrad fused<2> p=0.1    ", lambda: ops.gemm_bf16_fused(do, w2, M, F1, D, D, F1, 0, 1, 2, y=h, slope=0.01, p=0.1, seed=5, dbias=dbias)),
+    ("dgrad fused<2> p=0      ", lambda: ops.gemm_bf16_fused(do, w2, M, F1, D, D, F1, 0, 1, 2, y=h, slope=0.01, p=0.0, seed=5, dbias=dbias)),
+]:
+    print(f"{name}: {timeit(fn):6.1f} us")

@@ -129,7 +129,26 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
     if (OUT_MODE == 0 && ep.mode != 0) {   // fused elementwise epilogue: fp32 tile, one rounding at the end
         const int r = lane & 31, hh = lane >> 5;
         constexpr int LDT = BN + 4;
+        constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+        constexpr int NIT = BM * CPR / 256;         // chunks per thread; 256 % CPR == 0, so a thread keeps ONE column group
         float *tile = reinterpret_cast<float *>(smem);
+        bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
+        const int cc = (threadIdx.x % CPR) * 8, rr0 = threadIdx.x / CPR, n = n0 + cc;
+        const bool n_ok = n + 8 <= N;
+        // every global operand of the epilogue is requested BEFORE the accumulators go through LDS: a load issued inside the
+        // store loop put one L2 round trip on each of its NIT iterations (+26 us on the 8000x2048x256 FFN GEMM)
+        float bias8[8];
+        uint4 yraw[NIT];
+        if (ep.mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = (ep.bias && n_ok) ? ep.bias[n + e] : 0.f;
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int m = m0 + rr0 + it * (256 / CPR);
+                yraw[it] = (n_ok && m < M) ? *reinterpret_cast<const uint4 *>(ep.y + (long long)m * ep.ldy + n) : make_uint4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -143,46 +162,50 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
         const unsigned thr = drop_thr16(ep.p);
         const float ks = drop_scale16(thr);
         const DropKey dk = drop_key(seed);
-        bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
-        for (int c = threadIdx.x; c < BM * (BN / 8); c += 256) {
-            const int rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
-            const int m = m0 + rr, n = n0 + cc;
-            const float4 v_lo = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc), v_hi = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc + 4);
-            float v[8] = {v_lo.x, v_lo.y, v_lo.z, v_lo.w, v_hi.x, v_hi.y, v_hi.z, v_hi.w};
-            if (m < M && n + 8 <= N) {
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = rr0 + it * (256 / CPR);
+            const int m = m0 + rr;
+            if (m < M && n_ok) {
+                const float4 v_lo = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc), v_hi = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc + 4);
+                float v[8] = {v_lo.x, v_lo.y, v_lo.z, v_lo.w, v_hi.x, v_hi.y, v_hi.z, v_hi.w};
                 const unsigned long long idx = (unsigned long long)m * N + n;   // even: n % 8 == 0 and N % 8 == 0 on this path
                 const unsigned km = ep.p > 0.f ? drop_keep_mask<8>(idx, dk, thr) : ~0u;
                 if (ep.mode == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float t = v[e] + (ep.bias ? ep.bias[n + e] : 0.f);
+                        float t = v[e] + bias8[e];
                         if (ep.slope >= 0.f) t = lrelu(t, ep.slope);
                         if (ep.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
                         v[e] = t;
                     }
                 } else {
-                    float yv[8];
-                    ld8(ep.y + (long long)m * ep.ldy + n, yv);
+                    const unsigned yw[4] = {yraw[it].x, yraw[it].y, yraw[it].z, yraw[it].w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
+                        const bool y_neg = (yw[e >> 1] >> ((e & 1) ? 31 : 15)) & 1u;   // sign bit of the bf16 activation
+                        const bool y_nz = ((yw[e >> 1] >> ((e & 1) ? 16 : 0)) & 0x7fffu) != 0;
                         float t = v[e];
                         if (ep.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
-                        if (ep.slope >= 0.f && yv[e] < 0.f) t *= ep.slope;
+                        if (ep.slope >= 0.f && y_neg && y_nz) t *= ep.slope;
                         v[e] = t;
-                        tile[rr * LDT + cc + e] = t;
+                        csum[e] += t;
                     }
                 }
                 st8(Cb + (long long)m * ldc + n, v);
-            } else if (ep.mode == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) tile[rr * LDT + cc + e] = 0.f;   // rows/cols outside the matrix do not count
             }
         }
-        if (ep.mode == 2 && ep.colpart) {
+        if (ep.mode == 2 && ep.colpart) {   // column sums of this tile (dbias partials): per-thread partials -> LDS -> one row of colpart
+            __syncthreads();
+            float *red = tile;               // [256 / CPR][BN + 4]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rr0 * LDT + cc + e] = csum[e];
             __syncthreads();
             for (int t = threadIdx.x; t < BN; t += 256) {
                 float sum = 0.f;
-                for (int rr = 0; rr < BM; ++rr) sum += tile[rr * LDT + t];
+#pragma unroll 4
+                for (int q = 0; q < 256 / CPR; ++q) sum += red[q * LDT + t];
                 if (n0 + t < N) ep.colpart[(long long)tile_y * N + n0 + t] = sum;
             }
         }
