@@ -246,6 +246,15 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
                             unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
                             int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Whole-sequence LSTM recurrences (all U steps of tsasr_lstm_step_fwd / _bwd). bf16, H in {256, 512}, B <= 256: one persistent
+ * launch per direction (workgroups exchange h_t / dG_t through write-through stores and an arrival counter); otherwise a loop of
+ * the per-step kernels. Replaces the time loop inside torch.nn.LSTM (speechbrain/nnet/RNN.py:244-278). */
+size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H);
+int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, int H, int io_dtype, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, int H,
+                       int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -446,10 +446,13 @@ def test_linear_fn_grad_sink(ops):
         ops.set_grad_sink(None)
 
 
-def test_lstm_hip_path_vs_oracle(ops):
-    """bf16 predictor LSTM (HIP cell kernels + HIP GEMMs) vs the oracle's explicit recurrence (oracle/tsasr_ref.lstm), fwd + bwd."""
+@pytest.mark.parametrize("B,U,H", [(8, 21, 128), (8, 21, 256), (40, 9, 256), (32, 121, 512)])
+def test_lstm_hip_path_vs_oracle(ops, B, U, H):
+    """bf16 predictor LSTM vs the oracle's explicit recurrence (oracle/tsasr_ref.lstm), fwd + bwd. H = 128 runs the per-step
+    kernels, H in {256, 512} the persistent whole-sequence kernels (one and two 32-row batch groups, ragged last group; the
+    last case is the predictor's shape in BASELINE configs[1])."""
     from oracle import tsasr_ref as R
-    B, U, I, H = 8, 21, 28, 128
+    I = 28
     g = torch.Generator().manual_seed(9)
     rnn = torch.nn.LSTM(I, H, batch_first=True).to(DEV)
     tok = torch.randint(0, 29, (B, U), generator=g)

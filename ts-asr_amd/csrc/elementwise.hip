@@ -591,9 +591,18 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ 
                                                       float *__restrict__ o2, int nparts, int D) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = blockIdx.x * 16 + cl, W = 3 * D;
-    float s0 = 0.f;
-    if (col < W)
-        for (int n = slice; n < nparts; n += 16) s0 += part[(size_t)n * W + col];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < W) {
+        int n = slice;
+        for (; n + 48 < nparts; n += 64) {
+            s0 += part[(size_t)n * W + col];
+            s1 += part[(size_t)(n + 16) * W + col];
+            s2 += part[(size_t)(n + 32) * W + col];
+            s3 += part[(size_t)(n + 48) * W + col];
+        }
+        for (; n < nparts; n += 16) s0 += part[(size_t)n * W + col];
+    }
+    s0 += s1 + s2 + s3;
     red[slice][cl] = s0;
     __syncthreads();
     if (slice == 0 && col < W) {
@@ -815,7 +824,7 @@ int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, v
 }
 
 size_t tsasr_add_layernorm_bwd_workspace_bytes(long long M, int D) {
-    const int rpw = pick_rows_per_wg(M, 16);
+    const int rpw = pick_rows_per_wg(M, 32);
     return align_up((size_t)((M + rpw - 1) / rpw) * 3 * D * sizeof(float), 256);
 }
 
@@ -828,7 +837,7 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
     TSASR_CHECK_ARG(dy && s && gamma && mean && rstd && dres && dx && workspace, "tsasr_add_layernorm_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_add_layernorm_bwd: bad shape");
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_add_layernorm_bwd_workspace_bytes(M, D), "tsasr_add_layernorm_bwd: workspace too small");
-    const int rpw = pick_rows_per_wg(M, 16);
+    const int rpw = pick_rows_per_wg(M, 32);
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;

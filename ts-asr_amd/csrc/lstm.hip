@@ -168,6 +168,223 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
     }
 }
 
+// =====================================================================================================================
+// Whole-sequence persistent kernels: ONE launch per direction instead of one per time step.
+//   The per-step launches above cost 11-12 us each (121 steps x 2 directions = 2.9 ms of a 31 ms training step) although a
+//   step is 67 MFLOP: every launch re-reads its W_hh slice from L2 and pays a kernel boundary. Here a workgroup owns 32 hidden
+//   units for the whole sequence, keeps its slice of W_hh (forward: [4 x 32, H]; backward: W_hh^T [32, 4H], K split over the
+//   four waves) in REGISTERS as MFMA A-fragments, and the workgroups of one 32-row batch group exchange h_t (forward) / the gate
+//   gradients dG_t (backward) once per step through global memory:
+//     producer: payload tile -> LDS -> 16-byte write-through (sc1) stores, each wave-instruction writing 1 KiB of whole
+//               lines -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane's agent-scope atomic add;
+//     consumer: ONE lane polls the counter with sc1 loads (s_sleep between polls, bounded) -> workgroup barrier -> every
+//               load of the payload is an sc1 16-byte buffer load straight to registers (MFMA B-fragments).
+//   (gfx950's eight XCD-private L2s are not coherent with each other: plain loads of another workgroup's stores are stale.)
+//   Each step's payload has its own location (no reuse inside a launch); the counter is zeroed by a memset node ahead of the
+//   launch. Grid = (H/32, ceil(B/32)) <= the CU count, 1 workgroup per CU (96 KB of dynamic LDS keeps a second one away), so
+//   every workgroup is resident and the per-step waits cannot deadlock; a poll that never matches gives up after ~1 s,
+//   raises the error word and poisons the output with NaN (the step's finite-check then rejects the update).
+// =====================================================================================================================
+#define LQ_UN 32
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool lq_wait(unsigned *ctr, unsigned target, unsigned *err) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict__ gates, float *__restrict__ c, bf16_t *__restrict__ h,
+                                                              const bf16_t *__restrict__ whh /*[4H,H]*/, bf16_t *xh /*[G][U][H/32][32][32]*/,
+                                                              unsigned *sync, int B, int U) {
+    constexpr int KS = H / 16, NWG = H / LQ_UN;
+    __shared__ __attribute__((aligned(16))) float pre[32][LQ_UN * 4 + 4];   // [batch][unit*4 + gate]
+    __shared__ __attribute__((aligned(16))) bf16_t hs[32][LQ_UN];            // this step's h tile, laid out as it is published
+    __shared__ int ok_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * 32;
+    unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
+    bf16_t *xh_g = xh + (size_t)bg * U * H * 32;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xh_g, 0, U * H * 32 * 2, 0x00020000);
+    // A operand (W_hh rows): MFMA row r of this wave = gate (r & 3) of unit u0 + 8*wave + (r >> 2) -> the four gates of a unit
+    // land in four consecutive accumulator registers of ONE lane
+    bf16x8 af[KS];
+    {
+        const bf16_t *wrow = whh + ((long long)(r & 3) * H + u0 + 8 * wave + (r >> 2)) * H;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s + 8 * hh);
+    }
+    float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+    bool failed = false;
+#pragma unroll 1
+    for (int t = 0; t < U; ++t) {
+        float gx[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // x-part pre-activations of this thread's four (batch, unit) pairs: in flight across the wait
+            const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
+            const float *gp = gates + ((long long)min(b0 + bl, B - 1) * U + t) * 4 * H + u0 + ul;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gx[j][g] = gp[g * H];
+        }
+        f32x16 acc = {0};
+        if (t > 0) {
+            if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * t), err) ? 1 : 0;
+            __syncthreads();
+            if (!ok_flag) { failed = true; break; }
+            const int base = (t - 1) * NWG * 1024 + r * 32 + 8 * hh;   // elements; + (s >> 1) * 1024 + (s & 1) * 16
+            u32x4 raw[KS];   // all of h_{t-1} for this lane's batch row requested at once: ONE memory round trip per step
+#pragma unroll
+            for (int s = 0; s < KS; ++s) raw[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (base + (s >> 1) * 1024 + (s & 1) * 16) * 2, 0, 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], __builtin_bit_cast(bf16x8, raw[s]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = b0 + bl;
+            const float4 pr = *reinterpret_cast<const float4 *>(&pre[bl][ul * 4]);
+            const float gi = sigm(gx[j][0] + pr.x), gf = sigm(gx[j][1] + pr.y), gg = tanh_fast(gx[j][2] + pr.z), go = sigm(gx[j][3] + pr.w);
+            const float cn = gf * cprev[j] + gi * gg;
+            cprev[j] = cn;
+            const float hv = go * tanh_fast(cn);
+            if (b < B) {
+                float *gp = gates + ((long long)b * U + t) * 4 * H + u0 + ul;
+                gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+                c[((long long)b * U + t) * H + u0 + ul] = cn;
+            }
+            hs[bl][ul] = (bf16_t)(b < B ? hv : 0.f);
+        }
+        __syncthreads();
+        if (wave < 2) {   // 2 KB tile: two wave-instructions of 1 KiB (whole 128-byte lines), write-through
+            const int ch = wave * 64 + lane, bl = ch >> 2, part = ch & 3;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(&hs[bl][part * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * 1024 + ch * 8) * 2, 0, 16);
+            if (b0 + bl < B) *reinterpret_cast<u32x4 *>(h + ((long long)(b0 + bl) * U + t) * H + u0 + part * 8) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (failed && tid == 0) h[((long long)min(b0, B - 1) * U + U - 1) * H + u0] = (bf16_t)__builtin_nanf("");
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c,
+                                                              const bf16_t *__restrict__ dout, bf16_t *__restrict__ dgates,
+                                                              const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][32][128]*/,
+                                                              unsigned *sync, int B, int U) {
+    constexpr int K4 = 4 * H, KSW = K4 / 16 / 4, NWG = H / LQ_UN;   // KSW k-steps per wave
+    __shared__ float red[4][32][33];                                  // [wave][batch][unit]
+    __shared__ __attribute__((aligned(16))) bf16_t dgt[32][4 * LQ_UN];   // [batch][gate*32 + unit]: the published tile
+    __shared__ int ok_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * 32;
+    unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
+    bf16_t *xg_g = xg + (size_t)bg * U * K4 * 32;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xg_g, 0, U * K4 * 32 * 2, 0x00020000);
+    // A operand: row r = unit u0 + r of W_hh^T; the reduction index runs over the PUBLISHED order c' = wg'*128 + gate*32 + unit'
+    bf16x8 af[KSW];
+    {
+        const bf16_t *wrow = whhT + (long long)(u0 + r) * K4;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const int cp = 16 * (KSW * wave + i) + 8 * hh;
+            af[i] = *reinterpret_cast<const bf16x8 *>(wrow + ((cp & 127) >> 5) * H + (cp >> 7) * 32 + (cp & 31));
+        }
+    }
+    float dcar[4] = {0.f, 0.f, 0.f, 0.f};
+    bool failed = false;
+#pragma unroll 1
+    for (int t = U - 1; t >= 0; --t) {
+        float gv[4][4], cn[4], cpv[4], dov[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = min(b0 + bl, B - 1);
+            const float *gp = gates + ((long long)b * U + t) * K4 + u0 + ul;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[j][g] = gp[g * H];
+            cn[j] = c[((long long)b * U + t) * H + u0 + ul];
+            cpv[j] = t > 0 ? c[((long long)b * U + t - 1) * H + u0 + ul] : 0.f;
+            dov[j] = (float)dout[((long long)b * U + t) * H + u0 + ul];
+        }
+        f32x16 acc = {0};
+        const bool last = (t == U - 1);
+        if (!last) {
+            if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * (U - 1 - t)), err) ? 1 : 0;
+            __syncthreads();
+            if (!ok_flag) { failed = true; break; }
+            u32x4 raw[KSW];
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) {
+                const int cp = 16 * (KSW * wave + i) + 8 * hh;
+                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((t + 1) * NWG + (cp >> 7)) * 32 + r) * 128 + (cp & 127)) * 2, 0, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) red[wave][r][(g & 3) + 8 * (g >> 2) + 4 * hh] = acc[g];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
+            const float dh_rec = red[0][bl][ul] + red[1][bl][ul] + red[2][bl][ul] + red[3][bl][ul];
+            const float gi = gv[j][0], gf = gv[j][1], gg = gv[j][2], go = gv[j][3];
+            const float tc = tanh_fast(cn[j]);
+            const float dh = dov[j] + (last ? 0.f : dh_rec);
+            const float dc = dh * go * (1.f - tc * tc) + dcar[j];
+            const bool live = b0 + bl < B;
+            dgt[bl][ul] = (bf16_t)(live ? dc * gg * gi * (1.f - gi) : 0.f);
+            dgt[bl][LQ_UN + ul] = (bf16_t)(live ? dc * cpv[j] * gf * (1.f - gf) : 0.f);
+            dgt[bl][2 * LQ_UN + ul] = (bf16_t)(live ? dc * gi * (1.f - gg * gg) : 0.f);
+            dgt[bl][3 * LQ_UN + ul] = (bf16_t)(live ? dh * tc * go * (1.f - go) : 0.f);
+            dcar[j] = dc * gf;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {   // 8 KB tile: eight wave-instructions of 1 KiB, write-through
+            const int ch = tid + 256 * k, bl = ch >> 4, part = ch & 15;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(&dgt[bl][part * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * 4096 + ch * 8) * 2, 0, 16);
+            if (b0 + bl < B) *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (failed && tid == 0) dgates[((long long)min(b0, B - 1) * U) * K4 + u0] = (bf16_t)__builtin_nanf("");
+}
+
+template <int H>
+static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
+    auto kern = lstm_seq_fwd_kernel<H>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    (void)hipMemsetAsync(ws, 0, 256, st);
+    kern<<<dim3(H / LQ_UN, cdiv(B, 32)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+}
+template <int H>
+static void launch_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, char *ws, hipStream_t st) {
+    auto kern = lstm_seq_bwd_kernel<H>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    (void)hipMemsetAsync(ws, 0, 256, st);
+    kern<<<dim3(H / LQ_UN, cdiv(B, 32)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+}
+
+
 extern "C" {
 
 int tsasr_lstm_cell_fwd(float *gates, float *c, void *h, int B, int U, int H, int t, int io_dtype, void *stream) {
@@ -213,6 +430,55 @@ int tsasr_lstm_step_bwd(const float *gates, const float *c, const void *dout, vo
     else if (io_dtype == TSASR_F32) lstm_step_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(gates, c, (const float *)dout, (float *)dgates, (const bf16_t *)whhT, dc_io, B, U, H, t);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     TSASR_CHECK_LAUNCH("tsasr_lstm_step_bwd");
+    return 0;
+}
+
+size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H) {
+    const size_t G = (size_t)cdiv(B, 32);
+    return 256 + align_up(G * U * 32 * 4 * (size_t)H * sizeof(bf16_t), 256) + align_up((size_t)B * H * sizeof(float), 256);
+}
+
+static bool seq_persistent_ok(int B, int H, int io_dtype) { return io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, 32) <= 8; }
+
+/* The whole forward recurrence (t = 0 .. U-1) of tsasr_lstm_step_fwd. bf16 with H in {256, 512} and B <= 256: ONE persistent launch
+ * (csrc/lstm.hip, "Whole-sequence persistent kernels"); otherwise the per-step kernels in a loop. workspace: tsasr_lstm_seq_workspace_bytes. */
+int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, int H, int io_dtype, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(gates && c && h && whh && B > 0 && U > 0 && H > 0 && H % 16 == 0, "tsasr_lstm_seq_fwd: bad arguments (H=%d)", H);
+    hipStream_t st = (hipStream_t)stream;
+    if (seq_persistent_ok(B, H, io_dtype)) {
+        TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_lstm_seq_workspace_bytes(B, U, H), "tsasr_lstm_seq_fwd: workspace too small");
+        if (H == 512) launch_seq_fwd<512>(gates, c, h, whh, B, U, (char *)workspace, st);
+        else launch_seq_fwd<256>(gates, c, h, whh, B, U, (char *)workspace, st);
+        TSASR_CHECK_LAUNCH("tsasr_lstm_seq_fwd");
+        return 0;
+    }
+    for (int t = 0; t < U; ++t) {
+        const int rc = tsasr_lstm_step_fwd(gates, c, h, whh, B, U, H, t, io_dtype, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* The whole backward recurrence (t = U-1 .. 0) of tsasr_lstm_step_bwd; same dispatch and workspace as tsasr_lstm_seq_fwd. */
+int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, int H,
+                       int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(gates && c && dout && dgates && whhT && B > 0 && U > 0 && H > 0 && H % 16 == 0, "tsasr_lstm_seq_bwd: bad arguments");
+    TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_lstm_seq_workspace_bytes(B, U, H), "tsasr_lstm_seq_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (seq_persistent_ok(B, H, io_dtype)) {
+        if (H == 512) launch_seq_bwd<512>(gates, c, dout, dgates, whhT, B, U, (char *)workspace, st);
+        else launch_seq_bwd<256>(gates, c, dout, dgates, whhT, B, U, (char *)workspace, st);
+        TSASR_CHECK_LAUNCH("tsasr_lstm_seq_bwd");
+        return 0;
+    }
+    const size_t G = (size_t)cdiv(B, 32);
+    float *dc_io = (float *)((char *)workspace + 256 + align_up(G * U * 32 * 4 * (size_t)H * sizeof(bf16_t), 256));
+    (void)hipMemsetAsync(dc_io, 0, (size_t)B * H * sizeof(float), st);
+    for (int t = U - 1; t >= 0; --t) {
+        const int rc = tsasr_lstm_step_bwd(gates, c, dout, dgates, whhT, dc_io, B, U, H, t, io_dtype, stream);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -263,9 +263,10 @@ class _LstmFn(torch.autograd.Function):
         h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
         whh16 = _bf16_weight(w_hh).contiguous()
         lib, st = C.lib(), C.stream_ptr()
-        with prof.region("lstm_fwd"):
-            for t in range(U):   # one fused launch per step: gates[:, t] += h[:, t-1] . W_hh^T, then the cell update
-                C.check(lib.tsasr_lstm_step_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh16), B, U, H, t, C.BF16, st), "tsasr_lstm_step_fwd")
+        ws = _ws(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dev)
+        with prof.region("lstm_fwd"):   # the whole recurrence: one persistent launch (H in {256, 512}), else one fused launch per step
+            C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh16), B, U, H, C.BF16, C.ptr(ws), ws.numel(), st),
+                    "tsasr_lstm_seq_fwd")
         ctx.save_for_backward(x, gates, c, h, whh16)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
         return h
@@ -279,13 +280,12 @@ class _LstmFn(torch.autograd.Function):
         dev = x.device
         dout = dout.contiguous()
         dgates = torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=dev)
-        dc = torch.zeros(B, H, dtype=torch.float32, device=dev)
         whhT = whh16.t().contiguous()
         lib, st = C.lib(), C.stream_ptr()
-        with prof.region("lstm_bwd"):
-            for t in range(U - 1, -1, -1):   # one fused launch per step: dh = dout[:, t] + dgates[:, t+1] . W_hh, cell backward
-                C.check(lib.tsasr_lstm_step_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), C.ptr(dc), B, U, H, t,
-                                                C.BF16, st), "tsasr_lstm_step_bwd")
+        ws = _ws(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dev)
+        with prof.region("lstm_bwd"):   # dh = dout[:, t] + dgates[:, t+1] . W_hh, cell backward, t = U-1 .. 0 in one launch
+            C.check(lib.tsasr_lstm_seq_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), B, U, H, C.BF16,
+                                           C.ptr(ws), ws.numel(), st), "tsasr_lstm_seq_bwd")
         dg2 = dgates.view(B * U, 4 * H)
         h_prev = torch.zeros_like(h)
         h_prev[:, 1:] = h[:, :-1]
