@@ -120,7 +120,7 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
  * Replaces SB/lobes/models/transformer/Conformer.py:101-115 between the two pointwise GEMMs: bottleneck bias + nn.GLU
  * (:76-82), depthwise nn.Conv1d(D,D,K,groups=D) 'same' or causal pad+chomp (:68-71,84-93,108-110), after_conv LayerNorm +
  * activation (:95-97).  y2 [B,T,2D] io_dtype = bottleneck GEMM output without bias; b2 [2D] or NULL; conv_w [D,K] (the
- * [D,1,K] parameter); conv_b, gamma, beta [D]. D % 8 == 0, D <= 256, K in {31,15,7,3}. c_save [B,T,D], mean/rstd [B*T] are
+ * [D,1,K] parameter); conv_b, gamma, beta [D]. D % 8 == 0, D <= 2048, K in {31,15,7,3}. c_save [B,T,D], mean/rstd [B*T] are
  * written by fwd and read by bwd. bwd: dparams fp32 = [dgamma D | dbeta D | dconv_b D | db2 2D | dconv_w D*K], overwritten.
  * ------------------------------------------------------------------------------------------ */
 int tsasr_convmod_fwd(const void *y2, const float *b2, const float *conv_w, const float *conv_b, const float *gamma,
@@ -191,7 +191,8 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
  *   out_dtype TSASR_BF16 | TSASR_F32; accumulate (fp32 only): C += result, used to add weight gradients straight into the
  *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
  * ------------------------------------------------------------------------------------------ */
-void tsasr_gemm_set_ring(int on); /* 1 (default): LDS-DMA ring main loop when K % 64 == 0; 0: register-staged loop (A/B tests) */
+void tsasr_gemm_set_ring(int on);                 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: whenever K % 64 == 0; 0: register-staged loop (A/B tests) */
+void tsasr_gemm_set_plan(int tile, int splits);   /* A/B tests only: force macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64, -1 = automatic) and split-K */
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                     int transA, int transB, int out_dtype, int accumulate, void *workspace, size_t workspace_bytes, void *stream);

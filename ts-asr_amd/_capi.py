@@ -62,6 +62,7 @@ _PROTOS = {
     "tsasr_accumulate_many": (c_int, [c_void_p, c_int, c_void_p]),
     "tsasr_clip_adamw_workspace_bytes": (c_size_t, []),
     "tsasr_clip_adamw_step": (c_int, [c_void_p] * 7 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_gemm_set_plan": (None, [c_int, c_int]),
     "tsasr_gemm_set_ring": (None, [c_int]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_gemm_bf16_fused_workspace_bytes": (c_size_t, [c_int] * 2),

@@ -3,208 +3,176 @@
 // Replaces the middle of ConvolutionModule.forward (vendor/speechbrain/speechbrain/lobes/models/transformer/Conformer.py:
 // 101-115): `bottleneck` bias + nn.GLU(dim=1) (:76-82), depthwise nn.Conv1d(D, D, K, groups=D) with 'same' padding or
 // causal pad+chomp (:68-71,84-93,108-110), `after_conv` LayerNorm + activation (:95-97). The two pointwise GEMMs around
-// it stay library GEMMs. In the reference this is two layout transposes, a GLU kernel, MIOpen's grouped conv
+// it are csrc/gemm.hip. In the reference this is two layout transposes, a GLU kernel, MIOpen's grouped conv
 // (im2col + one tiny GEMM per channel group on ROCm: 384 launches per step), LayerNorm and LeakyReLU.
 //
-// Layout: channels-last [B, T, 2D] in, [B, T, D] out - time is the row index, so a workgroup owning TT consecutive
-// frames of one utterance reads (TT + K - 1) full rows (coalesced 16-byte accesses along the channel axis; the K-1
-// halo rows are the only re-read), keeps the GLU tile in LDS (fp32, row stride D: lane = channel -> conflict-free),
-// runs the K taps out of LDS with the filter in registers, and normalises each frame with one wave (LayerNorm needs all
-// channels of a frame, which is why channels are not split across workgroups).
-// Backward recomputes GLU from the saved GEMM output, reads the saved pre-norm conv output c (io dtype) and the row
-// statistics, and produces dy2 plus per-workgroup partial rows of every parameter gradient (reduced by colsum).
+// Layout: channels-last [B, T, 2D] in, [B, T, D] out - time is the row index. Two launches per direction:
+//   forward : (1) glu_dwconv_fwd   y2 -> c = dwconv(GLU(y2 + b2)) + conv_b   (io dtype; saved for the backward)
+//             (2) tsasr_layernorm_fwd(c) with the fused LeakyReLU -> z, mean, rstd            (csrc/elementwise.hip)
+//   backward: (1) tsasr_layernorm_bwd(dz; c) -> dc, dgamma, dbeta
+//             (2) glu_dwconv_bwd   dc, y2 -> dy2 and per-workgroup partial rows of dconv_b, db2, dconv_w (reduced by colsum)
+// The depthwise stage is independent per channel, so a workgroup takes 64 frames x 64 channels (+K-1 halo frames): the GLU
+// tile (and in the backward the dc tile) sit in LDS as fp32 (24 / 48 KB -> 3-6 workgroups per CU), thread = (channel, group
+// of 16 frames), filter taps in registers. An earlier version ran all of it in ONE kernel that owned every channel of 32
+// frames (LayerNorm needs whole rows): 135 KB of LDS = one 4-wave workgroup per CU, every phase latency-bound (s_memtime
+// stamps: 17 us tile load, 38 us row normalisation, 26 us taps) - 105 us per call against ~3 us of HBM traffic. Splitting
+// the row-wise and the channel-wise halves costs one extra [B,T,D] round trip and runs each half at full occupancy.
 #include "common.h"
 
-#define CM_TT 32       // output frames per workgroup
-#define CM_MAXD 256    // channels handled by one workgroup (thread = channel in the conv phases)
+#define CV_TT 64       // output frames per workgroup
+#define CV_CH 64       // channels per workgroup
+#define CV_FPT 16      // frames per thread (4 frame groups x 64 channels = 256 threads)
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// rows [row0, row0+nrows) of the GLU output of utterance b into LDS (zero outside [0,T))
-template <typename T>
-__device__ __forceinline__ void load_glu_tile(const T *__restrict__ y2, const float *__restrict__ b2, float *g_lds, int b,
-                                              int Tn, int D, int row0, int nrows) {
-    const int vec_per_row = D / 8;
-    for (int i = threadIdx.x; i < nrows * vec_per_row; i += 256) {
-        const int rr = i / vec_per_row, c = (i % vec_per_row) * 8;
-        const int t = row0 + rr;
-        float o[8];
-        if (t >= 0 && t < Tn) {
-            float a[8], g[8];
+// rows [row0, row0+R) x channels [c0, c0+64) of GLU(y2 + b2) of utterance b -> g_lds[R][64] (zero outside [0,T) x [0,D)).
+// All of a thread's 16-byte pieces are requested before the first sigmoid (one memory round trip).
+template <typename T, int R>
+__device__ __forceinline__ void load_glu_tile(const T *__restrict__ y2, const float *__restrict__ b2, float *g_lds, int b, int Tn,
+                                              int D, int c0, int row0) {
+    constexpr int ITEMS = R * (CV_CH / 8), NIT = (ITEMS + 255) / 256;
+    float a[NIT][8], g[NIT][8];
+    bool live[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = threadIdx.x + u * 256, rr = i >> 3, c = c0 + (i & 7) * 8, t = row0 + rr;
+        live[u] = i < ITEMS && t >= 0 && t < Tn && c < D;
+        if (live[u]) {
             const T *p = y2 + ((size_t)b * Tn + t) * 2 * D;
-            ld8(p + c, a);
-            ld8(p + D + c, g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (a[j] + (b2 ? b2[c + j] : 0.f)) * sigmoidf_fast(g[j] + (b2 ? b2[D + c + j] : 0.f));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            ld8(p + c, a[u]);
+            ld8(p + D + c, g[u]);
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g_lds[rr * D + c + j] = o[j];
+    for (int u = 0; u < NIT; ++u) {
+        const int i = threadIdx.x + u * 256, rr = i >> 3, cl = (i & 7) * 8, c = c0 + cl;
+        if (i >= ITEMS) break;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = live[u] ? (a[u][j] + (b2 ? b2[c + j] : 0.f)) * sigmoidf_fast(g[u][j] + (b2 ? b2[D + c + j] : 0.f)) : 0.f;
+        *reinterpret_cast<float4 *>(g_lds + rr * CV_CH + cl) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(g_lds + rr * CV_CH + cl + 4) = make_float4(o[4], o[5], o[6], o[7]);
     }
 }
 
 template <typename T, int K>
-__global__ __launch_bounds__(256) void convmod_fwd_kernel(const T *__restrict__ y2, const float *__restrict__ b2,
-                                                          const float *__restrict__ cw, const float *__restrict__ cb,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          T *__restrict__ z, T *__restrict__ c_save, float *__restrict__ mean,
-                                                          float *__restrict__ rstd, int Tn, int D, int pad_l, float eps,
-                                                          float slope) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *g_lds = smem;                          // [(TT+K-1)][D]
-    float *c_lds = smem + (CM_TT + K - 1) * D;    // [TT][D]
-    const int b = blockIdx.y, t0 = blockIdx.x * CM_TT;
-    load_glu_tile<T>(y2, b2, g_lds, b, Tn, D, t0 - pad_l, CM_TT + K - 1);
+__global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T *__restrict__ y2, const float *__restrict__ b2,
+                                                             const float *__restrict__ cw, const float *__restrict__ cb,
+                                                             T *__restrict__ c_out, int Tn, int D, int pad_l) {
+    constexpr int R = CV_TT + K - 1;
+    __shared__ __attribute__((aligned(16))) float g_lds[R * CV_CH];
+    const int b = blockIdx.z, c0 = blockIdx.y * CV_CH, t0 = blockIdx.x * CV_TT;
+    load_glu_tile<T, R>(y2, b2, g_lds, b, Tn, D, c0, t0 - pad_l);
     __syncthreads();
-    const int d = threadIdx.x;
-    if (d < D) {
+    const int ch = threadIdx.x & 63, fg = threadIdx.x >> 6, d = c0 + ch;
+    if (d >= D) return;
+    float w[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = cw[d * K + k];
+    const float bias = cb[d];
+#pragma unroll 4
+    for (int s = 0; s < CV_FPT; ++s) {
+        const int tl = fg * CV_FPT + s, t = t0 + tl;
+        if (t >= Tn) break;
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += w[k] * g_lds[(tl + k) * CV_CH + ch];
+        st1(c_out + ((size_t)b * Tn + t) * D + d, acc);
+    }
+}
+
+// slab row of one workgroup-part (b, time tile), floats: [dconv_b D][db2 2D][dconv_w D*K]; every channel group fills its own columns
+template <typename T, int K>
+__global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict__ dc, const T *__restrict__ y2,
+                                                             const float *__restrict__ b2, const float *__restrict__ cw,
+                                                             T *__restrict__ dy2, float *__restrict__ slab, int Tn, int D, int pad_l) {
+    constexpr int R = CV_TT + K - 1, NP = K + 3;   // NP partial sums per channel: dconv_w[K], dconv_b, db2 (value half), db2 (gate half)
+    constexpr int TILE = R * CV_CH, RED = 4 * CV_CH * NP;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE > RED ? 2 * TILE : RED];
+    float *g_lds = smem;           // GLU rows  [t0 - pad_l, +R)
+    float *dc_lds = smem + TILE;   // dc rows   [t0 - (K-1-pad_l), +R)
+    const int b = blockIdx.z, c0 = blockIdx.y * CV_CH, t0 = blockIdx.x * CV_TT;
+    const int dc_row0 = t0 - (K - 1 - pad_l);
+    {   // dc tile (zero outside the utterance / channel range): 16-byte pieces, requested together with the GLU operands
+        constexpr int ITEMS = R * (CV_CH / 8), NIT = (ITEMS + 255) / 256;
+        float v[NIT][8];
+        bool live[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = threadIdx.x + u * 256, rr = i >> 3, c = c0 + (i & 7) * 8, t = dc_row0 + rr;
+            live[u] = i < ITEMS && t >= 0 && t < Tn && c < D;
+            if (live[u]) ld8(dc + ((size_t)b * Tn + t) * D + c, v[u]);
+        }
+        load_glu_tile<T, R>(y2, b2, g_lds, b, Tn, D, c0, t0 - pad_l);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = threadIdx.x + u * 256, rr = i >> 3, cl = (i & 7) * 8;
+            if (i >= ITEMS) break;
+            *reinterpret_cast<float4 *>(dc_lds + rr * CV_CH + cl) = live[u] ? make_float4(v[u][0], v[u][1], v[u][2], v[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(dc_lds + rr * CV_CH + cl + 4) = live[u] ? make_float4(v[u][4], v[u][5], v[u][6], v[u][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 63, fg = threadIdx.x >> 6, d = c0 + ch;
+    const bool ch_ok = d < D;
+    float dw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) dw[k] = 0.f;
+    float dcb = 0.f, dba = 0.f, dbb = 0.f;
+    if (ch_ok) {
         float w[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) w[k] = cw[d * K + k];
-        const float bias = cb[d];
-        for (int t = 0; t < CM_TT; ++t) {
-            float acc = bias;
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc += w[k] * g_lds[(t + k) * D + d];
-            c_lds[t * D + d] = acc;
-        }
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = wave; t < CM_TT; t += 4) {
-        const int tt = t0 + t;
-        if (tt >= Tn) break;
-        float v[4];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;
-            v[j] = c < D ? c_lds[t * D + c] : 0.f;
-            s += v[j];
-        }
-        const float mu = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) { const float dd = v[j] - mu; q += dd * dd; }
-        }
-        const float rs = rsqrtf(wave_sum(q) / D + eps);
-        const size_t row = (size_t)b * Tn + tt;
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) {
-                st1(c_save + row * D + c, v[j]);
-                st1(z + row * D + c, lrelu((v[j] - mu) * rs * gamma[c] + beta[c], slope));
-            }
-        }
-    }
-}
-
-// slab layout per workgroup (floats): [dgamma D][dbeta D][dcb D][db2 2D][dcw D*K]
-template <typename T, int K>
-__global__ __launch_bounds__(256) void convmod_bwd_kernel(const T *__restrict__ dz, const T *__restrict__ y2,
-                                                          const float *__restrict__ b2, const float *__restrict__ cw,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          const T *__restrict__ c_save, const float *__restrict__ mean,
-                                                          const float *__restrict__ rstd, T *__restrict__ dy2,
-                                                          float *__restrict__ slab, int Tn, int D, int pad_l, float slope) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int R = CM_TT + K - 1;
-    float *g_lds = smem;               // GLU rows  [t0 - pad_l, t0 - pad_l + R)
-    float *dc_lds = smem + R * D;      // dc rows   [t0 - (K-1-pad_l), ... + R)
-    float *red = smem + 2 * R * D;     // [4][2][D] cross-wave combine of dgamma/dbeta
-    const int b = blockIdx.y, t0 = blockIdx.x * CM_TT;
-    const int g_row0 = t0 - pad_l, dc_row0 = t0 - (K - 1 - pad_l);
-    load_glu_tile<T>(y2, b2, g_lds, b, Tn, D, g_row0, R);
-
-    // ---- LayerNorm(+LeakyReLU) backward per frame -> dc rows (halo included); dgamma/dbeta over OWN frames only
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float ag[4] = {0.f, 0.f, 0.f, 0.f}, abt[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rr = wave; rr < R; rr += 4) {
-        const int t = dc_row0 + rr;
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < Tn) {  // wave-uniform
-            const size_t row = (size_t)b * Tn + t;
-            const float mu = mean[row], rs = rstd[row];
-            const bool own = (t >= t0) && (t < t0 + CM_TT);
-            float xh[4], gd[4];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = lane + 64 * j;
-                xh[j] = gd[j] = 0.f;
-                if (c < D) {
-                    const float h = (ld1(c_save + row * D + c) - mu) * rs;
-                    float dd = ld1(dz + row * D + c);
-                    const float gm = gamma[c];
-                    if (h * gm + beta[c] <= 0.f) dd *= slope;
-                    if (own) { ag[j] += dd * h; abt[j] += dd; }
-                    xh[j] = h;
-                    gd[j] = dd * gm;
-                    s1 += gd[j];
-                    s2 += gd[j] * h;
-                }
-            }
-            const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = rs * (gd[j] - m1 - xh[j] * m2);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;
-            if (c < D) dc_lds[rr * D + c] = o[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = lane + 64 * j;
-        if (c < D) { red[(wave * 2 + 0) * D + c] = ag[j]; red[(wave * 2 + 1) * D + c] = abt[j]; }
-    }
-    __syncthreads();
-
-    float *my = slab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(D * (K + 5));
-    const int d = threadIdx.x;
-    if (d < D) {
-        my[d] = red[0 * D + d] + red[2 * D + d] + red[4 * D + d] + red[6 * D + d];
-        my[D + d] = red[1 * D + d] + red[3 * D + d] + red[5 * D + d] + red[7 * D + d];
-        float w[K], dw[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) { w[k] = cw[d * K + k]; dw[k] = 0.f; }
-        float dcb = 0.f, dba = 0.f, dbb = 0.f;
         const float ba = b2 ? b2[d] : 0.f, bb = b2 ? b2[D + d] : 0.f;
-        const int own_off = K - 1 - pad_l;  // dc_lds row of frame t0
-        for (int s = 0; s < CM_TT; ++s) {
-            const int t = t0 + s;
-            if (t >= Tn) break;
-            // dW[k] += dc[t] * g[t + k - pad_l] ; dcb += dc[t]
-            const float dct = dc_lds[(own_off + s) * D + d];
-            dcb += dct;
-            float dg = 0.f;
+        const int own_off = K - 1 - pad_l;   // dc_lds row of frame t0
+        float a_in[CV_FPT], g_in[CV_FPT];    // GEMM outputs (value / gate halves) of this thread's frames, requested before the tap loops
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                dw[k] += dct * g_lds[(s + k) * D + d];
-                // dg[t] = sum_k w[k] * dc[t - k + pad_l]  -> dc_lds row (t - k + pad_l) - dc_row0 = s + (K-1) - k
-                dg += w[k] * dc_lds[(s + (K - 1) - k) * D + d];
-            }
-            const T *p = y2 + ((size_t)b * Tn + t) * 2 * D;
-            const float a = ld1(p + d) + ba, sg = sigmoidf_fast(ld1(p + D + d) + bb);
-            const float da = dg * sg, db = dg * a * sg * (1.f - sg);
-            T *q = dy2 + ((size_t)b * Tn + t) * 2 * D;
-            st1(q + d, da);
-            st1(q + D + d, db);
-            dba += da;
-            dbb += db;
+        for (int s = 0; s < CV_FPT; ++s) {
+            const T *p = y2 + ((size_t)b * Tn + min(t0 + fg * CV_FPT + s, Tn - 1)) * 2 * D;
+            a_in[s] = ld1(p + d);
+            g_in[s] = ld1(p + D + d);
         }
-        my[2 * D + d] = dcb;
-        my[3 * D + d] = dba;
-        my[4 * D + d] = dbb;
 #pragma unroll
-        for (int k = 0; k < K; ++k) my[5 * D + d * K + k] = dw[k];
+        for (int s = 0; s < CV_FPT; ++s) {
+            const int tl = fg * CV_FPT + s, t = t0 + tl;
+            if (t < Tn) {
+                // dW[k] += dc[t] * g[t + k - pad_l] ; dconv_b += dc[t] ; dg[t] = sum_k w[k] * dc[t - k + pad_l]
+                const float dct = dc_lds[(own_off + tl) * CV_CH + ch];
+                dcb += dct;
+                float dg = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    dw[k] += dct * g_lds[(tl + k) * CV_CH + ch];
+                    dg += w[k] * dc_lds[(tl + (K - 1) - k) * CV_CH + ch];
+                }
+                const float a = a_in[s] + ba, sg = sigmoidf_fast(g_in[s] + bb);
+                const float da = dg * sg, db = dg * a * sg * (1.f - sg);
+                T *q = dy2 + ((size_t)b * Tn + t) * 2 * D;
+                st1(q + d, da);
+                st1(q + D + d, db);
+                dba += da;
+                dbb += db;
+            }
+        }
+    }
+    __syncthreads();   // tiles are dead: reuse them for the cross-frame-group reduction [fg][NP][64]
+    float *red = smem;
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(fg * NP + k) * CV_CH + ch] = dw[k];
+    red[(fg * NP + K) * CV_CH + ch] = dcb;
+    red[(fg * NP + K + 1) * CV_CH + ch] = dba;
+    red[(fg * NP + K + 2) * CV_CH + ch] = dbb;
+    __syncthreads();
+    float *my = slab + (size_t)(blockIdx.z * gridDim.x + blockIdx.x) * (size_t)(D * (K + 3));
+    for (int i = threadIdx.x; i < NP * CV_CH; i += 256) {
+        const int q = i >> 6, c = i & 63;
+        if (c0 + c >= D) continue;
+        const float v = red[(0 * NP + q) * CV_CH + c] + red[(1 * NP + q) * CV_CH + c] + red[(2 * NP + q) * CV_CH + c] + red[(3 * NP + q) * CV_CH + c];
+        if (q < K) my[3 * D + (size_t)(c0 + c) * K + q] = v;
+        else if (q == K) my[c0 + c] = v;
+        else if (q == K + 1) my[D + c0 + c] = v;
+        else my[2 * D + c0 + c] = v;
     }
 }
 
@@ -235,21 +203,19 @@ __global__ __launch_bounds__(256) void convmod_colsum_kernel(const float *__rest
 }
 
 template <typename T, int K>
-static void launch_fwd(const void *y2, const float *b2, const float *cw, const float *cb, const float *g, const float *be, void *z,
-                       void *cs, float *mean, float *rstd, int B, int Tn, int D, int pad_l, float eps, float slope, hipStream_t st) {
-    const size_t lds = (size_t)(2 * CM_TT + K - 1) * D * sizeof(float);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)convmod_fwd_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    convmod_fwd_kernel<T, K><<<dim3(cdiv(Tn, CM_TT), B), 256, lds, st>>>((const T *)y2, b2, cw, cb, g, be, (T *)z, (T *)cs, mean, rstd, Tn, D, pad_l, eps, slope);
+static void launch_fwd(const void *y2, const float *b2, const float *cw, const float *cb, void *cs, int B, int Tn, int D, int pad_l,
+                       hipStream_t st) {
+    glu_dwconv_fwd_kernel<T, K><<<dim3(cdiv(Tn, CV_TT), cdiv(D, CV_CH), B), 256, 0, st>>>((const T *)y2, b2, cw, cb, (T *)cs, Tn, D, pad_l);
 }
 
 template <typename T, int K>
-static void launch_bwd(const void *dz, const void *y2, const float *b2, const float *cw, const float *g, const float *be,
-                       const void *cs, const float *mean, const float *rstd, void *dy2, float *slab, int B, int Tn, int D, int pad_l,
-                       float slope, hipStream_t st) {
-    const size_t lds = ((size_t)2 * (CM_TT + K - 1) * D + 8 * D) * sizeof(float);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)convmod_bwd_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    convmod_bwd_kernel<T, K><<<dim3(cdiv(Tn, CM_TT), B), 256, lds, st>>>((const T *)dz, (const T *)y2, b2, cw, g, be, (const T *)cs, mean, rstd, (T *)dy2, slab, Tn, D, pad_l, slope);
+static void launch_bwd(const void *dc, const void *y2, const float *b2, const float *cw, void *dy2, float *slab, int B, int Tn, int D,
+                       int pad_l, hipStream_t st) {
+    glu_dwconv_bwd_kernel<T, K><<<dim3(cdiv(Tn, CV_TT), cdiv(D, CV_CH), B), 256, 0, st>>>((const T *)dc, (const T *)y2, b2, cw, (T *)dy2, slab, Tn, D, pad_l);
 }
+
+static size_t slab_bytes(int B, int T, int D, int K) { return align_up((size_t)B * cdiv(T, CV_TT) * D * (K + 3) * sizeof(float), 256); }
+static size_t dc_bytes(int B, int T, int D) { return align_up((size_t)B * T * D * sizeof(float), 256); }
 
 extern "C" {
 
@@ -259,21 +225,21 @@ int tsasr_convmod_fwd(const void *y2, const float *b2, const float *conv_w, cons
                       const float *beta, void *z, void *c_save, float *mean, float *rstd, int B, int T, int D, int K, int causal,
                       float eps, float slope, int io_dtype, void *stream) {
     TSASR_CHECK_ARG(y2 && conv_w && conv_b && gamma && beta && z && c_save && mean && rstd, "tsasr_convmod_fwd: null pointer");
-    TSASR_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= CM_MAXD, "tsasr_convmod_fwd: D=%d must be a multiple of 8 and <= %d", D, CM_MAXD);
+    TSASR_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= 2048, "tsasr_convmod_fwd: D=%d must be a multiple of 8 and <= 2048", D);
     TSASR_CHECK_ARG(K == 31 || K == 15 || K == 7 || K == 3, "tsasr_convmod_fwd: kernel size %d not instantiated (31, 15, 7, 3)", K);
+    TSASR_CHECK_ARG(io_dtype == TSASR_F32 || io_dtype == TSASR_BF16, "tsasr_convmod_fwd: bad io_dtype %d", io_dtype);
     const int pad_l = causal ? K - 1 : (K - 1) / 2;
     hipStream_t st = (hipStream_t)stream;
-#define CM_F(TT, KK) launch_fwd<TT, KK>(y2, b2, conv_w, conv_b, gamma, beta, z, c_save, mean, rstd, B, T, D, pad_l, eps, slope, st)
+#define CM_F(TT, KK) launch_fwd<TT, KK>(y2, b2, conv_w, conv_b, c_save, B, T, D, pad_l, st)
 #define CM_FK(TT) do { if (K == 31) CM_F(TT, 31); else if (K == 15) CM_F(TT, 15); else if (K == 7) CM_F(TT, 7); else CM_F(TT, 3); } while (0)
     if (io_dtype == TSASR_F32) CM_FK(float);
-    else if (io_dtype == TSASR_BF16) CM_FK(bf16_t);
-    else TSASR_CHECK_ARG(false, "tsasr_convmod_fwd: bad io_dtype %d", io_dtype);
+    else CM_FK(bf16_t);
     TSASR_CHECK_LAUNCH("tsasr_convmod_fwd");
-    return 0;
+    return tsasr_layernorm_fwd(c_save, gamma, beta, z, mean, rstd, (long long)B * T, D, eps, slope, io_dtype, stream);
 }
 
 size_t tsasr_convmod_bwd_workspace_bytes(int B, int T, int D, int K) {
-    return align_up((size_t)B * cdiv(T, CM_TT) * D * (K + 5) * sizeof(float), 256);
+    return slab_bytes(B, T, D, K) + dc_bytes(B, T, D) + tsasr_layernorm_bwd_workspace_bytes((long long)B * T, D);
 }
 
 /* grads: dy2 [B,T,2D]; dparams fp32 packed [dgamma D | dbeta D | dconv_b D | db2 2D | dconv_w D*K] (OVERWRITTEN). */
@@ -281,19 +247,27 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
                       const void *c_save, const float *mean, const float *rstd, void *dy2, float *dparams, int B, int T, int D,
                       int K, int causal, float slope, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(dz && y2 && conv_w && gamma && beta && c_save && mean && rstd && dy2 && dparams && workspace, "tsasr_convmod_bwd: null pointer");
-    TSASR_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= CM_MAXD, "tsasr_convmod_bwd: bad D=%d", D);
+    TSASR_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= 2048, "tsasr_convmod_bwd: bad D=%d", D);
     TSASR_CHECK_ARG(K == 31 || K == 15 || K == 7 || K == 3, "tsasr_convmod_bwd: kernel size %d not instantiated", K);
+    TSASR_CHECK_ARG(io_dtype == TSASR_F32 || io_dtype == TSASR_BF16, "tsasr_convmod_bwd: bad io_dtype %d", io_dtype);
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_convmod_bwd_workspace_bytes(B, T, D, K), "tsasr_convmod_bwd: workspace too small");
     const int pad_l = causal ? K - 1 : (K - 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
-#define CM_B(TT, KK) launch_bwd<TT, KK>(dz, y2, b2, conv_w, gamma, beta, c_save, mean, rstd, dy2, slab, B, T, D, pad_l, slope, st)
+    void *dc = (char *)workspace + slab_bytes(B, T, D, K);
+    void *ln_ws = (char *)dc + dc_bytes(B, T, D);
+    const size_t ln_ws_bytes = tsasr_layernorm_bwd_workspace_bytes((long long)B * T, D);
+    // (1) LayerNorm + LeakyReLU backward, row-wise: dc, dgamma, dbeta
+    const int rc = tsasr_layernorm_bwd(dz, c_save, gamma, beta, mean, rstd, dc, dparams, dparams + D, (long long)B * T, D, slope, io_dtype,
+                                       ln_ws, ln_ws_bytes, stream);
+    if (rc) return rc;
+    // (2) depthwise conv + GLU backward, channel-wise
+#define CM_B(TT, KK) launch_bwd<TT, KK>(dc, y2, b2, conv_w, dy2, slab, B, T, D, pad_l, st)
 #define CM_BK(TT) do { if (K == 31) CM_B(TT, 31); else if (K == 15) CM_B(TT, 15); else if (K == 7) CM_B(TT, 7); else CM_B(TT, 3); } while (0)
     if (io_dtype == TSASR_F32) CM_BK(float);
-    else if (io_dtype == TSASR_BF16) CM_BK(bf16_t);
-    else TSASR_CHECK_ARG(false, "tsasr_convmod_bwd: bad io_dtype %d", io_dtype);
-    const int width = D * (K + 5), nparts = B * cdiv(T, CM_TT);
-    convmod_colsum_kernel<<<cdiv(width, 16), 256, 0, st>>>(slab, dparams, nparts, width);
+    else CM_BK(bf16_t);
+    const int width = D * (K + 3), nparts = B * cdiv(T, CV_TT);
+    convmod_colsum_kernel<<<cdiv(width, 16), 256, 0, st>>>(slab, dparams + 2 * D, nparts, width);
     TSASR_CHECK_LAUNCH("tsasr_convmod_bwd");
     return 0;
 }

@@ -489,8 +489,16 @@ static void launch_t(int tA, int tB, const void *A, const void *B, void *C, int 
 }
 
 struct GemmPlan { int tile; int splits; int kchunk; };   // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
+static int g_force_tile = -1, g_force_splits = 0;             // tools/gemm_bench.py sweeps (tsasr_gemm_set_plan)
 static GemmPlan plan(int M, int N, int K, int out_f32) {
     GemmPlan p;
+    if (g_force_tile >= 0) {
+        p.tile = g_force_tile;
+        p.splits = (out_f32 && g_force_splits > 0) ? g_force_splits : 1;
+        p.kchunk = cdiv(cdiv(K, p.splits), GB_K) * GB_K;
+        p.splits = cdiv(K, p.kchunk);
+        return p;
+    }
     const long long t0 = (long long)cdiv(M, 128) * cdiv(N, 128), t1 = (long long)cdiv(M, 128) * cdiv(N, 64),
                     t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
     p.tile = t0 >= 192 ? 0 : (t1 >= 192 ? 1 : 2);   // the largest macro-tile whose grid still covers the 256 CUs
@@ -540,6 +548,8 @@ extern "C" {
 
 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: ring whenever K % 64 == 0; 0: register-staged loop only (A/B tests). */
 void tsasr_gemm_set_ring(int on) { g_use_ring = on; }
+/* A/B tests only: force the macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64; -1 = automatic) and the split-K factor of fp32-output GEMMs. */
+void tsasr_gemm_set_plan(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
 
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype) {
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
