@@ -256,6 +256,10 @@ int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, 
 int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, int H,
                        int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Transposed bf16 copies of a list of row-major matrices (GEMM weights -> k-contiguous operands of the input-gradient GEMMs), one
+ * launch. jobs: DEVICE int32 [njobs][5] = {src offset, dst offset (elements), rows, cols, first 64x64 tile index}. */
+int tsasr_transpose_many_bf16(const void *src_base, void *dst_base, const void *jobs, int njobs, int ntiles, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,7 @@ _PROTOS = {
     "tsasr_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_lstm_seq_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_transpose_many_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 
 

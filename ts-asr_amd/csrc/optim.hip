@@ -90,6 +90,38 @@ __global__ __launch_bounds__(256) void accumulate_many_kernel(const float *const
     for (int i = threadIdx.x; i < len; i += 256) d[i] += s[i];
 }
 
+// dst_j[c][r] = src_j[r][c] for a list of 2-D bf16 matrices, one launch: transposed copies of the GEMM weights, refreshed after
+// every optimizer step so that the input-gradient GEMMs (dx = dy . W) read W^T as a k-contiguous [K', N'] operand (the same
+// fast path as the forward GEMM) instead of through transposing LDS reads (41 vs 22 us on the 8000 x 256 x 2048 FFN dgrad).
+// jobs: int32 [njobs][5] = {src offset, dst offset (elements), rows, cols, first tile}; tile = 64 x 64 through LDS.
+__global__ __launch_bounds__(256) void transpose_many_bf16_kernel(const unsigned short *__restrict__ src_base, unsigned short *__restrict__ dst_base,
+                                                                  const int *__restrict__ jobs, int njobs) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {   // last job whose first tile <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid * 5 + 4] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int *jb = jobs + lo * 5;
+    const int rows = jb[2], cols = jb[3], lt = bid - jb[4], tcn = (cols + 63) >> 6;
+    const int r0 = (lt / tcn) * 64, c0 = (lt % tcn) * 64;
+    const unsigned short *src = src_base + jb[0];
+    unsigned short *dst = dst_base + jb[1];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ry + 4 * i, c = c0 + cx;
+        tile[ry + 4 * i][cx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ry + 4 * i, r = r0 + cx;
+        if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[cx][ry + 4 * i];
+    }
+}
+
 extern "C" {
 
 /* Adds `count` small fp32 gradient vectors into their slots of the gradient arena with ONE launch (replaces one
@@ -122,6 +154,15 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
     if (blocks > 2048) blocks = 2048;
     clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, (bf16_t *)p_bf16, g, m, v, part, hyper, norm_out, n, beta1, beta2, eps, weight_decay, max_norm);
     TSASR_CHECK_LAUNCH("tsasr_clip_adamw_step");
+    return 0;
+}
+
+/* Transposed bf16 copies of `njobs` row-major matrices in ONE launch. jobs: DEVICE int32 [njobs][5] = {src offset, dst offset
+ * (elements from src_base / dst_base), rows, cols, index of the matrix' first 64x64 tile}; ntiles = total tile count. */
+int tsasr_transpose_many_bf16(const void *src_base, void *dst_base, const void *jobs, int njobs, int ntiles, void *stream) {
+    TSASR_CHECK_ARG(src_base && dst_base && jobs && njobs > 0 && ntiles > 0, "tsasr_transpose_many_bf16: bad arguments");
+    transpose_many_bf16_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const unsigned short *)src_base, (unsigned short *)dst_base, (const int *)jobs, njobs);
+    TSASR_CHECK_LAUNCH("tsasr_transpose_many_bf16");
     return 0;
 }
 

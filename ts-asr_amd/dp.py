@@ -110,14 +110,38 @@ class GradArena:
         self.bucket_of = {i: b for b in self.buckets for i in b["ids"]}
 
     def refresh_shadow(self):
-        """(Re)build the bf16 shadow and hand every parameter its view (``p._bf16``; valid while ``p._version`` is unchanged)."""
+        """(Re)build the bf16 shadow and hand every parameter its view (``p._bf16``; valid while ``p._version`` is unchanged).
+        Matrices also get a TRANSPOSED bf16 copy (``p._bf16_t`` [cols, rows]): the k-contiguous operand of dx = dy . W."""
         if self.flat_params16 is None:
             return
         self.flat_params16.copy_(self.flat_params)
+        jobs, t_off, tiles = [], 0, 0
+        mats = [p for p in self.params_ordered if p.dim() == 2 and min(p.shape) >= 16 and p.numel() >= 4096]
+        total_t = sum(p.numel() for p in mats)
+        if getattr(self, "flat_params16_t", None) is None or self.flat_params16_t.numel() != total_t:
+            self.flat_params16_t = torch.empty(max(total_t, 1), dtype=torch.bfloat16, device=self.device)
         for p in self.params_ordered:
             o, n = self.offset[id(p)], p.numel()
             p._bf16 = self.flat_params16[o:o + n].view(p.shape)
             p._bf16_ver = p._version
+            p._bf16_t = None
+        for p in mats:
+            r, c = p.shape
+            jobs.append((self.offset[id(p)], t_off, r, c, tiles))
+            p._bf16_t = self.flat_params16_t[t_off:t_off + r * c].view(c, r)
+            t_off += r * c
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+        self._tr_njobs, self._tr_tiles = len(jobs), tiles
+        self._tr_jobs = torch.tensor(jobs, dtype=torch.int32).reshape(-1).to(self.device) if jobs else None
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        """Rewrite the transposed weight copies from the bf16 shadow: one launch, issued after every optimizer step (graph-capturable)."""
+        if getattr(self, "_tr_jobs", None) is None:
+            return
+        from . import _capi as C
+        C.check(C.lib().tsasr_transpose_many_bf16(C.ptr(self.flat_params16), C.ptr(self.flat_params16_t), C.ptr(self._tr_jobs),
+                                                  self._tr_njobs, self._tr_tiles, C.stream_ptr()), "tsasr_transpose_many_bf16")
 
     # ---- gradient sink: kernels that add a weight gradient straight into the arena (ops._LinearFn) ---------
     def accepts(self, p):

@@ -112,6 +112,23 @@ def _bf16_weight(w):
     return w.detach().to(torch.bfloat16)
 
 
+def _bf16_weight_t(w):
+    """Transposed bf16 copy [in, out] of a Linear weight kept by the gradient arena (dp.GradArena.refresh_transposed), or None."""
+    sh = getattr(w, "_bf16_t", None)
+    if sh is not None and getattr(w, "_bf16_ver", -1) == w._version and sh.shape[0] % 8 == 0 and sh.shape[1] % 8 == 0:
+        return sh
+    return None
+
+
+def _dgrad(dy2, weight, w16, M, N, K):
+    """dx [M, K] = dy [M, N] . W [N, K]: through the transposed copy W^T [K, N] when the arena keeps one (both operands
+    k-contiguous - the forward GEMM's fast path), else through the transposing fragment reads."""
+    wt = _bf16_weight_t(weight)
+    if wt is not None:
+        return gemm_bf16(dy2, wt, M, K, N, N, N, 0, 0)
+    return gemm_bf16(dy2, w16, M, K, N, N, w16.stride(0), 0, 1)
+
+
 def _gemm_ok(x, weight):
     return (x.dtype == torch.bfloat16 and x.is_cuda and weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 8 == 0
             and weight.shape[0] % 8 == 0 and weight.stride(0) % 8 == 0 and x.shape[-1] == weight.shape[1])
@@ -148,7 +165,7 @@ class _LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_bf16(dy2, w16, M, K, N, N, w16.stride(0), 0, 1).view(ctx.xshape)      # dy . W
+            dx = _dgrad(dy2, weight, w16, M, N, K).view(ctx.xshape)                         # dy . W
         dw = None
         if ctx.needs_input_grad[1]:
             sink = _GRAD_SINK
@@ -206,8 +223,12 @@ class _FFNFn(torch.autograd.Function):
             do2 = do2.contiguous()
         db1 = torch.empty(F1, dtype=torch.float32, device=x2.device) if b1 is not None else None
         # dh_pre = (do . W2) * dropout/activation backward, + column sums -> db1
-        dh = gemm_bf16_fused(do2, w2h, M, F1, Dout, Dout, F1, 0, 1, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
-        dx = gemm_bf16(dh, w1h, M, D, F1, F1, D, 0, 1).view(xshape) if ctx.needs_input_grad[0] else None
+        w2t = _bf16_weight_t(w2)
+        if w2t is not None:   # W2^T [F1, Dout]: k-contiguous operand
+            dh = gemm_bf16_fused(do2, w2t, M, F1, Dout, Dout, Dout, 0, 0, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
+        else:
+            dh = gemm_bf16_fused(do2, w2h, M, F1, Dout, Dout, F1, 0, 1, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
+        dx = _dgrad(dh, w1, w1h, M, F1, D).view(xshape) if ctx.needs_input_grad[0] else None
         sink = _GRAD_SINK
 
         def wgrad(w, g, a, n_out, k_in):
@@ -280,7 +301,9 @@ class _LstmFn(torch.autograd.Function):
         dev = x.device
         dout = dout.contiguous()
         dgates = torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=dev)
-        whhT = whh16.t().contiguous()
+        whhT = _bf16_weight_t(w_hh)
+        if whhT is None:
+            whhT = whh16.t().contiguous()
         lib, st = C.lib(), C.stream_ptr()
         ws = _ws(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dev)
         with prof.region("lstm_bwd"):   # dh = dout[:, t] + dgates[:, t+1] . W_hh, cell backward, t = U-1 .. 0 in one launch

@@ -53,6 +53,7 @@ class FusedClipAdamW:
                                                   C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self.last_grad_norm), a.numel,
                                                   float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.max_grad_norm,
                                                   C.ptr(self._ws), self._ws.numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
+            a.refresh_transposed()
 
     def step(self):
         self.prepare()
