@@ -40,8 +40,10 @@ struct EpiArgs {
 template <int BM, int BN, bool AT, bool BT>
 struct GemmSmem {
     // non-transposed operand tile: [rows][GB_K + 8]; transposed: [GB_K][rows + 8]
-    static constexpr int A_LD = AT ? (BM + 8) : (GB_K + 8);
-    static constexpr int B_LD = BT ? (BN + 8) : (GB_K + 8);
+    // padding: +16 B per k-contiguous row (b128 fragment reads of 16 consecutive rows rotate through the banks); +64 B per
+    // transposed row (the 64-byte pieces that 4 consecutive k-rows feed to one ds_read_b64_tr_b16 must not share banks)
+    static constexpr int A_LD = AT ? (BM + 32) : (GB_K + 8);
+    static constexpr int B_LD = BT ? (BN + 32) : (GB_K + 8);
     static constexpr int A_ELEMS = AT ? GB_K * A_LD : BM * A_LD;
     static constexpr int B_ELEMS = BT ? GB_K * B_LD : BN * B_LD;
     static constexpr int STAGE = A_ELEMS + B_ELEMS;
@@ -282,7 +284,17 @@ struct RingTile {
     static constexpr int NCH = ROW_BYTES / 16;                           // 16-byte chunks per row
     static constexpr int BYTES = NROWS * ROW_BYTES;
     static constexpr int INSTR = BYTES / 4096;                           // wave-instructions per wave (4 waves x 1 KiB)
-    __device__ static __forceinline__ int swz(int row, int ch) { return ch ^ (row & 7); }
+    // XOR swizzle of the 16-byte chunk index, applied to the DMA source address and to the fragment reads alike. Chosen per layout
+    // so that every group of lanes the LDS serves together hits 64 distinct banks:
+    //   k-contiguous tile (128-byte rows, ds_read_b128: 16 lanes = 16 consecutive rows, one chunk each): bank group =
+    //   (row & 1) * 8 + chunk -> chunk ^ ((row >> 1) & 7) makes the 16 rows distinct (chunk ^ (row & 7) left rows r, r+8 colliding);
+    //   transposed tile (rows of ROWS bf16, ds_read_b64_tr_b16: 32 lanes = 4 consecutive k-rows x 64 bytes): the 64-byte group
+    //   (chunk >> 2) must differ between those rows -> 256-byte rows: chunk ^ ((row & 3) << 2); 128-byte rows (two groups per
+    //   row, consecutive rows already alternate halves): chunk ^ (((row >> 1) & 1) << 2).
+    __device__ static __forceinline__ int swz(int row, int ch) {
+        if (!TR) return ch ^ ((row >> 1) & 7);
+        return ROW_BYTES >= 256 ? ch ^ ((row & 3) << 2) : ch ^ (((row >> 1) & 1) << 2);
+    }
     // issue this wave's share of one tile; rows/cols beyond the matrix are clamped (their results are never stored)
     __device__ static __forceinline__ void issue(const bf16_t *__restrict__ src, long long ld, int row0, int nrows, int k0, char *slot,
                                                  int wave, int lane) {
