@@ -90,6 +90,19 @@ def cpu_baseline(brain, torch, budget_steps=2, B=2):
             "sample": f"fwd+loss+bwd of the same model/shape at B={B} (T=1000 mel, U=120, 5 s enrollment), fp32, median of {len(times)} steps after 1 warm-up; optimizer step excluded"}
 
 
+def pmc_traffic(kernel):
+    """FETCH_SIZE + WRITE_SIZE bytes per launch of `kernel` (PMC passes of this same bench command, corrected per the gfx950 guide)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            for r in json.load(open(path))["kernels"]:
+                if r["kernel"] == kernel:
+                    return round(r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]), os.path.basename(path)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +208,8 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": fam[dom]["avg_ms"]}
+        if roof is not None:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py), newest round
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])
         rnnt_ms = sum(fam[k]["avg_ms"] for k in ("joint_fwd", "rnnt_loss_fwd", "rnnt_loss_bwd", "joint_bwd") if k in fam)
         out = {
             "metric": "utterance-frames/sec (conformer-t_scratch training step, T=1000, B=32/GPU)",

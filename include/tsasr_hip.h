@@ -188,7 +188,7 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
  * bf16 MFMA GEMM with the operand layouts of a Linear layer (replaces the library GEMMs behind torch.nn.functional.linear on
  * SB/nnet/attention.py:549-553,581-583,635,820-836, Conformer.py:76-82,98, SB/nnet/linear.py:64-78):
  *   C[M,N] (+)= op(A)[M,K] . op(B)[K,N];  transA=0: A [M,K], 1: A [K,M];  transB=0: B [N,K] (a Linear weight), 1: B [K,N].
- *   out_dtype TSASR_BF16 | TSASR_F32; accumulate (fp32 only): C += result, used to add weight gradients straight into the
+ *   out_dtype TSASR_BF16 | TSASR_F32; accumulate (fp32 only; 2 = the slab sum may be deferred, see tsasr_reduce_defer): C += result, used to add weight gradients straight into the
  *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
  * ------------------------------------------------------------------------------------------ */
 void tsasr_gemm_set_ring(int on);                 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: whenever K % 64 == 0; 0: register-staged loop (A/B tests) */
@@ -259,6 +259,16 @@ int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, voi
 /* Transposed bf16 copies of a list of row-major matrices (GEMM weights -> k-contiguous operands of the input-gradient GEMMs), one
  * launch. jobs: DEVICE int32 [njobs][5] = {src offset, dst offset (elements), rows, cols, first 64x64 tile index}. */
 int tsasr_transpose_many_bf16(const void *src_base, void *dst_base, const void *jobs, int njobs, int ntiles, void *stream);
+
+/* Batched deterministic reductions of partial gradient rows / split-K slabs (csrc/reduce.hip). While tsasr_reduce_defer(1) is in
+ * force the parameter-gradient outputs of the *_bwd entry points (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias)
+ * and of tsasr_gemm_bf16(accumulate = 2) are only QUEUED: their workspaces and outputs must stay alive and untouched until
+ * tsasr_reduce_flush runs all queued jobs in one launch (table_host: pinned host memory, table_dev: device memory, both at least
+ * tsasr_reduce_table_bytes(tsasr_reduce_pending()) bytes; must outlive a captured graph). Replaces ~310 small launches per step. */
+int tsasr_reduce_defer(int on);
+int tsasr_reduce_pending(void);
+size_t tsasr_reduce_table_bytes(int max_jobs);
+int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,10 @@ _PROTOS = {
     "tsasr_lstm_seq_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_lstm_seq_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_transpose_many_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "tsasr_reduce_defer": (c_int, [c_int]),
+    "tsasr_reduce_pending": (c_int, []),
+    "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
+    "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -176,32 +176,6 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void convmod_colsum_kernel(const float *__restrict__ slab, float *__restrict__ out, int nparts,
-                                                             int width) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (col < width) {
-        int n = slice;
-        for (; n + 48 < nparts; n += 64) {  // 4 independent loads in flight per lane
-            s0 += slab[(size_t)n * width + col];
-            s1 += slab[(size_t)(n + 16) * width + col];
-            s2 += slab[(size_t)(n + 32) * width + col];
-            s3 += slab[(size_t)(n + 48) * width + col];
-        }
-        for (; n < nparts; n += 16) s0 += slab[(size_t)n * width + col];
-    }
-    red[slice][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (slice == 0 && col < width) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[q][cl];
-        out[col] = s;
-    }
-}
-
 template <typename T, int K>
 static void launch_fwd(const void *y2, const float *b2, const float *cw, const float *cb, void *cs, int B, int Tn, int D, int pad_l,
                        hipStream_t st) {
@@ -267,7 +241,7 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
     if (io_dtype == TSASR_F32) CM_BK(float);
     else CM_BK(bf16_t);
     const int width = D * (K + 3), nparts = B * cdiv(T, CV_TT);
-    convmod_colsum_kernel<<<cdiv(width, 16), 256, 0, st>>>(slab, dparams + 2 * D, nparts, width);
+    tsasr_reduce_submit(slab, dparams + 2 * D, width, nparts, width, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_convmod_bwd");
     return 0;
 }

@@ -707,7 +707,10 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
            : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
                                     : -2;
     TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_bwd: D=%d too large or bad io_dtype %d", D, io_dtype);
-    colsum_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
+    if (tsasr_reduce_deferring()) {
+        tsasr_reduce_submit(part, dgamma, 2 * D, nwg, D, 0, st);
+        tsasr_reduce_submit(part + D, dbeta, 2 * D, nwg, D, 0, st);
+    } else colsum_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
     TSASR_CHECK_LAUNCH("tsasr_layernorm_bwd");
     return 0;
 }
@@ -758,7 +761,7 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
     else if (io_dtype == TSASR_BF16)
         bias_act_dropout_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dy, (const bf16_t *)y, (bf16_t *)dx, part, M, N, act_slope, p, seed, seed_dev, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) tsasr_reduce_submit(part, dbias, N, nwg, N, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_bias_act_dropout_bwd");
     return 0;
 }
@@ -794,7 +797,7 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     else if (io_dtype == TSASR_BF16)
         dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    if (dbias) colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(part, dbias, nullptr, nwg, N, N);
+    if (dbias) tsasr_reduce_submit(part, dbias, N, nwg, N, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
     return 0;
 }
@@ -851,7 +854,11 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
         else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_bwd: D=%d too large", D);
     } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
 #undef ALN_B
-    colsum3_kernel<<<cdiv(3 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, dbias, nwg, D);
+    if (tsasr_reduce_deferring()) {
+        tsasr_reduce_submit(part, dgamma, 3 * D, nwg, D, 0, st);
+        tsasr_reduce_submit(part + D, dbeta, 3 * D, nwg, D, 0, st);
+        tsasr_reduce_submit(part + 2 * D, dbias, 3 * D, nwg, D, 0, st);
+    } else colsum3_kernel<<<cdiv(3 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, dbias, nwg, D);
     TSASR_CHECK_LAUNCH("tsasr_add_layernorm_bwd");
     return 0;
 }

@@ -539,23 +539,6 @@ static void launch_tile(int tile, int tA, int tB, const void *A, const void *B, 
 
 static int tile_bm(int tile) { return tile == 2 ? 64 : 128; }
 
-// out[n] = sum_parts part[p][n]
-__global__ __launch_bounds__(256) void gemm_colsum_kernel(const float *__restrict__ part, float *__restrict__ out, int nparts, int N) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = blockIdx.x * 16 + cl;
-    float s0 = 0.f;
-    if (col < N)
-        for (int n = slice; n < nparts; n += 16) s0 += part[(size_t)n * N + col];
-    red[slice][cl] = s0;
-    __syncthreads();
-    if (slice == 0 && col < N) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[q][cl];
-        out[col] = s;
-    }
-}
-
 extern "C" {
 
 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: ring whenever K % 64 == 0; 0: register-staged loop only (A/B tests). */
@@ -588,7 +571,10 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
         TSASR_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "tsasr_gemm_bf16: split-K output needs N, ldc multiples of 4");
         const long long ss = (long long)M * N;
         launch_tile<1>(p.tile, transA, transB, A, B, workspace, M, N, K, lda, ldb, N, p.splits, p.kchunk, ss, st);
-        gemm_slab_reduce_kernel<<<(unsigned)cdiv((int)((ss + 3) / 4), 256), 256, 0, st>>>((const float *)workspace, (float *)C, M, N, ldc, p.splits, ss, accumulate);
+        if (accumulate == 2 && ldc == N && ss < (1ll << 31) && tsasr_reduce_deferring())   // slabs stay in the workspace until tsasr_reduce_flush
+            tsasr_reduce_submit((const float *)workspace, (float *)C, ss, p.splits, (int)ss, 1, st);
+        else
+            gemm_slab_reduce_kernel<<<(unsigned)cdiv((int)((ss + 3) / 4), 256), 256, 0, st>>>((const float *)workspace, (float *)C, M, N, ldc, p.splits, ss, accumulate != 0);
     } else if (out_dtype == TSASR_BF16) {
         launch_tile<0>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     } else if (accumulate) {
@@ -622,7 +608,7 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     ep.mode = epi_mode; ep.bias = bias; ep.y = (const bf16_t *)y; ep.ldy = ldy; ep.slope = slope; ep.p = p; ep.seed = seed; ep.seed_dev = seed_dev;
     ep.colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;
     launch_tile<0>(pl.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, pl.kchunk, 0, st, ep);
-    if (ep.colpart) gemm_colsum_kernel<<<cdiv(N, 16), 256, 0, st>>>(ep.colpart, dbias, cdiv(M, tile_bm(pl.tile)), N);
+    if (ep.colpart) tsasr_reduce_submit(ep.colpart, dbias, N, cdiv(M, tile_bm(pl.tile)), N, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_fused");
     return 0;
 }

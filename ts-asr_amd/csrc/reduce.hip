@@ -1,0 +1,144 @@
+// Deterministic partial-sum reductions, immediate or batched.
+//
+// Every parameter gradient on the path ends in the same shape of work: out[c] (+)= sum_p part[p][c] over the per-workgroup
+// partial rows a backward kernel left in its workspace (LayerNorm gamma/beta, biases, conv filters, dropout-add biases) or over
+// the split-K fp32 slabs of a weight-gradient GEMM. Launched one by one these are ~310 tiny kernels per training step, each
+// paying the ~4.7 us floor of a dependent launch inside the step's hipGraph (1.5 ms of a 27 ms step). While deferral is on
+// (gradient arena, between begin_backward and finish_backward) the producers only QUEUE a job; tsasr_reduce_flush then runs all
+// of them in ONE launch. Summation order inside a job is fixed (slices of 16 partial rows, combined in index order), so results
+// are bit-identical between the immediate and the batched path and from run to run - no float atomics anywhere.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+struct ReduceJob {
+    const float *src;     // partial rows: src[p * pstride + c]
+    float *dst;           // dst[c] (+)= sum_p
+    long long pstride;
+    int nparts, width, accumulate, tile0, wide, pad_;
+};
+
+// tall jobs (many partial rows, few columns): tile = 16 columns, 16 row slices per workgroup, slices combined through LDS
+// wide jobs (few slabs, many columns):        tile = 1024 columns, one thread = 4 consecutive columns, 16-byte slab loads
+#define RD_WIDE_TILE 1024
+
+__device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*red)[17]) {
+    if (j.wide) {
+        const int c = lt * RD_WIDE_TILE + threadIdx.x * 4;
+        if (c >= j.width) return;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c + 4 <= j.width && ((reinterpret_cast<uintptr_t>(j.src) | (uintptr_t)(j.pstride * 4)) & 15) == 0) {
+            for (int p = 0; p < j.nparts; ++p) {
+                const float4 v = *reinterpret_cast<const float4 *>(j.src + (long long)p * j.pstride + c);
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            }
+        } else {
+            for (int p = 0; p < j.nparts; ++p)
+                for (int e = 0; e < 4 && c + e < j.width; ++e) s[e] += j.src[(long long)p * j.pstride + c + e];
+        }
+        for (int e = 0; e < 4 && c + e < j.width; ++e) {
+            if (j.accumulate) j.dst[c + e] += s[e];
+            else j.dst[c + e] = s[e];
+        }
+        return;
+    }
+    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = lt * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < j.width) {
+        int n = slice;
+        for (; n + 48 < j.nparts; n += 64) {   // four independent loads in flight per lane
+            s0 += j.src[(long long)n * j.pstride + col];
+            s1 += j.src[(long long)(n + 16) * j.pstride + col];
+            s2 += j.src[(long long)(n + 32) * j.pstride + col];
+            s3 += j.src[(long long)(n + 48) * j.pstride + col];
+        }
+        for (; n < j.nparts; n += 16) s0 += j.src[(long long)n * j.pstride + col];
+    }
+    red[slice][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && col < j.width) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        if (j.accumulate) j.dst[col] += s;
+        else j.dst[col] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_one_kernel(ReduceJob job) {
+    __shared__ float red[16][17];
+    reduce_tile(job, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__restrict__ jobs, int njobs) {
+    __shared__ float red[16][17];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {   // last job whose first tile <= bid (uniform per workgroup)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const ReduceJob j = jobs[lo];
+    reduce_tile(j, bid - j.tile0, red);
+}
+
+static std::vector<ReduceJob> g_jobs;
+static int g_defer = 0, g_tiles = 0;
+
+static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE) : cdiv(j.width, 16); }
+
+bool tsasr_reduce_deferring() { return g_defer != 0; }
+
+// dst[c] (+)= sum_{p < nparts} src[p * pstride + c], c < width: queued while deferral is on, else launched on `st`
+void tsasr_reduce_submit(const float *src, float *dst, long long pstride, int nparts, int width, int accumulate, hipStream_t st) {
+    if (!dst || width <= 0 || nparts <= 0) return;
+    ReduceJob j{src, dst, pstride, nparts, width, accumulate, g_tiles, nparts < 32 && width >= 4096 ? 1 : 0, 0};
+    if (g_defer) {
+        g_jobs.push_back(j);
+        g_tiles += job_tiles(j);
+        return;
+    }
+    j.tile0 = 0;
+    reduce_one_kernel<<<job_tiles(j), 256, 0, st>>>(j);
+}
+
+extern "C" {
+
+/* 1: reductions of partial gradient rows / split-K slabs requested from now on are queued (their partial buffers and outputs
+ * must stay alive and untouched until tsasr_reduce_flush); 0: launched immediately (default). Switching off with jobs still
+ * queued is an error. Only calls that declare it take part: tsasr_gemm_bf16(accumulate = 2) and the *_bwd kernels' parameter
+ * gradient outputs (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias). */
+int tsasr_reduce_defer(int on) {
+    TSASR_CHECK_ARG(on || g_jobs.empty(), "tsasr_reduce_defer(0) with %d reductions still queued: call tsasr_reduce_flush first", (int)g_jobs.size());
+    g_defer = on ? 1 : 0;
+    return 0;
+}
+
+int tsasr_reduce_pending(void) { return (int)g_jobs.size(); }
+
+size_t tsasr_reduce_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof(ReduceJob); }
+
+/* Runs every queued reduction in ONE launch. table_host: PINNED host memory, table_dev: device memory, both `table_bytes` >=
+ * tsasr_reduce_table_bytes(tsasr_reduce_pending()); the job table is copied host -> device on `stream` (a memcpy node under
+ * graph capture - the buffers must outlive the graph). */
+int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream) {
+    if (g_jobs.empty()) return 0;
+    const size_t need = g_jobs.size() * sizeof(ReduceJob);
+    TSASR_CHECK_ARG(table_host && table_dev && table_bytes >= need, "tsasr_reduce_flush: job table too small (%zu < %zu bytes)", table_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    memcpy(table_host, g_jobs.data(), need);
+    hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+        tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
+        return TSASR_E_LAUNCH;
+    }
+    reduce_many_kernel<<<g_tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)g_jobs.size());
+    g_jobs.clear();
+    g_tiles = 0;
+    TSASR_CHECK_LAUNCH("tsasr_reduce_flush");
+    return 0;
+}
+
+}  // extern "C"

@@ -186,6 +186,9 @@ class GradArena:
     def begin_backward(self, will_sync):
         self.in_backward = True
         self._sync_this_step = bool(will_sync) and self.sync_enabled and self.world_size > 1
+        if not self._sync_this_step and self.device.type == "cuda":   # (a bucket may only be sent once its gradients are final)
+            from . import ops
+            ops.reduce_defer_begin(self.device)
         for b in self.buckets:
             b["left"], b["sent"] = len(b["ids"]), False
         self._handles = []
@@ -211,6 +214,9 @@ class GradArena:
             self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
     def finish_backward(self):
+        if self.device.type == "cuda":
+            from . import ops
+            ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()
         self.in_backward = False
         if self._sync_this_step:

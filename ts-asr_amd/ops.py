@@ -48,8 +48,52 @@ def begin_step(device):
         C.check(C.lib().tsasr_seed_advance(C.ptr(seed_state(device)), 0x9E3779B97F4A7C15, C.stream_ptr()), "tsasr_seed_advance")
 
 
+# Deferred reductions (csrc/reduce.hip): between GradArena.begin_backward and finish_backward the partial-sum reductions of
+# parameter gradients are queued and run as one launch; their workspaces must outlive the queue, so they are parked here.
+_DEFER = {"on": False, "keep": [], "host": None, "dev": None}
+_DEFER_MAX_JOBS = 8192
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    if _DEFER["on"]:
+        _DEFER["keep"].append(t)
+    return t
+
+
+def _keep(*tensors):
+    """Outputs of a queued reduction must not be recycled by the allocator before the flush writes them."""
+    if _DEFER["on"]:
+        _DEFER["keep"].extend(t for t in tensors if t is not None)
+
+
+def reduce_defer_begin(device):
+    if device.type != "cuda":
+        return
+    if _DEFER["host"] is None:
+        nb = C.lib().tsasr_reduce_table_bytes(_DEFER_MAX_JOBS)
+        _DEFER["host"] = torch.empty(nb, dtype=torch.uint8).pin_memory()
+        _DEFER["dev"] = torch.empty(nb, dtype=torch.uint8, device=device)
+    C.check(C.lib().tsasr_reduce_defer(1), "tsasr_reduce_defer")
+    _DEFER["on"] = True
+
+
+def reduce_flush():
+    """Run the queued reductions now (one launch); the parked workspaces are released afterwards (stream order keeps them valid)."""
+    if not _DEFER["on"]:
+        return
+    if C.lib().tsasr_reduce_pending() > _DEFER_MAX_JOBS:
+        raise C.TsasrHipError("more queued reductions than the job table holds")
+    C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"]), C.ptr(_DEFER["dev"]), _DEFER["host"].numel(), C.stream_ptr()), "tsasr_reduce_flush")
+    _DEFER["keep"] = []
+
+
+def reduce_defer_end():
+    if not _DEFER["on"]:
+        return
+    reduce_flush()
+    C.check(C.lib().tsasr_reduce_defer(0), "tsasr_reduce_defer")
+    _DEFER["on"] = False
 
 
 def _f32(p):
@@ -79,11 +123,12 @@ def _pgrad(param, g, shape=None):
     sink = _GRAD_SINK
     if sink is not None and isinstance(param, torch.nn.Parameter) and sink.defer_add(param, g):
         return None
+    reduce_flush()   # autograd will read g right away: a queued reduction that produces it has to run first
     g = g.view(shape if shape is not None else param.shape)
     return g if g.dtype == param.dtype else g.to(param.dtype)
 
 
-def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=torch.bfloat16, accumulate=False, ldc=None):
+def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=torch.bfloat16, accumulate=False, ldc=None, defer_ok=False):
     """C[M,N] (+)= op(A).op(B) on the hand-written MFMA kernel (csrc/gemm.hip); see include/tsasr_hip.h for the layouts."""
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
@@ -100,7 +145,8 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
         label = "gemm"
     with prof.region(label, 2.0 * M * N * K):
         C.check(C.lib().tsasr_gemm_bf16(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, N if ldc is None else ldc, int(trans_a),
-                                        int(trans_b), od, int(accumulate), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                                        int(trans_b), od, (2 if defer_ok and _DEFER["on"] else 1) if accumulate else 0,
+                                        C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
                 "tsasr_gemm_bf16")
     return out
 
@@ -171,7 +217,7 @@ class _LinearFn(torch.autograd.Function):
             sink = _GRAD_SINK
             if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
                     and weight.grad.is_contiguous()):
-                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad, accumulate=True)     # grad += dy^T . x
+                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad, accumulate=True, defer_ok=True)     # grad += dy^T . x
                 sink.mark_ready(weight)
             else:
                 dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype)
@@ -222,6 +268,7 @@ class _FFNFn(torch.autograd.Function):
         if not do2.is_contiguous():
             do2 = do2.contiguous()
         db1 = torch.empty(F1, dtype=torch.float32, device=x2.device) if b1 is not None else None
+        _keep(db1)
         # dh_pre = (do . W2) * dropout/activation backward, + column sums -> db1
         w2t = _bf16_weight_t(w2)
         if w2t is not None:   # W2^T [F1, Dout]: k-contiguous operand
@@ -233,7 +280,7 @@ class _FFNFn(torch.autograd.Function):
 
         def wgrad(w, g, a, n_out, k_in):
             if sink is not None and w.is_leaf and sink.accepts(w) and w.grad.dtype == torch.float32 and w.grad.is_contiguous():
-                gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out=w.grad, accumulate=True)
+                gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out=w.grad, accumulate=True, defer_ok=True)
                 sink.mark_ready(w)
                 return None
             return gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out_dtype=torch.float32).to(w.dtype)
@@ -357,6 +404,7 @@ class _LayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(xc)
         dg, db = torch.empty_like(g), torch.empty_like(b)
+        _keep(dg, db)
         ws = _ws(C.lib().tsasr_layernorm_bwd_workspace_bytes(M, D), xc.device)
         with prof.region("layernorm_bwd"):
             C.check(C.lib().tsasr_layernorm_bwd(C.ptr(dy), C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(mean), C.ptr(rstd), C.ptr(dx), C.ptr(dg),
@@ -400,6 +448,7 @@ class _BiasActDropoutFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(y)
         db = torch.empty(N, dtype=torch.float32, device=y.device) if has_bias else None
+        _keep(db)
         ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), y.device) if has_bias else None
         with prof.region("bias_act_dropout_bwd"):
             C.check(C.lib().tsasr_bias_act_dropout_bwd(C.ptr(dy), C.ptr(y), C.ptr(dx), C.ptr(db), M, N, slope, p, seed,
@@ -444,6 +493,7 @@ class _DropoutAddFn(torch.autograd.Function):
         M = dout.numel() // N
         dx = torch.empty_like(dout)
         db = torch.empty(N, dtype=torch.float32, device=dout.device) if has_bias else None
+        _keep(db)
         ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), dout.device) if has_bias else None
         with prof.region("dropout_add_bwd"):
             C.check(C.lib().tsasr_dropout_add_bwd(C.ptr(dout), C.ptr(dx), C.ptr(db), M, N, alpha, p, seed,
@@ -501,6 +551,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         dg = torch.empty(D, dtype=torch.float32, device=s_out.device)
         dbt = torch.empty_like(dg)
         db = torch.empty_like(dg) if bias_param is not None else None
+        _keep(dg, dbt, db)
         ws = _ws(C.lib().tsasr_add_layernorm_bwd_workspace_bytes(M, D), s_out.device)
         with prof.region("add_layernorm_bwd"):
             C.check(C.lib().tsasr_add_layernorm_bwd(C.ptr(dy), C.ptr(ds_in), C.ptr(s_out), C.ptr(g), C.ptr(mean), C.ptr(rstd), C.ptr(dres),
@@ -769,6 +820,7 @@ class _ConvModCoreFn(torch.autograd.Function):
         dz = dz.contiguous()
         dy2 = torch.empty_like(y2c)
         dpar = torch.empty(D * (K + 5), dtype=torch.float32, device=y2c.device)
+        _keep(dpar)
         ws = _ws(C.lib().tsasr_convmod_bwd_workspace_bytes(B, T, D, K), y2c.device)
         with prof.region("convmod_bwd"):
             C.check(C.lib().tsasr_convmod_bwd(C.ptr(dz), C.ptr(y2c), C.ptr(b2f), C.ptr(cw), C.ptr(g), C.ptr(be), C.ptr(c_save), C.ptr(mean),
