@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     }
     // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
     T *dq = dqkv + ((long long)b * Tn + iqc) * row_stride + (long long)h * 3 * Dh;
-    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * H + h) * 4 + wave) * 128;
+    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * 4 + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -558,18 +558,6 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
     }
 }
 
-__global__ void attn_uv_reduce_kernel(const float *__restrict__ slab, float *__restrict__ du, float *__restrict__ dv, int nparts,
-                                      int H, int Dh) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;  // (h, which, d)
-    if (c >= H * 128) return;
-    const int h = c / 128, which = (c % 128) / 64, d = c % 64;
-    if (d >= Dh) return;
-    float s = 0.f;
-    for (int n = 0; n < nparts; ++n)
-        for (int w = 0; w < 4; ++w) s += slab[(((size_t)n * H + h) * 4 + w) * 128 + which * 64 + d];
-    (which == 0 ? du : dv)[h * Dh + d] = s;
-}
-
 extern "C" {
 
 size_t tsasr_relpos_attn_lds_bytes(void) {
@@ -636,8 +624,12 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);
     }
-    // slab rows [(b, qtile)][h][wave][2][64] -> sum over (b, qtile, wave) per (h, which, d)
-    attn_uv_reduce_kernel<<<cdiv(H * 128, 64), 64, 0, st>>>(slab, d_bias_u, d_bias_v, B * nqt, H, Dh);
+    // slab parts [(b, qtile, wave)] x row [h][u 64 | v 64] -> sum over the parts per (h, which, d): batched with the other
+    // parameter-gradient reductions while tsasr_reduce_defer is on (csrc/reduce.hip)
+    for (int h = 0; h < H; ++h) {
+        tsasr_reduce_submit(slab + h * 128, d_bias_u + h * Dh, (long long)H * 128, 4 * B * nqt, Dh, 0, st);
+        tsasr_reduce_submit(slab + h * 128 + 64, d_bias_v + h * Dh, (long long)H * 128, 4 * B * nqt, Dh, 0, st);
+    }
     TSASR_CHECK_LAUNCH("tsasr_relpos_attn_bwd");
     return 0;
 }

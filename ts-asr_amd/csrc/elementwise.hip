@@ -618,8 +618,9 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ 
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
 static int pick_rows_per_wg(long long M, int min_rows) {
-    // ~512 workgroups (2 per CU) unless rows are few; at least `min_rows` rows each so partial slabs stay small
-    long long r = (M + 511) / 512;
+    // ~1024 workgroups (4 per CU: a wave walks its rows one after the other, so other waves must cover its memory round
+    // trips) unless rows are few; at least `min_rows` rows each so partial slabs stay small
+    long long r = (M + 1023) / 1024;
     if (r < min_rows) r = min_rows;
     return (int)r;
 }
@@ -827,7 +828,7 @@ int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, v
 }
 
 size_t tsasr_add_layernorm_bwd_workspace_bytes(long long M, int D) {
-    const int rpw = pick_rows_per_wg(M, 32);
+    const int rpw = pick_rows_per_wg(M, 8);
     return align_up((size_t)((M + rpw - 1) / rpw) * 3 * D * sizeof(float), 256);
 }
 
@@ -840,7 +841,7 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
     TSASR_CHECK_ARG(dy && s && gamma && mean && rstd && dres && dx && workspace, "tsasr_add_layernorm_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_add_layernorm_bwd: bad shape");
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_add_layernorm_bwd_workspace_bytes(M, D), "tsasr_add_layernorm_bwd: workspace too small");
-    const int rpw = pick_rows_per_wg(M, 32);
+    const int rpw = pick_rows_per_wg(M, 8);
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;

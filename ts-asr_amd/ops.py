@@ -744,6 +744,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkvc)
         dbd = torch.zeros(H, R, B, T, dtype=qkvc.dtype, device=qkvc.device)
         du, dv = torch.empty_like(u), torch.empty_like(v)
+        _keep(du, dv)
         ws = _ws(C.lib().tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), qkvc.device)
         with prof.region("relpos_attn_bwd"):
             C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
