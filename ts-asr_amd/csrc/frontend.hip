@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void fe_c1_fwd_kernel(const T *__restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy1, const T *__restrict__ dy2,
                                                         float *__restrict__ slab, int B, int Tn, int F, int C, int tmode, int fmode) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][C*12]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][C*12]
     const int To = out_len(Tn), Fo = out_len(F);
     const int cg = threadIdx.x % (C / 8), pl = threadIdx.x / (C / 8), ppb = 256 / (C / 8);
     float dw[8][9], db1[8], dw2[8], db2[8];
@@ -112,49 +112,36 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
             db2[j] += g2[j];
         }
     }
-    const int W = C * 12;
-    float *mine = red + pl * W;
+    // lanes of a wave that share a channel group differ in the position bits: fold them with xor-shuffles first, so that the
+    // workgroup needs 4 x C*12 floats of LDS (12 KB at C = 64) instead of ppb x C*12 (96 KB = one workgroup per CU, every
+    // loop iteration's memory round trip exposed) and many workgroups share a CU
+    const int W = C * 12, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cgs = C / 8;
+    for (int off = cgs; off < 64; off <<= 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = cg * 8 + j;
+        for (int j = 0; j < 8; ++j) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) mine[c * 9 + k] = dw[j][k];
-        mine[C * 9 + c] = db1[j];
-        mine[C * 10 + c] = dw2[j];
-        mine[C * 11 + c] = db2[j];
+            for (int k = 0; k < 9; ++k) dw[j][k] += __shfl_xor(dw[j][k], off, 64);
+            db1[j] += __shfl_xor(db1[j], off, 64);
+            dw2[j] += __shfl_xor(dw2[j], off, 64);
+            db2[j] += __shfl_xor(db2[j], off, 64);
+        }
+    }
+    if (lane < cgs) {
+        float *mine = red + wave * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) mine[c * 9 + k] = dw[j][k];
+            mine[C * 9 + c] = db1[j];
+            mine[C * 10 + c] = dw2[j];
+            mine[C * 11 + c] = db2[j];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < W; i += 256) {
-        float s = 0.f;
-        for (int q = 0; q < ppb; ++q) s += red[q * W + i];
-        slab[(size_t)blockIdx.x * W + i] = s;
-    }
+    for (int i = threadIdx.x; i < W; i += 256) slab[(size_t)blockIdx.x * W + i] = (red[i] + red[W + i]) + (red[2 * W + i] + red[3 * W + i]);
 }
 
-__global__ __launch_bounds__(256) void fe_colsum_kernel(const float *__restrict__ slab, float *__restrict__ out, int nparts, int width) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (col < width) {
-        int n = slice;
-        for (; n + 48 < nparts; n += 64) {  // 4 independent loads in flight per lane
-            s0 += slab[(size_t)n * width + col];
-            s1 += slab[(size_t)(n + 16) * width + col];
-            s2 += slab[(size_t)(n + 32) * width + col];
-            s3 += slab[(size_t)(n + 48) * width + col];
-        }
-        for (; n < nparts; n += 16) s0 += slab[(size_t)n * width + col];
-    }
-    red[slice][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (slice == 0 && col < width) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[q][cl];
-        out[col] = s;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // block 2: gather / inverse gather of 3x3 stride-2 taps, C-vectors of 16-byte chunks
@@ -251,7 +238,7 @@ int tsasr_frontend_c1_fwd(const void *x, const float *w1, const float *b1, const
     return 0;
 }
 
-#define FE_C1_BWD_WGS 512
+#define FE_C1_BWD_WGS 2048
 size_t tsasr_frontend_c1_bwd_workspace_bytes(int C) { return align_up((size_t)FE_C1_BWD_WGS * C * 12 * sizeof(float), 256); }
 
 /* dparams fp32 packed [dw1 C*9 | db1 C | dw2 C | db2 C], overwritten. */
@@ -262,8 +249,7 @@ int tsasr_frontend_c1_bwd(const void *x, const void *dy1, const void *dy2, float
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_frontend_c1_bwd_workspace_bytes(C), "tsasr_frontend_c1_bwd: workspace too small");
     int tm, fm;
     pad_modes(causal, &tm, &fm);
-    const int ppb = 256 / (C / 8);
-    const size_t lds = (size_t)ppb * C * 12 * sizeof(float);
+    const size_t lds = (size_t)4 * C * 12 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     if (io_dtype == TSASR_F32) {
@@ -273,7 +259,7 @@ int tsasr_frontend_c1_bwd(const void *x, const void *dy1, const void *dy2, float
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fe_c1_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         fe_c1_bwd_kernel<bf16_t><<<FE_C1_BWD_WGS, 256, lds, st>>>((const bf16_t *)x, (const bf16_t *)dy1, (const bf16_t *)dy2, slab, B, T, F, C, tm, fm);
     } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
-    fe_colsum_kernel<<<cdiv(C * 12, 16), 256, 0, st>>>(slab, dparams, FE_C1_BWD_WGS, C * 12);
+    tsasr_reduce_submit(slab, dparams, C * 12, FE_C1_BWD_WGS, C * 12, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_frontend_c1_bwd");
     return 0;
 }

@@ -635,6 +635,7 @@ class _FrontendC1Fn(torch.autograd.Function):
         causal, Co, prm = ctx.cfg
         B, T, Fq = xc.shape
         dpar = torch.empty(Co * 12, dtype=torch.float32, device=xc.device)
+        _keep(dpar)
         ws = _ws(C.lib().tsasr_frontend_c1_bwd_workspace_bytes(Co), xc.device)
         with prof.region("frontend_c1_bwd"):
             C.check(C.lib().tsasr_frontend_c1_bwd(C.ptr(xc), C.ptr(dy1.contiguous()), C.ptr(dy2.contiguous()), C.ptr(dpar), B, T, Fq, Co,
