@@ -230,7 +230,8 @@ int tsasr_frontend_c1_fwd(const void *x, const float *w1, const float *b1, const
     int tm, fm;
     pad_modes(causal, &tm, &fm);
     const long long P = (long long)B * out_len(T) * out_len(F);
-    const unsigned grid = grid_for(P * (C / 8));
+    // few, long-lived workgroups: a thread keeps its 8 x 12 filter values in registers and walks ~10 output positions with them
+    const unsigned grid = min(grid_for(P * (C / 8)), 2048u);
     if (io_dtype == TSASR_F32) fe_c1_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float *)x, w1, b1, w2, b2, (float *)y1, (float *)y2, B, T, F, C, tm, fm);
     else if (io_dtype == TSASR_BF16) fe_c1_fwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t *)x, w1, b1, w2, b2, (bf16_t *)y1, (bf16_t *)y2, B, T, F, C, tm, fm);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
