@@ -208,8 +208,9 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
 
 /* ------------------------------------------------------------------------------------------
  * LSTM cell steps of the prediction network (replaces torch.nn.LSTM behind SB/nnet/RNN.py:244-278; gate order i,f,g,o).
- * gates [B,U,4H] fp32: pre-activations (x W_ih^T + biases + h_{t-1} W_hh^T, the last term added by tsasr_gemm_bf16 with
- * accumulate) in, ACTIVATED gates out; c [B,U,H] fp32; h [B,U,H] io_dtype. One launch per time step; step t reads step t-1.
+ * gates [B,U,H,4] fp32 - GATE-MINOR: the gates (i,f,g,o) of a unit are one float4, i.e. column 4*k + g of a [B*U, 4H] matrix, so
+ * the caller permutes the rows of W_ih (and of W_hh if it adds h_{t-1} W_hh^T itself with tsasr_gemm_bf16 accumulate) from the
+ * reference's gate-major order: pre-activations in, ACTIVATED gates out; c [B,U,H] fp32; h [B,U,H] io_dtype. One launch per time step; step t reads step t-1.
  * bwd: dout [B,U,H] (gradient of the layer output), dh_rec [B,H] fp32 (= dgates_{t+1} . W_hh, ignored at t = U-1),
  * dc_io [B,H] fp32 carried between steps, dgates [B,U,4H] io_dtype out (operand of the dh / dW GEMMs).
  * ------------------------------------------------------------------------------------------ */

@@ -3,12 +3,14 @@
 //
 // Replaces torch.nn.LSTM as wrapped by speechbrain/nnet/RNN.py:244-278 (single layer, batch_first, gate order i,f,g,o).
 //   gates_t = x_t W_ih^T + b_ih + b_hh + h_{t-1} W_hh^T ;  c_t = sig(f) c_{t-1} + sig(i) tanh(g) ;  h_t = sig(o) tanh(c_t)
-// Layout: gates [B, U, 4H] fp32 (pre-activations in, ACTIVATED gates out - kept for the backward), c [B, U, H] fp32,
+// Layout: gates [B, U, H, 4] fp32 - the four gates (i,f,g,o) of a unit are ONE float4 (the caller permutes the rows of W_ih
+// accordingly; pre-activations in, ACTIVATED gates out - kept for the backward); dgates [B, U, 4H] gate-major; c [B, U, H] fp32,
 // h [B, U, H] in the activation dtype (it is the next step's GEMM operand and the layer output).
 #include "common.h"
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) / (1.f + e); return x < 0.f ? -t : t; }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence: 5 transcendentals per cell sit on the recurrence's critical path
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { const float e = __expf(-2.f * fabsf(x)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); return x < 0.f ? -t : t; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *__restrict__ gates, float *__restrict__ c, T *__restrict__ h, int B,
@@ -16,11 +18,12 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float *__restrict__ 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, k = i % H;
-    float *g = gates + ((long long)b * U + t) * 4 * H;
-    const float gi = sigm(g[k]), gf = sigm(g[H + k]), gg = tanh_fast(g[2 * H + k]), go = sigm(g[3 * H + k]);
+    float4 *g = reinterpret_cast<float4 *>(gates + (((long long)b * U + t) * H + k) * 4);
+    const float4 pre4 = *g;
+    const float gi = sigm(pre4.x), gf = sigm(pre4.y), gg = tanh_fast(pre4.z), go = sigm(pre4.w);
     const float cp = t > 0 ? c[((long long)b * U + t - 1) * H + k] : 0.f;
     const float cn = gf * cp + gi * gg;
-    g[k] = gi; g[H + k] = gf; g[2 * H + k] = gg; g[3 * H + k] = go;
+    *g = make_float4(gi, gf, gg, go);
     c[((long long)b * U + t) * H + k] = cn;
     st1(h + ((long long)b * U + t) * H + k, go * tanh_fast(cn));
 }
@@ -34,8 +37,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float *__restr
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * H) return;
     const int b = i / H, k = i % H;
-    const float *g = gates + ((long long)b * U + t) * 4 * H;
-    const float gi = g[k], gf = g[H + k], gg = g[2 * H + k], go = g[3 * H + k];
+    const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)b * U + t) * H + k) * 4);
+    const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
     const float cn = c[((long long)b * U + t) * H + k];
     const float cp = t > 0 ? c[((long long)b * U + t - 1) * H + k] : 0.f;
     const float tc = tanh_fast(cn);
@@ -103,11 +106,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float *__restrict__ 
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[g] = red[0][bl][16 * g + j] + red[1][bl][16 * g + j] + red[2][bl][16 * g + j] + red[3][bl][16 * g + j];
-        float *gp = gates + ((long long)b * U + t) * 4 * H;
-        const float gi = sigm(gp[k] + pre[0]), gf = sigm(gp[H + k] + pre[1]), gg = tanh_fast(gp[2 * H + k] + pre[2]), go = sigm(gp[3 * H + k] + pre[3]);
+        float4 *gp = reinterpret_cast<float4 *>(gates + (((long long)b * U + t) * H + k) * 4);
+        const float4 gx4 = *gp;
+        const float gi = sigm(gx4.x + pre[0]), gf = sigm(gx4.y + pre[1]), gg = tanh_fast(gx4.z + pre[2]), go = sigm(gx4.w + pre[3]);
         const float cp = t > 0 ? c[((long long)b * U + t - 1) * H + k] : 0.f;
         const float cn = gf * cp + gi * gg;
-        gp[k] = gi; gp[H + k] = gf; gp[2 * H + k] = gg; gp[3 * H + k] = go;
+        *gp = make_float4(gi, gf, gg, go);
         c[((long long)b * U + t) * H + k] = cn;
         st1(h + ((long long)b * U + t) * H + k, go * tanh_fast(cn));
     }
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
         const int bl = i / LS_UN, j = i % LS_UN, b = b0 + bl, k = u0 + j;
         if (b >= B) continue;
         const float dh_rec = red[0][bl][j] + red[1][bl][j] + red[2][bl][j] + red[3][bl][j];
-        const float *g = gates + ((long long)b * U + t) * 4 * H;
-        const float gi = g[k], gf = g[H + k], gg = g[2 * H + k], go = g[3 * H + k];
+        const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)b * U + t) * H + k) * 4);
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
         const float cn = c[((long long)b * U + t) * H + k];
         const float cp = t > 0 ? c[((long long)b * U + t - 1) * H + k] : 0.f;
         const float tc = tanh_fast(cn);
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
     constexpr int KS = H / 16, NWG = H / LQ_UN;
     __shared__ __attribute__((aligned(16))) float pre[32][LQ_UN * 4 + 4];   // [batch][unit*4 + gate]
     __shared__ __attribute__((aligned(16))) bf16_t hs[32][LQ_UN];            // this step's h tile, laid out as it is published
+    __shared__ __attribute__((aligned(16))) bf16_t hl[(H / 32) * 32 * 40];   // h_{t-1}: [unit block][batch row][32 + 8 pad]
     __shared__ int ok_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * 32;
@@ -223,29 +228,47 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
     }
     float cprev[4] = {0.f, 0.f, 0.f, 0.f};
     bool failed = false;
+#ifdef LQ_PROFILE
+    long long acc_t[5] = {0, 0, 0, 0, 0}, t_prev = clock64();
+#define LQ_STAMP(i) do { const long long n_ = clock64(); acc_t[i] += n_ - t_prev; t_prev = n_; } while (0)
+#else
+#define LQ_STAMP(i)
+#endif
 #pragma unroll 1
     for (int t = 0; t < U; ++t) {
         float gx[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {   // x-part pre-activations of this thread's four (batch, unit) pairs: in flight across the wait
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
-            const float *gp = gates + ((long long)min(b0 + bl, B - 1) * U + t) * 4 * H + u0 + ul;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gx[j][g] = gp[g * H];
+            const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)min(b0 + bl, B - 1) * U + t) * H + u0 + ul) * 4);
+            gx[j][0] = g4.x; gx[j][1] = g4.y; gx[j][2] = g4.z; gx[j][3] = g4.w;
         }
         f32x16 acc = {0};
         if (t > 0) {
             if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * t), err) ? 1 : 0;
             __syncthreads();
             if (!ok_flag) { failed = true; break; }
-            const int base = (t - 1) * NWG * 1024 + r * 32 + 8 * hh;   // elements; + (s >> 1) * 1024 + (s & 1) * 16
-            u32x4 raw[KS];   // all of h_{t-1} for this lane's batch row requested at once: ONE memory round trip per step
+            LQ_STAMP(0);   // wait for h_{t-1}
+            // h_{t-1} [32 x H] enters the workgroup ONCE (each thread NLD coalesced 16-byte sc1 loads, all requested together),
+            // is laid out in LDS as [unit block][batch row][32 + 8 pad] and feeds the four waves' B fragments from there
+            // (s_memtime: the per-wave loads of the whole tile took 44% of a step)
+            constexpr int NLD = H * 32 / 8 / 256;
+            u32x4 raw[NLD];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) raw[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (base + (s >> 1) * 1024 + (s & 1) * 16) * 2, 0, 16);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < NLD; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((t - 1) * NWG * 1024 + (tid + 256 * i) * 8) * 2, 0, 16);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], __builtin_bit_cast(bf16x8, raw[s]), acc, 0, 0, 0);
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = tid + 256 * i;
+                *reinterpret_cast<u32x4 *>(&hl[((ch >> 7) * 32 + ((ch & 127) >> 2)) * 40 + (ch & 3) * 8]) = raw[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&hl[((s >> 1) * 32 + r) * 40 + (s & 1) * 16 + 8 * hh]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfrag, acc, 0, 0, 0);
+            }
         }
+        LQ_STAMP(1);   // operand loads + MFMA
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -259,13 +282,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
             cprev[j] = cn;
             const float hv = go * tanh_fast(cn);
             if (b < B) {
-                float *gp = gates + ((long long)b * U + t) * 4 * H + u0 + ul;
-                gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+                *reinterpret_cast<float4 *>(gates + (((long long)b * U + t) * H + u0 + ul) * 4) = make_float4(gi, gf, gg, go);
                 c[((long long)b * U + t) * H + u0 + ul] = cn;
             }
             hs[bl][ul] = (bf16_t)(b < B ? hv : 0.f);
         }
         __syncthreads();
+        LQ_STAMP(2);   // cell math
         if (wave < 2) {   // 2 KB tile: two wave-instructions of 1 KiB (whole 128-byte lines), write-through
             const int ch = wave * 64 + lane, bl = ch >> 2, part = ch & 3;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(&hs[bl][part * 8]);
@@ -274,8 +297,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LQ_STAMP(3);   // publish + drain
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LQ_STAMP(4);
     }
+#ifdef LQ_PROFILE
+    if (tid == 0 && wg == 3 && bg == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<long long *>(sync + 16)[i] = acc_t[i];
+#endif
     if (failed && tid == 0) h[((long long)min(b0, B - 1) * U + U - 1) * H + u0] = (bf16_t)__builtin_nanf("");
 }
 
@@ -311,9 +339,8 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = min(b0 + bl, B - 1);
-            const float *gp = gates + ((long long)b * U + t) * K4 + u0 + ul;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gv[j][g] = gp[g * H];
+            const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)b * U + t) * H + u0 + ul) * 4);
+            gv[j][0] = g4.x; gv[j][1] = g4.y; gv[j][2] = g4.z; gv[j][3] = g4.w;
             cn[j] = c[((long long)b * U + t) * H + u0 + ul];
             cpv[j] = t > 0 ? c[((long long)b * U + t - 1) * H + u0 + ul] : 0.f;
             dov[j] = (float)dout[((long long)b * U + t) * H + u0 + ul];

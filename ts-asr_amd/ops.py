@@ -326,7 +326,9 @@ class _LstmFn(torch.autograd.Function):
         B, U, I = x.shape
         H = w_hh.shape[1]
         dev = x.device
-        gates = F.linear(x.float(), w_ih.float(), (b_ih + b_hh).float()).contiguous()       # [B,U,4H] fp32
+        # x-part of the gate pre-activations, laid out [B,U,H,4] (gate-minor: the kernels move a unit's four gates as one float4)
+        perm = lambda t: t.view(4, H, *t.shape[1:]).transpose(0, 1).reshape(t.shape)  # noqa: E731
+        gates = F.linear(x.float(), perm(w_ih.float()), perm((b_ih + b_hh).float())).contiguous()
         c = torch.empty(B, U, H, dtype=torch.float32, device=dev)
         h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
         whh16 = _bf16_weight(w_hh).contiguous()
