@@ -156,6 +156,23 @@ __device__ __forceinline__ void load_a_frags(const float *__restrict__ dl_row, b
     }
 }
 
+// Unconditional forms for the software-pipelined loops (ldl == 32: a dlogits row is one 128-byte line). A conditional load sits
+// in its own basic block and is waited for on the spot - s_memtime stamps showed 90% of both backward kernels in exposed load
+// latency - so addresses are clamped, the load is always issued, and invalid rows are zeroed when the fragment is built.
+__device__ __forceinline__ void load_a_raw32(const float *__restrict__ dl_row, int h, float (&af)[2][8]) {
+    ld8(dl_row + 8 * h, af[0]);
+    ld8(dl_row + 16 + 8 * h, af[1]);
+}
+__device__ __forceinline__ void cvt_a(float (&af)[2][8], bool valid, bf16x8 (&a)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            af[s][j] = valid ? af[s][j] : 0.f;
+            a[s][j] = (bf16_t)af[s][j];
+        }
+}
+
 // u index (within the 32-row tile) of accumulator register g for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
@@ -178,14 +195,23 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
     load_w_frags(f, W, J, V, wslot, nslots, r, h);
     float dv[KB][16], dacc[KB][16];
     f32x16 wacc[KB];
+    int kbc[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) {
-        wacc[i] = (f32x16){0};
+    for (int i = 0; i < KB; ++i) kbc[i] = max(f.kb[i], 0);
+    {
+        T raw[KB][16];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int u = u0 + acc_row(g, h);
-            dv[i][g] = (f.kb[i] >= 0 && u < U1) ? ld1(dec + ((size_t)b * U1 + u) * J + f.kb[i] * 32 + r) : 0.f;
-            dacc[i][g] = 0.f;
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) raw[i][g] = dec[((size_t)b * U1 + min(u0 + acc_row(g, h), U1 - 1)) * J + kbc[i] * 32 + r];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            wacc[i] = (f32x16){0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                dv[i][g] = (f.kb[i] >= 0 && u0 + acc_row(g, h) < U1) ? (float)raw[i][g] : 0.f;
+                dacc[i][g] = 0.f;
+            }
         }
     }
     float bsum[2][8];
@@ -196,10 +222,36 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
 
     bf16_t *my_lds = a_lds[wave];
     const bool row_ok = (u0 + r) < U1;
+    // software pipeline over the frames (ldl == 32): frame t+1's dlogits row and enc values are requested before frame t's MFMAs
+    const bool pipe = (ldl == 32);
+    const float *dl0 = dlogits + (((size_t)b * Tn) * U1 + min(u0 + r, U1 - 1)) * 32;
+    float afn[2][8];
+    T en[KB];
+    if (pipe && t_end > 0) {
+        load_a_raw32(dl0, h, afn);
+#pragma unroll
+        for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn) * J + kbc[i] * 32 + r];
+    }
     for (int t = 0; t < t_end; ++t) {
         bf16x8 a[2];
-        float af[2][8];
-        load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+        float af[2][8], ev[KB];
+        if (pipe) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) af[s2][j] = afn[s2][j];
+#pragma unroll
+            for (int i = 0; i < KB; ++i) ev[i] = (float)en[i];
+            const int tn = min(t + 1, Tn - 1);
+            load_a_raw32(dl0 + (size_t)tn * U1 * 32, h, afn);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + tn) * J + kbc[i] * 32 + r];
+            cvt_a(af, row_ok, a);
+        } else {
+            load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) ev[i] = f.kb[i] >= 0 ? ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r) : 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -215,8 +267,8 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
             for (int j = 0; j < 8; ++j) at[s][j] = my_lds[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * 32 + r];
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
-            if (f.kb[i] < 0) continue;
-            const float e = ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r);
+            if (f.kb[i] < 0) continue;   // wave-uniform
+            const float e = ev[i];
             f32x16 D = {0};
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
@@ -275,39 +327,99 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_y_kernel(
 #pragma unroll
         for (int i = 0; i < KB; ++i) eacc[tt][i] = 0.f;
     const int nt = max(0, min(TG, Tb - t0));
+#ifdef JY_PROFILE
+    long long acc_t[4] = {0, 0, 0, 0}, t_prev = clock64();
+#define JY_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long n_ = clock64(); acc_t[i] += n_ - t_prev; t_prev = n_; } while (0)
+#else
+#define JY_STAMP(i)
+#endif
     if (nt > 0) {
+        int kbc[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) kbc[i] = max(f.kb[i], 0);
         for (int u0 = 0; u0 <= Ub; u0 += 32) {
             float dv[KB][16];
+            {   // dec values of the u tile: all requested together (clamped addresses), masked afterwards
+                T raw[KB][16];
 #pragma unroll
-            for (int i = 0; i < KB; ++i)
+                for (int i = 0; i < KB; ++i)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int u = u0 + acc_row(g, h);
-                    dv[i][g] = (f.kb[i] >= 0 && u < U1) ? ld1(dec + ((size_t)b * U1 + u) * J + f.kb[i] * 32 + r) : 0.f;
-                }
+                    for (int g = 0; g < 16; ++g) raw[i][g] = dec[((size_t)b * U1 + min(u0 + acc_row(g, h), U1 - 1)) * J + kbc[i] * 32 + r];
+#pragma unroll
+                for (int i = 0; i < KB; ++i)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) dv[i][g] = (f.kb[i] >= 0 && u0 + acc_row(g, h) < U1) ? (float)raw[i][g] : 0.f;
+            }
             const bool row_ok = (u0 + r) < U1;
+            JY_STAMP(0);   // dec values of the u tile
+            if (ldl == 32) {
+                // software pipeline over the TG frames: frame tt+1's dlogits row and enc values are in flight during frame tt
+                const float *dl0 = dlogits + (((size_t)b * Tn) * U1 + min(u0 + r, U1 - 1)) * 32;
+                float afn[2][8];
+                T en[KB];
+                load_a_raw32(dl0 + (size_t)t0 * U1 * 32, h, afn);
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                if (tt >= nt) continue;
-                const int t = t0 + tt;
-                bf16x8 a[2];
-                float af[2][8];
-                load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+                for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + t0) * J + kbc[i] * 32 + r];
 #pragma unroll
-                for (int i = 0; i < KB; ++i) {
-                    if (f.kb[i] < 0) continue;
-                    const float e = ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r);
-                    f32x16 D = {0};
-                    D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
-                    D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
-                    float sacc = 0.f;
+                for (int tt = 0; tt < TG; ++tt) {
+                    float af[2][8], e[KB];
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) sacc += ((e + dv[i][g]) > 0.f) ? D[g] : slope * D[g];
-                    eacc[tt][i] += sacc;
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) af[s2][j] = afn[s2][j];
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) e[i] = (float)en[i];
+                    if (tt + 1 < TG) {
+                        const int tn = min(t0 + tt + 1, Tn - 1);
+                        load_a_raw32(dl0 + (size_t)tn * U1 * 32, h, afn);
+#pragma unroll
+                        for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + tn) * J + kbc[i] * 32 + r];
+                    }
+                    bf16x8 a[2];
+                    cvt_a(af, row_ok && tt < nt, a);
+                    JY_STAMP(1);
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) {
+                        f32x16 D = {0};
+                        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) sacc += ((e[i] + dv[i][g]) > 0.f) ? D[g] : slope * D[g];
+                        eacc[tt][i] += sacc;   // rows of dead frames / absent k-blocks are zero: a == 0 or wf == 0
+                    }
+                    JY_STAMP(2);
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt) {
+                    if (tt >= nt) continue;
+                    const int t = t0 + tt;
+                    bf16x8 a[2];
+                    float af[2][8];
+                    load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) {
+                        if (f.kb[i] < 0) continue;
+                        const float e = ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r);
+                        f32x16 D = {0};
+                        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) sacc += ((e + dv[i][g]) > 0.f) ? D[g] : slope * D[g];
+                        eacc[tt][i] += sacc;
+                    }
                 }
             }
         }
     }
+#ifdef JY_PROFILE
+    if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 0 && b == 3) {
+        long long *o = reinterpret_cast<long long *>(const_cast<T *>(dec));   // probe build only: clobbers 24 bytes of an input
+        for (int i = 0; i < 3; ++i) o[i] = acc_t[i];
+    }
+#endif
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) {
         const int t = t0 + tt;
