@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void fe_c1_fwd_kernel(const T *__restrict__ x,
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) {
                 const int fi = src_index(fo, kf, F, fmode);
-                a[kf * 3 + kt] = (ti >= 0 && fi >= 0) ? ld1(x + ((size_t)b * Tn + ti) * F + fi) : 0.f;  // weight index = kf*3 + kt
+                // always issued (clamped address), masked afterwards: a conditional load is waited for where it stands
+                const float xv = ld1(x + ((size_t)b * Tn + max(ti, 0)) * F + max(fi, 0));
+                a[kf * 3 + kt] = (ti >= 0 && fi >= 0) ? xv : 0.f;  // weight index = kf*3 + kt
             }
         }
         const float centre = ld1(x + ((size_t)b * Tn + 2 * to) * F + 2 * fo);  // 1x1 stride-2 conv: no padding
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) {
                 const int fi = src_index(fo, kf, F, fmode);
-                a[kf * 3 + kt] = (ti >= 0 && fi >= 0) ? ld1(x + ((size_t)b * Tn + ti) * F + fi) : 0.f;
+                const float xv = ld1(x + ((size_t)b * Tn + max(ti, 0)) * F + max(fi, 0));
+                a[kf * 3 + kt] = (ti >= 0 && fi >= 0) ? xv : 0.f;
             }
         }
         const float centre = ld1(x + ((size_t)b * Tn + 2 * to) * F + 2 * fo);
