@@ -77,8 +77,30 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
     const bf16_t *wrow = w_lds + r * S + 8 * h;
     const T *drow = d_lds + r * S + 8 * h;
     const int nks = J / 16;
+    // The enc row of a frame is the same for all 64 lanes: it is fetched ONCE per wave (coalesced 16-byte pieces, one frame
+    // ahead, held in registers across the MFMA loop) into a per-wave LDS row and read from there as broadcasts, instead of
+    // every lane re-requesting it from global memory in every k-step (40 exposed round trips per frame).
+    constexpr int VE = 16 / sizeof(T);
+    T *e_w = d_lds + 32 * S + wave * J;                   // [4 waves][J]
+    uint4 stg[3];                                         // J <= 3 * 64 * VE (checked on the host)
+    auto request = [&](int t) {
+        const T *src = enc + ((size_t)b * Tn + min(t, Tn - 1)) * J;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int c = (q * 64 + lane) * VE;
+            stg[q] = *reinterpret_cast<const uint4 *>(src + min(c, J - VE));
+        }
+    };
+    request(t_begin + wave);
     for (int t = t_begin + wave; t < t_end; t += 4) {
-        const T *erow = enc + ((size_t)b * Tn + t) * J + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int c = (q * 64 + lane) * VE;
+            if (c < J) *reinterpret_cast<uint4 *>(e_w + c) = stg[q];
+        }
+        request(t + 4);                                   // next frame of this wave: in flight during the k-loop below
+        __builtin_amdgcn_wave_barrier();
+        const T *erow = e_w + 8 * h;
         f32x16 acc = {0};
 #pragma unroll 4
         for (int s = 0; s < nks; ++s) {
@@ -661,7 +683,9 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
     TSASR_CHECK_ARG(J > 0 && J % 16 == 0, "tsasr_joint_fwd: J=%d must be a multiple of 16", J);
     TSASR_CHECK_ARG(V > 0 && V <= 32, "tsasr_joint_fwd: V=%d not supported (1..32)", V);
     TSASR_CHECK_ARG(ldl >= V && ldl % 4 == 0 && ldl <= 32, "tsasr_joint_fwd: ldl=%d must be a multiple of 4 in [V,32]", ldl);
-    const size_t lds = (size_t)32 * lds_stride(J) * (sizeof(bf16_t) + (io_dtype == TSASR_F32 ? sizeof(float) : sizeof(bf16_t)));
+    const size_t esz = io_dtype == TSASR_F32 ? sizeof(float) : sizeof(bf16_t);
+    const size_t lds = (size_t)32 * lds_stride(J) * (sizeof(bf16_t) + esz) + (size_t)4 * J * esz;   // W tile, dec tile, one enc row per wave
+    TSASR_CHECK_ARG((size_t)J * esz <= 3 * 64 * 16, "tsasr_joint_fwd: J=%d too wide for the per-wave row staging", J);
     TSASR_CHECK_ARG(lds <= 160 * 1024, "tsasr_joint_fwd: J=%d needs %zu B of LDS (>160 KiB)", J, lds);
     const int nut = cdiv(U1, 32);
     int tsplit = 1;  // enough workgroups to cover 256 CUs twice, at least 8 frames per wave
