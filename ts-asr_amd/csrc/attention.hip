@@ -33,26 +33,51 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-// stage `rows` rows of Dh elements (row r -> src + r*src_stride, or zeros when r is outside [lo,hi)) into lds[rows][AT_LD]
+// Loads in these kernels are ALWAYS issued (clamped addresses) and masked afterwards: a conditional load lives in its own basic
+// block and is waited for where it stands, so a prologue of 160 guarded element loads or a staging loop of six guarded row
+// pieces costs that many serialized memory round trips (the same finding as in csrc/rnnt.hip's backward kernels).
+
+// 8 consecutive elements row[d0 .. d0+8), zero at and beyond Dh. fast: Dh % 8 == 0 (16-byte aligned pieces)
 template <typename T>
-__device__ __forceinline__ void stage_rows(bf16_t *lds, const T *src, long long src_stride, int first_row, int lo, int hi, int rows,
-                                           int Dh) {
-    const bool vec_ok = (Dh % (16 / (int)sizeof(T))) == 0;  // 16-byte aligned 8-element groups
-    for (int i = threadIdx.x; i < rows * (AT_DP / 8); i += 256) {
-        const int rr = i / (AT_DP / 8), c = (i % (AT_DP / 8)) * 8;
-        const int r = first_row + rr;
-        float v[8];
+__device__ __forceinline__ void load8_clamped(const T *__restrict__ row, int d0, int Dh, bool fast, float (&v)[8]) {
+    if (fast) {
+        ld8(row + min(d0, Dh - 8), v);
+        if (d0 >= Dh) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (r >= lo && r < hi) {
-            const T *p = src + (long long)r * src_stride + c;
-            if (vec_ok && c + 8 <= Dh) ld8(p, v);
-            else {
-                for (int j = 0; j < 8; ++j)
-                    if (c + j < Dh) v[j] = ld1(p + j);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
         }
-        st8(lds + rr * AT_LD + c, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = ld1(row + min(d0 + j, Dh - 1));
+            v[j] = (d0 + j < Dh) ? x : 0.f;
+        }
+    }
+}
+
+// stage ROWS rows of Dh elements (row r -> src + r*src_stride, or zeros when r is outside [lo,hi)) into lds[ROWS][AT_LD]:
+// all of a thread's pieces are requested before the first one is stored
+template <typename T, int ROWS>
+__device__ __forceinline__ void stage_rows(bf16_t *lds, const T *__restrict__ src, long long src_stride, int first_row, int lo, int hi,
+                                           int Dh) {
+    constexpr int NIT = ROWS * (AT_DP / 8) / 256;
+    static_assert(ROWS * (AT_DP / 8) % 256 == 0, "whole passes of the workgroup");
+    const bool fast = (Dh % 8) == 0;
+    const int c = (threadIdx.x % (AT_DP / 8)) * 8;      // 256 % (AT_DP / 8) == 0: one column group per thread
+    float v[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = (threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+        load8_clamped<T>(src + (long long)min(max(r, lo), hi - 1) * src_stride, c, Dh, fast, v[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int rr = (threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+        if (r < lo || r >= hi) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[it][j] = 0.f;
+        }
+        st8(lds + rr * AT_LD + c, v[it]);
     }
 }
 
@@ -81,20 +106,23 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
 
     // Q + u, Q + v as B operands: lane (i = r, hh) holds dims 16s + 8hh + [0,8)
     bf16x8 qu[4], qv[4];
+    {
+        const bool fast = (Dh % 8) == 0;
+        float q8[4][8], u8[4][8], v8[4][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * s + 8 * hh + j;
-            float q = 0.f, uu = 0.f, vv = 0.f;
-            if (d < Dh) {
-                q = ld1(q_base + (long long)iqc * row_stride + d);
-                uu = bias_u[h * Dh + d];
-                vv = bias_v[h * Dh + d];
-            }
-            qu[s][j] = (bf16_t)(q + uu);
-            qv[s][j] = (bf16_t)(q + vv);
+        for (int s = 0; s < 4; ++s) {
+            load8_clamped<T>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, fast, q8[s]);
+            load8_clamped<float>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, fast, u8[s]);
+            load8_clamped<float>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = 16 * s + 8 * hh + j < Dh;
+                qu[s][j] = (bf16_t)(ok ? q8[s][j] + u8[s][j] : 0.f);
+                qv[s][j] = (bf16_t)(ok ? q8[s][j] + v8[s][j] : 0.f);
+            }
     }
     f32x16 o_acc[2];
     o_acc[0] = (f32x16){0};
@@ -108,10 +136,10 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
     if (causal) j_end = min(j_end, i0 + AT_QB);  // keys beyond the last query of the workgroup are never attended
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();  // previous tile fully consumed
-        stage_rows<T>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
-        stage_rows<T>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
+        stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
         // band row R <-> r = j0 - i0 - (AT_QB - 1) + Tn - 1 + R
-        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, AT_BAND, Dh);
+        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -247,23 +275,28 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     float delta = 0.f;
     const T *orow = out + ((long long)b * Tn + iqc) * D + (long long)h * Dh;
     const T *dorow = dout + ((long long)b * Tn + iqc) * D + (long long)h * Dh;
+    {
+        const bool fast = (Dh % 8) == 0;
+        float q8[4][8], u8[4][8], v8[4][8], d8[4][8], o8[4][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * s + 8 * hh + j;
-            float q = 0.f, uu = 0.f, vv = 0.f, dd = 0.f, oo = 0.f;
-            if (d < Dh) {
-                q = ld1(q_base + (long long)iqc * row_stride + d);
-                uu = bias_u[h * Dh + d];
-                vv = bias_v[h * Dh + d];
-                if (q_ok) { dd = ld1(dorow + d); oo = ld1(orow + d); }
-            }
-            qu[s][j] = (bf16_t)(q + uu);
-            qv[s][j] = (bf16_t)(q + vv);
-            dob[s][j] = (bf16_t)dd;
-            delta += dd * oo;
+        for (int s = 0; s < 4; ++s) {
+            load8_clamped<T>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, fast, q8[s]);
+            load8_clamped<float>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, fast, u8[s]);
+            load8_clamped<float>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
+            load8_clamped<T>(dorow, 16 * s + 8 * hh, Dh, fast, d8[s]);
+            load8_clamped<T>(orow, 16 * s + 8 * hh, Dh, fast, o8[s]);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = 16 * s + 8 * hh + j < Dh;
+                const float dd = q_ok ? d8[s][j] : 0.f, oo = q_ok ? o8[s][j] : 0.f;
+                qu[s][j] = (bf16_t)(ok ? q8[s][j] + u8[s][j] : 0.f);
+                qv[s][j] = (bf16_t)(ok ? q8[s][j] + v8[s][j] : 0.f);
+                dob[s][j] = (bf16_t)dd;
+                delta += dd * oo;
+            }
     }
     delta += __shfl_xor(delta, 32, 64);
     const float lse_i = lse[((long long)b * H + h) * Tn + iqc];
@@ -278,10 +311,10 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     if (causal) j_end = min(j_end, i0 + AT_QB);
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();
-        stage_rows<T>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
-        stage_rows<T>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, AT_KT, Dh);
+        stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
+        stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
         const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
-        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, AT_BAND, Dh);
+        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -423,63 +456,74 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
     const bool k_live = jk < len;                                   // masked / out-of-range keys get zero gradients
 
     bf16x8 kb[4], vb[4];
+    {
+        const bool fast = (Dh % 8) == 0;
+        float k8[4][8], v8[4][8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * s + 8 * hh + j;
-            kb[s][j] = (bf16_t)((d < Dh) ? ld1(q_base + (long long)jkc * row_stride + Dh + d) : 0.f);
-            vb[s][j] = (bf16_t)((d < Dh) ? ld1(q_base + (long long)jkc * row_stride + 2 * Dh + d) : 0.f);
+        for (int s = 0; s < 4; ++s) {
+            load8_clamped<T>(q_base + (long long)jkc * row_stride + Dh, 16 * s + 8 * hh, Dh, fast, k8[s]);
+            load8_clamped<T>(q_base + (long long)jkc * row_stride + 2 * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kb[s][j] = (bf16_t)k8[s][j]; vb[s][j] = (bf16_t)v8[s][j]; }
+    }
     f32x16 dk[2], dv[2];
     dk[0] = dk[1] = dv[0] = dv[1] = (f32x16){0};
     const unsigned thr = drop_thr16(pdrop);
     const float keep_scale = drop_scale16(thr);
     const DropKey dkey = drop_key(seed);
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const bool vec_ok = (Dh % (16 / (int)sizeof(T))) == 0;
+    const bool fast_d = (Dh % 8) == 0;
+    float bu8[8], bv8[8];   // this thread's 8 bias columns in the staging passes (256 % 8 == 0: fixed per thread)
+    load8_clamped<float>(bias_u + h * Dh, (tid % (AT_DP / 8)) * 8, Dh, fast_d, bu8);
+    load8_clamped<float>(bias_v + h * Dh, (tid % (AT_DP / 8)) * 8, Dh, fast_d, bv8);
 
     const int i_begin = causal ? (j0 / AT_KT) * AT_KT : 0;   // queries before the first key of the workgroup never see it
     for (int i0 = i_begin; i0 < Tn; i0 += AT_KT) {
         __syncthreads();
-        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta
-        for (int idx = tid; idx < AT_KT * (AT_DP / 8); idx += 256) {
-            const int rr = idx / (AT_DP / 8), c = (idx % (AT_DP / 8)) * 8;
-            const int i = i0 + rr;
-            float q[8], d8[8], o8[8], a[8], c8[8];
+        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta: two passes of the workgroup, all loads of both requested first
+        {
+            constexpr int NIT = AT_KT * (AT_DP / 8) / 256;
+            const int c = (tid % (AT_DP / 8)) * 8;
+            float q[NIT][8], d8[NIT][8], o8[NIT][8], lse_v[NIT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[j] = d8[j] = o8[j] = 0.f;
-            if (i < Tn) {
-                const T *qp = q_base + (long long)i * row_stride + c;
-                const T *dp = dout + ((long long)b * Tn + i) * D + (long long)h * Dh + c;
-                const T *op = out + ((long long)b * Tn + i) * D + (long long)h * Dh + c;
-                if (vec_ok && c + 8 <= Dh) { ld8(qp, q); ld8(dp, d8); ld8(op, o8); }
-                else {
-                    for (int j = 0; j < 8; ++j)
-                        if (c + j < Dh) { q[j] = ld1(qp + j); d8[j] = ld1(dp + j); o8[j] = ld1(op + j); }
+            for (int it = 0; it < NIT; ++it) {
+                const int rr = (tid + it * 256) / (AT_DP / 8), ic = min(i0 + rr, Tn - 1);
+                load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, q[it]);
+                load8_clamped<T>(dout + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, d8[it]);
+                load8_clamped<T>(out + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, o8[it]);
+                lse_v[it] = lse[((long long)b * H + h) * Tn + ic];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rr = (tid + it * 256) / (AT_DP / 8);
+                const bool live = i0 + rr < Tn;
+                float a[8], c8[8], dd[8];
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = live && (c + j) < Dh;
+                    a[j] = ok ? q[it][j] + bu8[j] : 0.f;
+                    c8[j] = ok ? q[it][j] + bv8[j] : 0.f;
+                    dd[j] = live ? d8[it][j] : 0.f;
+                    part += dd[j] * (live ? o8[it][j] : 0.f);
                 }
-            }
-            float part = 0.f;
+                st8(qu_lds + rr * AT_LD + c, a);
+                st8(qv_lds + rr * AT_LD + c, c8);
+                st8(do_lds + rr * AT_LD + c, dd);
+                // delta: 8 consecutive threads hold the 8 column chunks of one row
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = (c + j) < Dh;
-                a[j] = ok ? q[j] + bias_u[h * Dh + c + j] : 0.f;
-                c8[j] = ok ? q[j] + bias_v[h * Dh + c + j] : 0.f;
-                part += d8[j] * o8[j];
-            }
-            st8(qu_lds + rr * AT_LD + c, a);
-            st8(qv_lds + rr * AT_LD + c, c8);
-            st8(do_lds + rr * AT_LD + c, d8);
-            // delta: 8 consecutive threads hold the 8 column chunks of one row
-#pragma unroll
-            for (int o = 4; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-            if ((idx % (AT_DP / 8)) == 0) {
-                st_lds[64 + rr] = part;
-                st_lds[rr] = (i < Tn) ? lse[((long long)b * H + h) * Tn + i] : 0.f;
+                for (int o = 4; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                if ((tid % (AT_DP / 8)) == 0) {
+                    st_lds[64 + rr] = part;
+                    st_lds[rr] = live ? lse_v[it] : 0.f;
+                }
             }
         }
         const int r_first = j0 - i0 - (AT_KT - 1) + Tn - 1;  // band row R <-> r = r_first + R ; keys [j0,j0+128) x queries [i0,i0+64)
-        stage_rows<T>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, AT_BAND, Dh);
+        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
