@@ -5,7 +5,7 @@
 // the split-K fp32 slabs of a weight-gradient GEMM. Launched one by one these are ~310 tiny kernels per training step, each
 // paying the ~4.7 us floor of a dependent launch inside the step's hipGraph (1.5 ms of a 27 ms step). While deferral is on
 // (gradient arena, between begin_backward and finish_backward) the producers only QUEUE a job; tsasr_reduce_flush then runs all
-// of them in ONE launch. Summation order inside a job is fixed (slices of 16 partial rows, combined in index order), so results
+// of them in ONE launch. Summation order inside a job is fixed (interleaved row slices, combined in index order), so results
 // are bit-identical between the immediate and the batched path and from run to run - no float atomics anywhere.
 #include <string.h>
 
@@ -20,11 +20,12 @@ struct ReduceJob {
     int nparts, width, accumulate, tile0, wide, pad_;
 };
 
-// tall jobs (many partial rows, few columns): tile = 16 columns, 16 row slices per workgroup, slices combined through LDS
+// tall jobs (many partial rows, few columns): tile = 64 columns (256-byte row pieces), 4 row slices per workgroup, combined through LDS
 // wide jobs (few slabs, many columns):        tile = 1024 columns, one thread = 4 consecutive columns, 16-byte slab loads
 #define RD_WIDE_TILE 1024
+#define RD_TALL_COLS 64
 
-__device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*red)[17]) {
+__device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*red)[RD_TALL_COLS + 1]) {
     if (j.wide) {
         const int c = lt * RD_WIDE_TILE + threadIdx.x * 4;
         if (c >= j.width) return;
@@ -44,36 +45,34 @@ __device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*
         }
         return;
     }
-    const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4, col = lt * 16 + cl;
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6, col = lt * RD_TALL_COLS + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (col < j.width) {
         int n = slice;
-        for (; n + 48 < j.nparts; n += 64) {   // four independent loads in flight per lane
+        for (; n + 12 < j.nparts; n += 16) {   // four independent loads in flight per lane
             s0 += j.src[(long long)n * j.pstride + col];
-            s1 += j.src[(long long)(n + 16) * j.pstride + col];
-            s2 += j.src[(long long)(n + 32) * j.pstride + col];
-            s3 += j.src[(long long)(n + 48) * j.pstride + col];
+            s1 += j.src[(long long)(n + 4) * j.pstride + col];
+            s2 += j.src[(long long)(n + 8) * j.pstride + col];
+            s3 += j.src[(long long)(n + 12) * j.pstride + col];
         }
-        for (; n < j.nparts; n += 16) s0 += j.src[(long long)n * j.pstride + col];
+        for (; n < j.nparts; n += 4) s0 += j.src[(long long)n * j.pstride + col];
     }
     red[slice][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && col < j.width) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         if (j.accumulate) j.dst[col] += s;
         else j.dst[col] = s;
     }
 }
 
 __global__ __launch_bounds__(256) void reduce_one_kernel(ReduceJob job) {
-    __shared__ float red[16][17];
+    __shared__ float red[4][RD_TALL_COLS + 1];
     reduce_tile(job, blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__restrict__ jobs, int njobs) {
-    __shared__ float red[16][17];
+    __shared__ float red[4][RD_TALL_COLS + 1];
     int lo = 0, hi = njobs - 1;
     const int bid = blockIdx.x;
     while (lo < hi) {   // last job whose first tile <= bid (uniform per workgroup)
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__res
 static std::vector<ReduceJob> g_jobs;
 static int g_defer = 0, g_tiles = 0;
 
-static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE) : cdiv(j.width, 16); }
+static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE) : cdiv(j.width, RD_TALL_COLS); }
 
 bool tsasr_reduce_deferring() { return g_defer != 0; }
 
