@@ -474,9 +474,9 @@ template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
                    int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep) {
     dim3 grid((unsigned)(cdiv(N, BN) * cdiv(M, BM) * splits));   // 1-D: tile coordinates come from the XCD-aware remap
-    // measured (tools/gemm_bench.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles; the
-    // register-staged loop wins on the short-K projections (K = 256: 4 k-tiles, prologue-bound)
-    const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024) &&
+    // measured (tools/gemm_bench.py, tools/fwd_sweep.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles and
+    // for the smaller macro-tiles at any K (3 workgroups per CU); the register-staged loop wins for 128x128 at short K (K = 256)
+    const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024 || BM * BN < 128 * 128) &&
                       (AT ? M >= 8 : true) && (BT ? N >= 8 : true);
     if (ring) {
         using R = RingSmem<BM, BN, AT, BT>;
@@ -513,7 +513,9 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
     }
     const long long t0 = (long long)cdiv(M, 128) * cdiv(N, 128), t1 = (long long)cdiv(M, 128) * cdiv(N, 64),
                     t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
-    p.tile = t0 >= 192 ? 0 : (t1 >= 192 ? 1 : 2);   // the largest macro-tile whose grid still covers the 256 CUs
+    // the largest macro-tile that still gives every CU work: 128x128 needs >= 2 tiles per CU (below that the 128x64 ring kernel
+    // wins by 5-20% at N <= 768: tools/fwd_sweep.py), 128x64 needs ~one per CU
+    p.tile = t0 >= 512 ? 0 : (t1 >= 192 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
     if (out_f32 && tiles < 256 && K >= 1024) {  // weight gradients: few output tiles, long inner dimension -> split it
