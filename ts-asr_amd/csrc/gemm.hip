@@ -72,21 +72,22 @@ struct TileLoader {
     static constexpr int CHUNKS = ROWS * GB_K / 8;
     static constexpr int ITERS = (CHUNKS + 255) / 256;
     uint4 v[ITERS];
+    // every piece is ALWAYS requested (row / k clamped into the matrix) and masked afterwards: a guarded load sits in its own basic
+    // block and is waited for on the spot, which turned the ITERS pieces of a k-tile into ITERS serialized memory round trips.
+    // Rows beyond the matrix may hold anything (their results are never stored); k beyond K must read as zero.
     __device__ __forceinline__ void load(const bf16_t *__restrict__ src, long long ld, int row0, int nrows, int k0, int K) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = it * 256 + threadIdx.x;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (c < CHUNKS) {
-                if (!TR) {
-                    const int rr = c / (GB_K / 8), kk = (c % (GB_K / 8)) * 8;
-                    if (row0 + rr < nrows && k0 + kk < K) x = *reinterpret_cast<const uint4 *>(src + (long long)(row0 + rr) * ld + k0 + kk);
-                } else {
-                    const int kk = c / (ROWS / 8), rr = (c % (ROWS / 8)) * 8;
-                    if (k0 + kk < K && row0 + rr < nrows) x = *reinterpret_cast<const uint4 *>(src + (long long)(k0 + kk) * ld + row0 + rr);
-                }
+            const int c = min(it * 256 + (int)threadIdx.x, CHUNKS - 1);
+            if (!TR) {
+                const int rr = c / (GB_K / 8), kk = (c % (GB_K / 8)) * 8;
+                v[it] = *reinterpret_cast<const uint4 *>(src + (long long)min(row0 + rr, nrows - 1) * ld + min(k0 + kk, K - 8));
+                if (k0 + kk >= K) v[it] = make_uint4(0, 0, 0, 0);
+            } else {
+                const int kk = c / (ROWS / 8), rr = (c % (ROWS / 8)) * 8;
+                v[it] = *reinterpret_cast<const uint4 *>(src + (long long)min(k0 + kk, K - 1) * ld + min(row0 + rr, nrows - 8));
+                if (k0 + kk >= K) v[it] = make_uint4(0, 0, 0, 0);
             }
-            v[it] = x;
         }
     }
     __device__ __forceinline__ void store(bf16_t *lds, int LD) const {
