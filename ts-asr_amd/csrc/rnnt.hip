@@ -559,60 +559,91 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
 #pragma unroll
     for (int i = 0; i < K; ++i) prev[i] = NEG_INF;
     float edge = NEG_INF;  // boundary value handed to the neighbour lane
+    // The per-step operands (log-probabilities of blank / label for this lane's K columns at its current frame) are requested PF
+    // steps ahead, unconditionally (frame index clamped): fetched inside the guarded step they cost one L2 round trip per step,
+    // and the Tb + 63 steps are strictly sequential (310 us for 313 steps before; the arithmetic of a step is ~50 cycles).
+    constexpr int PF = 8;
+    float qb[PF][K], qe[PF][K];
     if (dir == 0) {
-        for (int s = 0; s < nsteps; ++s) {
-            const int t = s - l;
-            const float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
-            if (t >= 0 && t < Tb) {
-                const float *pb = w.lpb + base + (size_t)(t > 0 ? t - 1 : 0) * U1P;
-                const float *pe = w.lpe_in + base + (size_t)t * U1P;
+        auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
+            const int t = min(max(ss - l, 0), Tb - 1);
+            const float *pb = w.lpb + base + (size_t)(t > 0 ? t - 1 : 0) * U1P;
+            const float *pe = w.lpe_in + base + (size_t)t * U1P;
 #pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    const int u = K * l + i;
-                    const float noemit = (t > 0) ? prev[i] + pb[i] : NEG_INF;
-                    const float lft = (i == 0) ? left : cur[i > 0 ? i - 1 : 0];
-                    const float emit = (u > 0) ? lft + pe[i] : NEG_INF;
-                    float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
-                    if (u > Ub) a = NEG_INF;
-                    cur[i] = a;
+            for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
+        };
+#pragma unroll
+        for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int s = s0 + d;
+                if (s >= nsteps) break;
+                const int t = s - l;
+                const float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                if (t >= 0 && t < Tb) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const int u = K * l + i;
+                        const float noemit = (t > 0) ? prev[i] + qb[d][i] : NEG_INF;
+                        const float lft = (i == 0) ? left : cur[i > 0 ? i - 1 : 0];
+                        const float emit = (u > 0) ? lft + qe[d][i] : NEG_INF;
+                        float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
+                        if (u > Ub) a = NEG_INF;
+                        cur[i] = a;
+                    }
+                    float *pa = w.alpha + base + (size_t)t * U1P;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
+                    edge = cur[K - 1];
+                    if (t == Tb - 1) {
+#pragma unroll
+                        for (int i = 0; i < K; ++i)
+                            if (K * l + i == Ub) {
+                                const float lp = cur[i] + w.lpb[base + (size_t)t * U1P + i];
+                                w.logp[b] = lp;
+                                costs[b] = -lp;
+                            }
+                    }
                 }
-                float *pa = w.alpha + base + (size_t)t * U1P;
-#pragma unroll
-                for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
-                edge = cur[K - 1];
-                if (t == Tb - 1) {
-#pragma unroll
-                    for (int i = 0; i < K; ++i)
-                        if (K * l + i == Ub) {
-                            const float lp = cur[i] + w.lpb[base + (size_t)t * U1P + i];
-                            w.logp[b] = lp;
-                            costs[b] = -lp;
-                        }
-                }
+                fetch(s + PF, qb[d], qe[d]);
             }
         }
     } else {
-        for (int s = 0; s < nsteps; ++s) {
-            const int t = Tb - 1 - (s - (63 - l));
-            const float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
-            if (t >= 0 && t < Tb) {
-                const float *pb = w.lpb + base + (size_t)t * U1P;
-                const float *pe = w.lpe_out + base + (size_t)t * U1P;
+        auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
+            const int t = min(max(Tb - 1 - (ss - (63 - l)), 0), Tb - 1);
+            const float *pb = w.lpb + base + (size_t)t * U1P;
+            const float *pe = w.lpe_out + base + (size_t)t * U1P;
 #pragma unroll
-                for (int i = K - 1; i >= 0; --i) {
-                    const int u = K * l + i;
-                    const float lb = pb[i];
-                    const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
-                    const float rgt = (i == K - 1) ? right : cur[i < K - 1 ? i + 1 : K - 1];
-                    const float emit = (u < Ub) ? rgt + pe[i] : NEG_INF;
-                    float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
-                    if (u > Ub) v = NEG_INF;
-                    cur[i] = v;
+            for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
+        };
+#pragma unroll
+        for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int s = s0 + d;
+                if (s >= nsteps) break;
+                const int t = Tb - 1 - (s - (63 - l));
+                const float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                if (t >= 0 && t < Tb) {
+#pragma unroll
+                    for (int i = K - 1; i >= 0; --i) {
+                        const int u = K * l + i;
+                        const float lb = qb[d][i];
+                        const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
+                        const float rgt = (i == K - 1) ? right : cur[i < K - 1 ? i + 1 : K - 1];
+                        const float emit = (u < Ub) ? rgt + qe[d][i] : NEG_INF;
+                        float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
+                        if (u > Ub) v = NEG_INF;
+                        cur[i] = v;
+                    }
+                    float *pbeta = w.beta + base + (size_t)t * U1P;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) { pbeta[i] = cur[i]; prev[i] = cur[i]; }
+                    edge = cur[0];
                 }
-                float *pbeta = w.beta + base + (size_t)t * U1P;
-#pragma unroll
-                for (int i = 0; i < K; ++i) { pbeta[i] = cur[i]; prev[i] = cur[i]; }
-                edge = cur[0];
+                fetch(s + PF, qb[d], qe[d]);
             }
         }
     }
