@@ -81,6 +81,51 @@ __device__ __forceinline__ void stage_rows(bf16_t *lds, const T *__restrict__ sr
     }
 }
 
+// The same staging split in two halves so that a tile can be REQUESTED one iteration ahead and written to LDS when the previous
+// tile has been consumed: request() issues the loads (clamped, unconditional) into registers in the storage type, commit() masks
+// and stores them. Between the two sits the MFMA work of the current tile - the key/query-tile loops no longer expose one memory
+// round trip per tile (4 tiles at T' = 250).
+template <typename T, int ROWS>
+struct StagePieces {
+    static constexpr int NIT = ROWS * (AT_DP / 8) / 256, W = 8 * (int)sizeof(T) / 16;   // uint4 words per 8-element piece
+    uint4 raw[NIT][W];
+    int first_row, lo, hi;
+    __device__ __forceinline__ void request(const T *__restrict__ src, long long src_stride, int first, int lo_, int hi_, int Dh) {
+        first_row = first; lo = lo_; hi = hi_;
+        const int c = (threadIdx.x % (AT_DP / 8)) * 8, cc = min(c, ((Dh + 7) & ~7) - 8);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = first + (int)(threadIdx.x + it * 256) / (AT_DP / 8);
+            const uint4 *p = reinterpret_cast<const uint4 *>(src + (long long)min(max(r, lo_), hi_ - 1) * src_stride + cc);
+#pragma unroll
+            for (int w = 0; w < W; ++w) raw[it][w] = p[w];
+        }
+    }
+    __device__ __forceinline__ void commit(bf16_t *lds, int Dh) const {
+        const int c = (threadIdx.x % (AT_DP / 8)) * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rr = (int)(threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+            float v[8];
+            if (sizeof(T) == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned wv = (&raw[it][0].x)[q];
+                    v[2 * q] = __uint_as_float(wv << 16);
+                    v[2 * q + 1] = __uint_as_float(wv & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = __uint_as_float((&raw[it][0].x)[q]);
+            }
+            const bool row_ok = r >= lo && r < hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (row_ok && c + j < Dh) ? v[j] : 0.f;
+            st8(lds + rr * AT_LD + c, v);
+        }
+    }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
                                                               const float *__restrict__ bias_u, const float *__restrict__ bias_v,
@@ -134,12 +179,32 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
 
     int j_end = len;
     if (causal) j_end = min(j_end, i0 + AT_QB);  // keys beyond the last query of the workgroup are never attended
+    const bool pipe = (Dh % 8) == 0;   // 16-byte aligned row pieces: tiles are requested one iteration ahead (StagePieces)
+    StagePieces<T, AT_KT> sk, sv;
+    StagePieces<T, AT_BAND> sp;
+    if (pipe && j_end > 0) {
+        sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
+        sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
+        sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
+    }
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();  // previous tile fully consumed
-        stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
-        stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
-        // band row R <-> r = j0 - i0 - (AT_QB - 1) + Tn - 1 + R
-        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
+        if (pipe) {
+            sk.commit(k_lds, Dh);
+            sv.commit(v_lds, Dh);
+            sp.commit(p_lds, Dh);
+            if (j0 + AT_KT < j_end) {   // next tile: in flight during this tile's MFMAs
+                const int jn = j0 + AT_KT;
+                sk.request(q_base + Dh, row_stride, jn, 0, Tn, Dh);
+                sv.request(q_base + 2 * Dh, row_stride, jn, 0, Tn, Dh);
+                sp.request(pk + (long long)h * Dh, D, jn - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
+            }
+        } else {
+            stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
+            stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
+            // band row R <-> r = j0 - i0 - (AT_QB - 1) + Tn - 1 + R
+            stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
+        }
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -309,12 +374,32 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
 
     int j_end = len;
     if (causal) j_end = min(j_end, i0 + AT_QB);
+    const bool pipe = (Dh % 8) == 0;
+    StagePieces<T, AT_KT> sk, sv;
+    StagePieces<T, AT_BAND> sp;
+    if (pipe && j_end > 0) {
+        sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
+        sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
+        sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
+    }
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();
-        stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
-        stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
         const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
-        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
+        if (pipe) {
+            sk.commit(k_lds, Dh);
+            sv.commit(v_lds, Dh);
+            sp.commit(p_lds, Dh);
+            if (j0 + AT_KT < j_end) {
+                const int jn = j0 + AT_KT;
+                sk.request(q_base + Dh, row_stride, jn, 0, Tn, Dh);
+                sv.request(q_base + 2 * Dh, row_stride, jn, 0, Tn, Dh);
+                sp.request(pk + (long long)h * Dh, D, jn - i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
+            }
+        } else {
+            stage_rows<T, AT_KT>(k_lds, q_base + Dh, row_stride, j0, 0, Tn, Dh);
+            stage_rows<T, AT_KT>(v_lds, q_base + 2 * Dh, row_stride, j0, 0, Tn, Dh);
+            stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
+        }
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
