@@ -566,20 +566,60 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
     load8_clamped<float>(bias_v + h * Dh, (tid % (AT_DP / 8)) * 8, Dh, fast_d, bv8);
 
     const int i_begin = causal ? (j0 / AT_KT) * AT_KT : 0;   // queries before the first key of the workgroup never see it
+    // query tiles are requested one iteration ahead (Dh % 8 == 0): Q, dO, O rows and the band in the storage type, lse in fp32
+    const bool pipe = fast_d;
+    StagePieces<T, AT_KT> sq, sdo, so;
+    StagePieces<T, AT_BAND> sp;
+    constexpr int NIT = AT_KT * (AT_DP / 8) / 256;
+    float lse_n[NIT];
+    auto request_tile = [&](int i0n) {
+        sq.request(q_base, row_stride, i0n, 0, Tn, Dh);
+        sdo.request(dout + ((long long)b * Tn) * D + (long long)h * Dh, D, i0n, 0, Tn, Dh);
+        so.request(out + ((long long)b * Tn) * D + (long long)h * Dh, D, i0n, 0, Tn, Dh);
+        sp.request(pk + (long long)h * Dh, D, j0 - i0n - (AT_KT - 1) + Tn - 1, 0, R, Dh);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) lse_n[it] = lse[((long long)b * H + h) * Tn + min(i0n + (tid + it * 256) / (AT_DP / 8), Tn - 1)];
+    };
+    if (pipe && i_begin < Tn) request_tile(i_begin);
     for (int i0 = i_begin; i0 < Tn; i0 += AT_KT) {
         __syncthreads();
-        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta: two passes of the workgroup, all loads of both requested first
+        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta
         {
-            constexpr int NIT = AT_KT * (AT_DP / 8) / 256;
             const int c = (tid % (AT_DP / 8)) * 8;
             float q[NIT][8], d8[NIT][8], o8[NIT][8], lse_v[NIT];
+            if (pipe) {
+                // the three row sets go through LDS scratch-free: unpack the requested pieces in registers
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int rr = (tid + it * 256) / (AT_DP / 8), ic = min(i0 + rr, Tn - 1);
-                load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, q[it]);
-                load8_clamped<T>(dout + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, d8[it]);
-                load8_clamped<T>(out + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, o8[it]);
-                lse_v[it] = lse[((long long)b * H + h) * Tn + ic];
+                for (int it = 0; it < NIT; ++it) {
+                    if (sizeof(T) == 2) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned a0 = (&sq.raw[it][0].x)[w], a1 = (&sdo.raw[it][0].x)[w], a2 = (&so.raw[it][0].x)[w];
+                            q[it][2 * w] = __uint_as_float(a0 << 16); q[it][2 * w + 1] = __uint_as_float(a0 & 0xffff0000u);
+                            d8[it][2 * w] = __uint_as_float(a1 << 16); d8[it][2 * w + 1] = __uint_as_float(a1 & 0xffff0000u);
+                            o8[it][2 * w] = __uint_as_float(a2 << 16); o8[it][2 * w + 1] = __uint_as_float(a2 & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            q[it][w] = __uint_as_float((&sq.raw[it][0].x)[w]);
+                            d8[it][w] = __uint_as_float((&sdo.raw[it][0].x)[w]);
+                            o8[it][w] = __uint_as_float((&so.raw[it][0].x)[w]);
+                        }
+                    }
+                    lse_v[it] = lse_n[it];
+                }
+                sp.commit(p_lds, Dh);
+                if (i0 + AT_KT < Tn) request_tile(i0 + AT_KT);   // next query tile: in flight during this tile's MFMAs
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int rr = (tid + it * 256) / (AT_DP / 8), ic = min(i0 + rr, Tn - 1);
+                    load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, q[it]);
+                    load8_clamped<T>(dout + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, d8[it]);
+                    load8_clamped<T>(out + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, o8[it]);
+                    lse_v[it] = lse[((long long)b * H + h) * Tn + ic];
+                }
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -592,8 +632,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                     const bool ok = live && (c + j) < Dh;
                     a[j] = ok ? q[it][j] + bu8[j] : 0.f;
                     c8[j] = ok ? q[it][j] + bv8[j] : 0.f;
-                    dd[j] = live ? d8[it][j] : 0.f;
-                    part += dd[j] * (live ? o8[it][j] : 0.f);
+                    dd[j] = ok ? d8[it][j] : 0.f;
+                    part += dd[j] * (ok ? o8[it][j] : 0.f);
                 }
                 st8(qu_lds + rr * AT_LD + c, a);
                 st8(qv_lds + rr * AT_LD + c, c8);
@@ -607,8 +647,10 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                 }
             }
         }
-        const int r_first = j0 - i0 - (AT_KT - 1) + Tn - 1;  // band row R <-> r = r_first + R ; keys [j0,j0+128) x queries [i0,i0+64)
-        stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
+        if (!pipe) {
+            const int r_first = j0 - i0 - (AT_KT - 1) + Tn - 1;  // band row R <-> r = r_first + R ; keys [j0,j0+128) x queries [i0,i0+64)
+            stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
+        }
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
