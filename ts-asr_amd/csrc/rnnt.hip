@@ -19,6 +19,8 @@
 //   * joint_bwd: two deterministic kernels that both recompute dh = lrelu'(enc+dec) * (dlogits . W) on MFMA:
 //       X: workgroup (b, u-tile) walks t  -> ddec, head dW/dbias slabs (reduced by a tiny second kernel);
 //       Y: workgroup (b, 8 frames) walks u-tiles -> denc.  No float atomics anywhere => bitwise reproducible.
+#include <type_traits>
+
 #include "common.h"
 
 #define NEG_INF (-INFINITY)
@@ -574,14 +576,18 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
         };
 #pragma unroll
         for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
-        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+        // a chunk of PF steps; GUARD = false when every lane has a valid frame in every step of the chunk (63 <= s < Tb): that
+        // version is straight-line code, so the compiler can count the outstanding prefetches exactly instead of draining them
+        // (s_waitcnt vmcnt(0)) behind every divergent guard
+        auto chunk = [&](int s0, auto guard_tag) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
-                if (s >= nsteps) break;
+                if (GUARD && s >= nsteps) break;
                 const int t = s - l;
                 const float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
-                if (t >= 0 && t < Tb) {
+                if (!GUARD || (t >= 0 && t < Tb)) {
 #pragma unroll
                     for (int i = 0; i < K; ++i) {
                         const int u = K * l + i;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
 #pragma unroll
                     for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
                     edge = cur[K - 1];
-                    if (t == Tb - 1) {
+                    if (GUARD && t == Tb - 1) {
 #pragma unroll
                         for (int i = 0; i < K; ++i)
                             if (K * l + i == Ub) {
@@ -608,6 +614,10 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
                 }
                 fetch(s + PF, qb[d], qe[d]);
             }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+            if (s0 >= 63 && s0 + PF < Tb) chunk(s0, std::false_type{});   // (t == Tb-1 only occurs in guarded chunks)
+            else chunk(s0, std::true_type{});
         }
     } else {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
@@ -619,14 +629,15 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
         };
 #pragma unroll
         for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
-        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+        auto chunk = [&](int s0, auto guard_tag) {
+            constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
-                if (s >= nsteps) break;
+                if (GUARD && s >= nsteps) break;
                 const int t = Tb - 1 - (s - (63 - l));
                 const float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
-                if (t >= 0 && t < Tb) {
+                if (!GUARD || (t >= 0 && t < Tb)) {
 #pragma unroll
                     for (int i = K - 1; i >= 0; --i) {
                         const int u = K * l + i;
@@ -645,6 +656,10 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
                 }
                 fetch(s + PF, qb[d], qe[d]);
             }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {
+            if (s0 >= 63 && s0 + PF < Tb) chunk(s0, std::false_type{});
+            else chunk(s0, std::true_type{});
         }
     }
 }
