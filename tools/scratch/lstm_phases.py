@@ -16,7 +16,7 @@ ws = torch.zeros(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dtype=torch.uint8,
 for _ in range(3):
     C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh), B, U, H, C.BF16, C.ptr(ws), ws.numel(), C.stream_ptr()), "fwd")
 torch.cuda.synchronize()
-st = ws[64:64 + 40].view(torch.int64).cpu().tolist()
+st = ws[128:128 + 40].view(torch.int64).cpu().tolist()
 names = ["wait h", "loads+mfma", "cell", "publish+drain", "atomic"]
 tot = sum(st)
 print({n: f"{v / U:.0f} cyc/step ({100 * v / tot:.0f}%)" for n, v in zip(names, st)}, "total cyc/step", tot // U)

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
 //               load of the payload is an sc1 16-byte buffer load straight to registers (MFMA B-fragments).
 //   (gfx950's eight XCD-private L2s are not coherent with each other: plain loads of another workgroup's stores are stale.)
 //   Each step's payload has its own location (no reuse inside a launch); the counter is zeroed by a memset node ahead of the
-//   launch. Grid = (H/32, ceil(B/32)) <= the CU count, 1 workgroup per CU (96 KB of dynamic LDS keeps a second one away), so
+//   launch. Grid = (H/32, ceil(B/16)) <= the CU count, 1 workgroup per CU (96 KB of dynamic LDS keeps a second one away), so
 //   every workgroup is resident and the per-step waits cannot deadlock; a poll that never matches gives up after ~1 s,
 //   raises the error word and poisons the output with NaN (the step's finite-check then rejects the update).
 // =====================================================================================================================
@@ -204,20 +204,25 @@ __device__ __forceinline__ bool lq_wait(unsigned *ctr, unsigned target, unsigned
     return true;
 }
 
-template <int H>
+// BR = batch rows per exchange group (a power of two <= 32). The recurrence is independent per batch row, so a launch runs
+// ceil(B / BR) groups of H/32 workgroups side by side; a smaller BR shrinks what a workgroup pulls through the exchange per step
+// and its cell work, but more workgroups poll and arrive per step: measured per-step cycles of the forward kernel (H = 512,
+// B = 32) 8.8k / 8.7k / 10.3k at BR = 32 / 16 / 8 (the wait for h_{t-1} grows 2.0k -> 2.7k -> 5.8k), backward 809 / 689 / 797 us.
+template <int H, int BR>
 __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict__ gates, float *__restrict__ c, bf16_t *__restrict__ h,
-                                                              const bf16_t *__restrict__ whh /*[4H,H]*/, bf16_t *xh /*[G][U][H/32][32][32]*/,
+                                                              const bf16_t *__restrict__ whh /*[4H,H]*/, bf16_t *xh /*[G][U][H/32][BR][32]*/,
                                                               unsigned *sync, int B, int U) {
-    constexpr int KS = H / 16, NWG = H / LQ_UN;
-    __shared__ __attribute__((aligned(16))) float pre[32][LQ_UN * 4 + 4];   // [batch][unit*4 + gate]
-    __shared__ __attribute__((aligned(16))) bf16_t hs[32][LQ_UN];            // this step's h tile, laid out as it is published
-    __shared__ __attribute__((aligned(16))) bf16_t hl[(H / 32) * 32 * 40];   // h_{t-1}: [unit block][batch row][32 + 8 pad]
+    constexpr int KS = H / 16, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 32;
+    static_assert(PP >= 1 && (BR & (BR - 1)) == 0 && BR <= 32, "BR in {8, 16, 32}");
+    __shared__ __attribute__((aligned(16))) float pre[BR][LQ_UN * 4 + 4];     // [batch][unit*4 + gate]
+    __shared__ __attribute__((aligned(16))) bf16_t hs[BR][LQ_UN];              // this step's h tile, laid out as it is published
+    __shared__ __attribute__((aligned(16))) bf16_t hl[(H / 32) * BR * 40];     // h_{t-1}: [unit block][batch row][32 + 8 pad]
     __shared__ int ok_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5, nr = r & (BR - 1);
+    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
-    bf16_t *xh_g = xh + (size_t)bg * U * H * 32;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xh_g, 0, U * H * 32 * 2, 0x00020000);
+    bf16_t *xh_g = xh + (size_t)bg * U * H * BR;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xh_g, 0, U * H * BR * 2, 0x00020000);
     // A operand (W_hh rows): MFMA row r of this wave = gate (r & 3) of unit u0 + 8*wave + (r >> 2) -> the four gates of a unit
     // land in four consecutive accumulator registers of ONE lane
     bf16x8 af[KS];
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
 #pragma unroll
         for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s + 8 * hh);
     }
-    float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+    float cprev[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) cprev[j] = 0.f;
     bool failed = false;
 #ifdef LQ_PROFILE
     long long acc_t[5] = {0, 0, 0, 0, 0}, t_prev = clock64();
@@ -236,9 +243,9 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
 #endif
 #pragma unroll 1
     for (int t = 0; t < U; ++t) {
-        float gx[4][4];
+        float gx[PP][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // x-part pre-activations of this thread's four (batch, unit) pairs: in flight across the wait
+        for (int j = 0; j < PP; ++j) {   // x-part pre-activations of this thread's (batch, unit) pairs: in flight across the wait
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
             const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)min(b0 + bl, B - 1) * U + t) * H + u0 + ul) * 4);
             gx[j][0] = g4.x; gx[j][1] = g4.y; gx[j][2] = g4.z; gx[j][3] = g4.w;
@@ -249,32 +256,33 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
             __syncthreads();
             if (!ok_flag) { failed = true; break; }
             LQ_STAMP(0);   // wait for h_{t-1}
-            // h_{t-1} [32 x H] enters the workgroup ONCE (each thread NLD coalesced 16-byte sc1 loads, all requested together),
+            // h_{t-1} [BR x H] enters the workgroup ONCE (each thread NLD coalesced 16-byte sc1 loads, all requested together),
             // is laid out in LDS as [unit block][batch row][32 + 8 pad] and feeds the four waves' B fragments from there
-            // (s_memtime: the per-wave loads of the whole tile took 44% of a step)
-            constexpr int NLD = H * 32 / 8 / 256;
+            constexpr int NLD = (H * BR / 8 + 255) / 256;
             u32x4 raw[NLD];
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((t - 1) * NWG * 1024 + (tid + 256 * i) * 8) * 2, 0, 16);
+            for (int i = 0; i < NLD; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((t - 1) * NWG * TILE + min(tid + 256 * i, H * BR / 8 - 1) * 8) * 2, 0, 16);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int ch = tid + 256 * i;
-                *reinterpret_cast<u32x4 *>(&hl[((ch >> 7) * 32 + ((ch & 127) >> 2)) * 40 + (ch & 3) * 8]) = raw[i];
+                if (ch < H * BR / 8) *reinterpret_cast<u32x4 *>(&hl[((ch / (BR * 4)) * BR + ((ch % (BR * 4)) >> 2)) * 40 + (ch & 3) * 8]) = raw[i];
             }
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&hl[((s >> 1) * 32 + r) * 40 + (s & 1) * 16 + 8 * hh]);
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&hl[((s >> 1) * BR + nr) * 40 + (s & 1) * 16 + 8 * hh]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfrag, acc, 0, 0, 0);
             }
         }
         LQ_STAMP(1);   // operand loads + MFMA
+        if (r < BR) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PP; ++j) {
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = b0 + bl;
             const float4 pr = *reinterpret_cast<const float4 *>(&pre[bl][ul * 4]);
             const float gi = sigm(gx[j][0] + pr.x), gf = sigm(gx[j][1] + pr.y), gg = tanh_fast(gx[j][2] + pr.z), go = sigm(gx[j][3] + pr.w);
@@ -289,10 +297,10 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
         }
         __syncthreads();
         LQ_STAMP(2);   // cell math
-        if (wave < 2) {   // 2 KB tile: two wave-instructions of 1 KiB (whole 128-byte lines), write-through
-            const int ch = wave * 64 + lane, bl = ch >> 2, part = ch & 3;
+        if (tid < BR * 4) {   // BR*64-byte tile: whole 128-byte lines per wave-instruction, write-through
+            const int ch = tid, bl = ch >> 2, part = ch & 3;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(&hs[bl][part * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * 1024 + ch * 8) * 2, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
             if (b0 + bl < B) *reinterpret_cast<u32x4 *>(h + ((long long)(b0 + bl) * U + t) * H + u0 + part * 8) = v;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -302,25 +310,25 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
         LQ_STAMP(4);
     }
 #ifdef LQ_PROFILE
-    if (tid == 0 && wg == 3 && bg == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<long long *>(sync + 16)[i] = acc_t[i];
+    if (tid == 0 && wg == 3 && bg == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<long long *>(sync + 32)[i] = acc_t[i];
 #endif
     if (failed && tid == 0) h[((long long)min(b0, B - 1) * U + U - 1) * H + u0] = (bf16_t)__builtin_nanf("");
 }
 
-template <int H>
+template <int H, int BR>
 __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c,
                                                               const bf16_t *__restrict__ dout, bf16_t *__restrict__ dgates,
-                                                              const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][32][128]*/,
+                                                              const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][BR][128]*/,
                                                               unsigned *sync, int B, int U) {
-    constexpr int K4 = 4 * H, KSW = K4 / 16 / 4, NWG = H / LQ_UN;   // KSW k-steps per wave
-    __shared__ float red[4][32][33];                                  // [wave][batch][unit]
-    __shared__ __attribute__((aligned(16))) bf16_t dgt[32][4 * LQ_UN];   // [batch][gate*32 + unit]: the published tile
+    constexpr int K4 = 4 * H, KSW = K4 / 16 / 4, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 128;   // KSW k-steps per wave
+    __shared__ float red[4][32][33];                                       // [wave][batch][unit]
+    __shared__ __attribute__((aligned(16))) bf16_t dgt[BR][4 * LQ_UN];     // [batch][gate*32 + unit]: the published tile
     __shared__ int ok_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5, nr = r & (BR - 1);
+    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
-    bf16_t *xg_g = xg + (size_t)bg * U * K4 * 32;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xg_g, 0, U * K4 * 32 * 2, 0x00020000);
+    bf16_t *xg_g = xg + (size_t)bg * U * K4 * BR;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xg_g, 0, U * K4 * BR * 2, 0x00020000);
     // A operand: row r = unit u0 + r of W_hh^T; the reduction index runs over the PUBLISHED order c' = wg'*128 + gate*32 + unit'
     bf16x8 af[KSW];
     {
@@ -331,18 +339,21 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             af[i] = *reinterpret_cast<const bf16x8 *>(wrow + ((cp & 127) >> 5) * H + (cp >> 7) * 32 + (cp & 31));
         }
     }
-    float dcar[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcar[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) dcar[j] = 0.f;
     bool failed = false;
 #pragma unroll 1
     for (int t = U - 1; t >= 0; --t) {
-        float gv[4][4], cn[4], cpv[4], dov[4];
+        float gv[PP][4], cn[PP], cpv[PP], dov[PP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PP; ++j) {   // always-issued loads (clamped), masked below
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = min(b0 + bl, B - 1);
             const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)b * U + t) * H + u0 + ul) * 4);
             gv[j][0] = g4.x; gv[j][1] = g4.y; gv[j][2] = g4.z; gv[j][3] = g4.w;
             cn[j] = c[((long long)b * U + t) * H + u0 + ul];
-            cpv[j] = t > 0 ? c[((long long)b * U + t - 1) * H + u0 + ul] : 0.f;
+            const float cpr = c[((long long)b * U + max(t - 1, 0)) * H + u0 + ul];
+            cpv[j] = t > 0 ? cpr : 0.f;
             dov[j] = (float)dout[((long long)b * U + t) * H + u0 + ul];
         }
         f32x16 acc = {0};
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 #pragma unroll
             for (int i = 0; i < KSW; ++i) {
                 const int cp = 16 * (KSW * wave + i) + 8 * hh;
-                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((t + 1) * NWG + (cp >> 7)) * 32 + r) * 128 + (cp & 127)) * 2, 0, 16);
+                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((t + 1) * NWG + (cp >> 7)) * BR + nr) * 128 + (cp & 127)) * 2, 0, 16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
         for (int g = 0; g < 16; ++g) red[wave][r][(g & 3) + 8 * (g >> 2) + 4 * hh] = acc[g];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PP; ++j) {
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
             const float dh_rec = red[0][bl][ul] + red[1][bl][ul] + red[2][bl][ul] + red[3][bl][ul];
             const float gi = gv[j][0], gf = gv[j][1], gg = gv[j][2], go = gv[j][3];
@@ -381,11 +392,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {   // 8 KB tile: eight wave-instructions of 1 KiB, write-through
+        for (int k = 0; k < (BR * 16 + 255) / 256; ++k) {   // BR*256-byte tile: wave-instructions of 1 KiB, write-through
             const int ch = tid + 256 * k, bl = ch >> 4, part = ch & 15;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(&dgt[bl][part * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * 4096 + ch * 8) * 2, 0, 16);
-            if (b0 + bl < B) *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = v;
+            if (ch < BR * 16) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&dgt[bl][part * 8]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
+                if (b0 + bl < B) *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = v;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -394,21 +407,23 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
     if (failed && tid == 0) dgates[((long long)min(b0, B - 1) * U) * K4 + u0] = (bf16_t)__builtin_nanf("");
 }
 
+#define LQ_BR 16   // batch rows per exchange group
+
 template <int H>
 static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
-    auto kern = lstm_seq_fwd_kernel<H>;
+    auto kern = lstm_seq_fwd_kernel<H, LQ_BR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     (void)hipMemsetAsync(ws, 0, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, 32)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
 }
 template <int H>
 static void launch_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, char *ws, hipStream_t st) {
-    auto kern = lstm_seq_bwd_kernel<H>;
+    auto kern = lstm_seq_bwd_kernel<H, LQ_BR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     (void)hipMemsetAsync(ws, 0, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, 32)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
 }
 
 
@@ -465,7 +480,9 @@ size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H) {
     return 256 + align_up(G * U * 32 * 4 * (size_t)H * sizeof(bf16_t), 256) + align_up((size_t)B * H * sizeof(float), 256);
 }
 
-static bool seq_persistent_ok(int B, int H, int io_dtype) { return io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, 32) <= 8; }
+static bool seq_persistent_ok(int B, int H, int io_dtype) {   // sync words: 2 per batch group in a 256-byte block; all workgroups resident
+    return io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, LQ_BR) <= 16 && cdiv(B, LQ_BR) * (H / LQ_UN) <= 256;
+}
 
 /* The whole forward recurrence (t = 0 .. U-1) of tsasr_lstm_step_fwd. bf16 with H in {256, 512} and B <= 256: ONE persistent launch
  * (csrc/lstm.hip, "Whole-sequence persistent kernels"); otherwise the per-step kernels in a loop. workspace: tsasr_lstm_seq_workspace_bytes. */
