@@ -122,12 +122,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("TSASR_DIST_BACKEND") == "gloo":   # rehearsal: every rank on the one visible GPU
+        local_rank = 0
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     dp = importlib.import_module(PKG + ".dp")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dp.ddp_init_group({"distributed_launch": True, "distributed_backend": "nccl"})
+        # RCCL ("nccl") always, except for the one-GPU rehearsal of the multi-rank code path (tools/ddp_rehearsal.sh)
+        dp.ddp_init_group({"distributed_launch": True, "distributed_backend": os.environ.get("TSASR_DIST_BACKEND", "nccl")})
     prof = importlib.import_module(PKG + ".prof")
     batch_mod = importlib.import_module(PKG + ".batch")
 

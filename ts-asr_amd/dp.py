@@ -71,6 +71,14 @@ class GradArena:
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        if self.device.type == "cuda":
+            # pinned / device job tables are created NOW: their first use may be inside a hipGraph capture (multi-rank runs only
+            # defer inside the captured step), where a host allocation is not permitted
+            cap = max(1024, 2 * len(params)) * 20
+            self._defer_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._defer_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            from . import ops
+            ops.reduce_defer_prepare(self.device)
 
     # ---- layout ---------------------------------------------------------------------------------------
     def _layout(self, params, first=False):

@@ -67,13 +67,18 @@ def _keep(*tensors):
         _DEFER["keep"].extend(t for t in tensors if t is not None)
 
 
-def reduce_defer_begin(device):
-    if device.type != "cuda":
-        return
-    if _DEFER["host"] is None:
+def reduce_defer_prepare(device):
+    """Allocate the job tables (pinned host + device) outside of any graph capture."""
+    if torch.device(device).type == "cuda" and _DEFER["host"] is None:
         nb = C.lib().tsasr_reduce_table_bytes(_DEFER_MAX_JOBS)
         _DEFER["host"] = torch.empty(nb, dtype=torch.uint8).pin_memory()
         _DEFER["dev"] = torch.empty(nb, dtype=torch.uint8, device=device)
+
+
+def reduce_defer_begin(device):
+    if device.type != "cuda":
+        return
+    reduce_defer_prepare(device)
     C.check(C.lib().tsasr_reduce_defer(1), "tsasr_reduce_defer")
     _DEFER["on"] = True
 
