@@ -61,7 +61,7 @@ def algorithmic_bytes(B=B_LOCAL, Tp=T_MEL // 4, U1=U + 1, J=640, V=29):
     }
 
 
-def cpu_baseline(brain, torch, budget_steps=2, B=2):
+def cpu_baseline(brain, torch, budget_steps=6, B=4):   # ~10 s of host work
     """Oracle (CPU restatement of the reference) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import rnnt_ref, tsasr_ref
     batch_mod = importlib.import_module(PKG + ".batch")
