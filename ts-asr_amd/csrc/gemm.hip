@@ -312,6 +312,50 @@ struct RingTile {
                                              (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, 0);
         }
     }
+    // ---- loop-invariant halves of issue() / frag(): everything that does not depend on the k-tile is computed ONCE per kernel.
+    // (Left to the compiler, the transposed layouts re-derived swizzles, clamps and a 64-bit row*ld product for every DMA and every
+    // fragment of every k-tile: ~70 VALU instructions per 4 MFMAs in the 64x64 weight-gradient kernel - VALU-bound.)
+    static constexpr int NFO = TR ? 2 : 1;                               // LDS reads per fragment
+    __device__ static __forceinline__ void src_ptrs(const bf16_t *__restrict__ src, long long ld, int row0, int nrows, int k0, int wave,
+                                                    int lane, const bf16_t *(&g)[INSTR]) {
+#pragma unroll
+        for (int i = 0; i < INSTR; ++i) {
+            const int byte = (i * 4 + wave) * 1024 + lane * 16;
+            const int lrow = byte / ROW_BYTES, pos = (byte % ROW_BYTES) / 16;
+            const int ch = swz(lrow, pos);
+            if (!TR) g[i] = src + (long long)min(row0 + lrow, nrows - 1) * ld + k0 + ch * 8;
+            else g[i] = src + (long long)(k0 + lrow) * ld + min(row0 + ch * 8, nrows - 8);
+        }
+    }
+    // elements to add to every source pointer per k-tile
+    __device__ static __forceinline__ long long k_step(long long ld) { return TR ? (long long)GB_K * ld : (long long)GB_K; }
+    __device__ static __forceinline__ void issue_at(const bf16_t *const (&g)[INSTR], long long off, char *slot, int wave) {
+#pragma unroll
+        for (int i = 0; i < INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g[i] + off),
+                                             (__attribute__((address_space(3))) void *)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+    __device__ static __forceinline__ void frag_offsets(int blk0, int s, int lane, int (&off)[NFO]) {
+        const int r = lane & 31, hh = lane >> 5;
+        if (!TR) {
+            const int row = blk0 + r;
+            off[0] = row * ROW_BYTES + swz(row, 2 * s + hh) * 16;
+        } else {
+            const int mhalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const int col = blk0 + 16 * mhalf + 4 * p4;
+            const int row_lo = 16 * s + 8 * hh + q4, row_hi = row_lo + 4;
+            off[0] = row_lo * ROW_BYTES + swz(row_lo, col >> 3) * 16 + (col & 7) * 2;
+            off[NFO - 1] = row_hi * ROW_BYTES + swz(row_hi, col >> 3) * 16 + (col & 7) * 2;
+        }
+    }
+    __device__ static __forceinline__ bf16x8 frag_at(const char *slot, const int (&off)[NFO]) {
+        if (!TR) return *reinterpret_cast<const bf16x8 *>(slot + off[0]);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(slot + off[0]));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(slot + off[NFO - 1]));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+    }
     __device__ static __forceinline__ bf16x8 frag(const char *slot, int blk0, int s, int lane) {
         const int r = lane & 31, hh = lane >> 5;
         if (!TR) {
@@ -353,11 +397,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
+    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
+    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
+    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    int a_off[RB][GB_K / 16][TA::NFO], b_off[CB][GB_K / 16][TB::NFO];
+#pragma unroll
+    for (int s = 0; s < GB_K / 16; ++s) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) TA::frag_offsets(wm * (BM / 2) + 32 * i, s, lane, a_off[i][s]);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) TB::frag_offsets(wn * (BN / 2) + 32 * j, s, lane, b_off[j][s]);
+    }
 #pragma unroll
     for (int t = 0; t < RING_STAGES - 1; ++t)
         if (t < nk) {
-            TA::issue(A, lda, m0, M, kbeg + t * GB_K, smem + t * SLOT, wave, lane);
-            TB::issue(B, ldb, n0, N, kbeg + t * GB_K, smem + t * SLOT + TA::BYTES, wave, lane);
+            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
+            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
         }
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's pieces of tile kt have landed once at most the next tile's LPT instructions are outstanding
@@ -366,17 +422,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
         __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1)%3
         if (kt + RING_STAGES - 1 < nk) {
             char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
-            TA::issue(A, lda, m0, M, kbeg + (kt + RING_STAGES - 1) * GB_K, slot, wave, lane);
-            TB::issue(B, ldb, n0, N, kbeg + (kt + RING_STAGES - 1) * GB_K, slot + TA::BYTES, wave, lane);
+            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
+            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
         }
         const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
 #pragma unroll
         for (int s = 0; s < GB_K / 16; ++s) {
             bf16x8 af[RB], bfr[CB];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) af[i] = TA::frag(as, wm * (BM / 2) + 32 * i, s, lane);
+            for (int i = 0; i < RB; ++i) af[i] = TA::frag_at(as, a_off[i][s]);
 #pragma unroll
-            for (int j = 0; j < CB; ++j) bfr[j] = TB::frag(bs, wn * (BN / 2) + 32 * j, s, lane);
+            for (int j = 0; j < CB; ++j) bfr[j] = TB::frag_at(bs, b_off[j][s]);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -519,7 +575,11 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
     p.tile = t0 >= 512 ? 0 : (t1 >= 192 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
-    if (out_f32 && tiles < 256 && K >= 1024) {  // weight gradients: few output tiles, long inner dimension -> split it
+    if (out_f32 && tiles < 256 && K >= 1024) {
+        // weight gradients: few output tiles, long inner dimension -> split it (fp32 slabs, reduced in fixed order). Both operands
+        // are k-major, i.e. every fragment comes through ds_read_b64_tr_b16, and that path - not the DMA, not VALU, not MFMA - is
+        // what bounds these kernels (the same tiles read with ds_read_b128, wrong results, run in 21.5 us instead of 30.1 us).
+        // Macro-tile / split sweeps (tools/wgrad_sweep.py) stay within 10% of this choice in isolation and within noise in the step.
         int s = (int)((512 + tiles - 1) / tiles);
         const int max_s = K / 256;             // at least 4 k-tiles per split
         if (s > max_s) s = max_s;
