@@ -37,11 +37,10 @@ __device__ __forceinline__ void load_glu_tile(const T *__restrict__ y2, const fl
     for (int u = 0; u < NIT; ++u) {
         const int i = threadIdx.x + u * 256, rr = i >> 3, c = c0 + (i & 7) * 8, t = row0 + rr;
         live[u] = i < ITEMS && t >= 0 && t < Tn && c < D;
-        if (live[u]) {
-            const T *p = y2 + ((size_t)b * Tn + t) * 2 * D;
-            ld8(p + c, a[u]);
-            ld8(p + D + c, g[u]);
-        }
+        // always issued (frame / channel clamped): a guarded load would be waited for where it stands
+        const T *p = y2 + ((size_t)b * Tn + min(max(t, 0), Tn - 1)) * 2 * D;
+        ld8(p + min(c, D - 8), a[u]);
+        ld8(p + D + min(c, D - 8), g[u]);
     }
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict
         for (int u = 0; u < NIT; ++u) {
             const int i = threadIdx.x + u * 256, rr = i >> 3, c = c0 + (i & 7) * 8, t = dc_row0 + rr;
             live[u] = i < ITEMS && t >= 0 && t < Tn && c < D;
-            if (live[u]) ld8(dc + ((size_t)b * Tn + t) * D + c, v[u]);
+            ld8(dc + ((size_t)b * Tn + min(max(t, 0), Tn - 1)) * D + min(c, D - 8), v[u]);
         }
         load_glu_tile<T, R>(y2, b2, g_lds, b, Tn, D, c0, t0 - pad_l);
 #pragma unroll

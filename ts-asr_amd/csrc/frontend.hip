@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void fe_im2col_kernel(const T *__restrict__ x,
         const long long p = i / ((long long)cv * 9);
         const int fo = p % Fo, to = (p / Fo) % To, b = p / ((long long)Fo * To);
         const int ti = src_index(to, tap / 3, Tn, tmode), fi = src_index(fo, tap % 3, F, fmode);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ti >= 0 && fi >= 0) v = *reinterpret_cast<const uint4 *>(x + (((size_t)b * Tn + ti) * F + fi) * C + c * VE);
+        uint4 v = *reinterpret_cast<const uint4 *>(x + (((size_t)b * Tn + max(ti, 0)) * F + max(fi, 0)) * C + c * VE);   // always issued
+        if (ti < 0 || fi < 0) v = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4 *>(A + (p * 9 + tap) * C + c * VE) = v;
     }
 }

@@ -149,7 +149,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int m = m0 + rr0 + it * (256 / CPR);
-                yraw[it] = (n_ok && m < M) ? *reinterpret_cast<const uint4 *>(ep.y + (long long)m * ep.ldy + n) : make_uint4(0, 0, 0, 0);
+                // always issued (row / column clamped into the matrix): rows beyond M are never stored, so their value is irrelevant
+                yraw[it] = *reinterpret_cast<const uint4 *>(ep.y + (long long)min(m, M - 1) * ep.ldy + min(n, N - 8));
             }
         }
 #pragma unroll
