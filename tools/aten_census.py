@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Which PyTorch (library) ops still launch kernels inside one training step: per-op counts and GPU time (torch.profiler, eager)."""
-import importlib, os, sys
+"""Which PyTorch (library) ops still launch kernels inside one training step, and from which source line (torch.profiler, eager)."""
+import collections, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
@@ -11,12 +11,20 @@ batch = batch_mod.synthetic_batch(bench.B_LOCAL, bench.T_MEL, bench.T_ENROLL, be
 for _ in range(3):
     brain.fit_batch(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     brain.fit_batch(batch)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages() if e.key.startswith("aten::") and getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)) > 0]
-rows.sort(key=lambda e: -e.count)
-print(f"{'op':40s} {'calls':>6s} {'gpu us':>10s}")
-for e in rows[:45]:
-    t = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))
-    print(f"{e.key:40s} {e.count:6d} {t:10.0f}")
+agg = collections.defaultdict(lambda: [0, 0.0])
+for e in prof.events():
+    if not e.name.startswith("aten::"):
+        continue
+    t = getattr(e, "self_device_time_total", 0) or getattr(e, "self_cuda_time_total", 0)
+    if t <= 0:
+        continue
+    src = next((f for f in (e.stack or []) if "ts-asr_amd" in f or "bench.py" in f), "(autograd engine / other)")
+    src = src.split("ts-asr_amd/")[-1][:70]
+    agg[(e.name, src)][0] += 1
+    agg[(e.name, src)][1] += t
+print(f"{'op':28s} {'calls':>5s} {'gpu us':>8s}  source")
+for (name, src), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f"{name:28s} {n:5d} {t:8.0f}  {src}")

@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                                                                  const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                  const int32_t *__restrict__ key_lens, const T *__restrict__ out,
                                                                  const T *__restrict__ dout, const float *__restrict__ lse,
-                                                                 T *__restrict__ dqkv, int Tn, int H, int Dh, float scale, int causal,
+                                                                 T *__restrict__ dqkv, T *__restrict__ qv_out /*[H][B*T][Dh] or NULL*/,
+                                                                 int Tn, int H, int Dh, float scale, int causal,
                                                                  float pdrop, unsigned long long seed,
                                                                  const unsigned long long *__restrict__ seed_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -638,6 +639,13 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__rest
                 st8(qu_lds + rr * AT_LD + c, a);
                 st8(qv_lds + rr * AT_LD + c, c8);
                 st8(do_lds + rr * AT_LD + c, dd);
+                // (Q + v) rows in the [H, B*T, Dh] layout of the d(pk) product: written once, by the workgroup of the first key block
+                if (qv_out && blockIdx.x == 0 && live && c < Dh) {
+                    T *qo = qv_out + (((long long)h * gridDim.z + b) * Tn + i0 + rr) * Dh + c;
+                    if (fast_d) st8(qo, c8);
+                    else
+                        for (int j = 0; j < 8 && c + j < Dh; ++j) st1(qo + j, c8[j]);
+                }
                 // delta: 8 consecutive threads hold the 8 column chunks of one row
 #pragma unroll
                 for (int o = 4; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
@@ -765,10 +773,11 @@ size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
 
 /* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh]
  * reading of the parameter storage, dbd [H, 2T-1, B, T] in io_dtype = scale * dS shifted back to the (r, i) grid; it
- * must be ZERO-FILLED by the caller (entries without a key are not touched) and d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] *
+ * must be ZERO-FILLED by the caller (entries without a key are not touched; an in-kernel fill of those entries by per-lane
+ * 2-byte stores measured slower than the separate 32 MB fill); qv_out (may be NULL): (Q + pos_bias_v) as [H, B*T, Dh] io_dtype and d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] *
  * (q[b,i,h,:] + v[h,:]) is then one library GEMM per head. */
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
-                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, float *d_bias_u,
+                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
                           void *stream) {
@@ -786,12 +795,12 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         relpos_attn_bwd_q_kernel<float><<<grid, 256, lds_q, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)qv_out, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else if (io_dtype == TSASR_BF16) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         relpos_attn_bwd_q_kernel<bf16_t><<<grid, 256, lds_q, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)qv_out, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);
     }
