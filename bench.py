@@ -178,6 +178,21 @@ def main():
         torch.cuda.synchronize()
         prof.ENABLED = False
         brain._graph_mode = True
+    feat_ms = None
+    if rank == 0:   # Fbank + sentence norm are timed separately, on wav ~ N(0, 0.1^2) [32, 159840] (the step is fed features)
+        wav = torch.randn(B_LOCAL, T_MEL * 160 - 160, device=device) * 0.1
+        wlens = torch.ones(B_LOCAL, device=device)
+        fx, nm = brain.modules.feature_extractor, brain.modules.normalizer
+        with torch.no_grad():
+            for _ in range(3):
+                nm(fx(wav), wlens, epoch=0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                nm(fx(wav), wlens, epoch=0)
+            e1.record()
+            torch.cuda.synchronize()
+            feat_ms = e0.elapsed_time(e1) / 10
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -227,6 +242,7 @@ def main():
                        "hip_graph": brain._graph is not None},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 1),
             "rnnt_joint_loss_ms": round(rnnt_ms, 4),
+            "fbank_sentnorm_ms": None if feat_ms is None else round(feat_ms, 4),
             "loss": round(float(loss), 4), "nonfinite_steps": nonfinite,
             "hip_kernels": fam,
             "roofline": roof,
