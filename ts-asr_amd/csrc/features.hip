@@ -26,7 +26,8 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 
 __global__ __launch_bounds__(256) void fbank_kernel(const float *__restrict__ wav, const float *__restrict__ window,
                                                     const float *__restrict__ melmat /*[257][n_mels]*/, float *__restrict__ out_db,
-                                                    int *__restrict__ umax, int L, int Tn, int n_mels, int hop, float amin) {
+                                                    int *__restrict__ umax, const int *__restrict__ band, int L, int Tn, int n_mels,
+                                                    int hop, float amin) {
     __shared__ float2 buf[4][FB_N];
     __shared__ float2 tw[FB_N / 2];
     __shared__ float pw[4][FB_N / 2 + 1];
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float *__restrict__ wa
     if (live) {
         for (int m = lane; m < n_mels; m += 64) {
             float s = 0.f;
-            for (int k = 0; k <= FB_N / 2; ++k) {
+            // triangular filters: bin m is non-zero on [band[m], band[n_mels + m]) only (fbank_bands_kernel) - ~6 of the 257
+            // frequency rows instead of all of them, summed in the same ascending order as the dense loop
+            const int k_lo = band[m], k_hi = band[n_mels + m];
+            for (int k = k_lo; k < k_hi; ++k) {
                 const float w = melmat[k * n_mels + m];
                 if (w != 0.f) s += w * pw[wave][k];
             }
@@ -97,19 +101,40 @@ __global__ void fbank_init_kernel(int *umax, int B) {
     if (i < B) umax[i] = f2ord(-INFINITY);
 }
 
+// band[m] = first non-zero frequency row of mel column m, band[n_mels + m] = one past the last (0, 0 for an all-zero column)
+__global__ void fbank_bands_kernel(const float *__restrict__ melmat, int *__restrict__ band, int n_mels) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_mels) return;
+    int lo = FB_N / 2 + 1, hi = 0;
+    for (int k = 0; k <= FB_N / 2; ++k)
+        if (melmat[k * n_mels + m] != 0.f) { lo = min(lo, k); hi = k + 1; }
+    band[m] = hi > 0 ? lo : 0;
+    band[n_mels + m] = hi;
+}
+
+#define SN_NT 1024   // one workgroup (16 waves) streams an utterance: rows of Fq bins are spread over SN_NT / Fq thread rows
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void sentence_norm_kernel(const TI *__restrict__ x, const int32_t *__restrict__ lens, TO *__restrict__ y,
-                                                            int Tn, int Fq, float eps) {
+__global__ __launch_bounds__(SN_NT) void sentence_norm_kernel(const TI *__restrict__ x, const int32_t *__restrict__ lens, TO *__restrict__ y,
+                                                              int Tn, int Fq, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [rows][Fq] partials, then mean[Fq], inv[Fq]
     const int b = blockIdx.x;
     const int n = min(max(lens[b], 1), Tn);
-    const int f = threadIdx.x % Fq, rl = threadIdx.x / Fq, rows = 256 / Fq;
+    const int f = threadIdx.x % Fq, rl = threadIdx.x / Fq, rows = SN_NT / Fq;
     const TI *xb = x + (long long)b * Tn * Fq;
     float *mean = sm + rows * Fq, *inv = mean + Fq;
-    float s = 0.f;
-    if (rl < rows)
-        for (int t = rl; t < n; t += rows) s += ld1(xb + (long long)t * Fq + f);
-    if (rl < rows) sm[rl * Fq + f] = s;
+    // column sums with four independent accumulators (loads of four frames in flight per thread)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (rl < rows) {
+        int t = rl;
+        for (; t + 3 * rows < n; t += 4 * rows) {
+            s0 += ld1(xb + (long long)t * Fq + f);
+            s1 += ld1(xb + (long long)(t + rows) * Fq + f);
+            s2 += ld1(xb + (long long)(t + 2 * rows) * Fq + f);
+            s3 += ld1(xb + (long long)(t + 3 * rows) * Fq + f);
+        }
+        for (; t < n; t += rows) s0 += ld1(xb + (long long)t * Fq + f);
+        sm[rl * Fq + f] = (s0 + s1) + (s2 + s3);
+    }
     __syncthreads();
     if (threadIdx.x < Fq) {
         float a = 0.f;
@@ -118,10 +143,18 @@ __global__ __launch_bounds__(256) void sentence_norm_kernel(const TI *__restrict
     }
     __syncthreads();
     const float mu = mean[f];
-    float v = 0.f;
-    if (rl < rows)
-        for (int t = rl; t < n; t += rows) { const float d = ld1(xb + (long long)t * Fq + f) - mu; v += d * d; }
-    if (rl < rows) sm[rl * Fq + f] = v;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (rl < rows) {
+        int t = rl;
+        for (; t + 3 * rows < n; t += 4 * rows) {
+            const float d0 = ld1(xb + (long long)t * Fq + f) - mu, d1 = ld1(xb + (long long)(t + rows) * Fq + f) - mu;
+            const float d2 = ld1(xb + (long long)(t + 2 * rows) * Fq + f) - mu, d3 = ld1(xb + (long long)(t + 3 * rows) * Fq + f) - mu;
+            v0 += d0 * d0; v1 += d1 * d1; v2 += d2 * d2; v3 += d3 * d3;
+        }
+        for (; t < n; t += rows) { const float d = ld1(xb + (long long)t * Fq + f) - mu; v0 += d * d; }
+    }
+    __syncthreads();   // pass-1 partials fully consumed
+    if (rl < rows) sm[rl * Fq + f] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (threadIdx.x < Fq) {
         float a = 0.f;
@@ -130,16 +163,17 @@ __global__ __launch_bounds__(256) void sentence_norm_kernel(const TI *__restrict
     }
     __syncthreads();
     TO *yb = y + (long long)b * Tn * Fq;
-    for (long long i = threadIdx.x; i < (long long)Tn * Fq; i += 256) {
-        const int ff = (int)(i % Fq);
-        st1(yb + i, (ld1(xb + i) - mean[ff]) * inv[ff]);
+    if (rl < rows) {   // thread (rl, f) keeps its bin: no modulo in the loop
+        const float m_f = mean[f], i_f = inv[f];
+#pragma unroll 4
+        for (int t = rl; t < Tn; t += rows) st1(yb + (long long)t * Fq + f, (ld1(xb + (long long)t * Fq + f) - m_f) * i_f);
     }
 }
 
 extern "C" {
 
 size_t tsasr_fbank_workspace_bytes(int B, int T, int n_mels) {
-    return align_up((size_t)B * T * n_mels * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256);
+    return align_up((size_t)B * T * n_mels * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)2 * n_mels * sizeof(int), 256);
 }
 
 /* wav [B,L] fp32 -> out [B, T = 1 + L/hop, n_mels] (out_dtype): log-mel in dB with the per-utterance (max - top_db) floor.
@@ -152,8 +186,10 @@ int tsasr_fbank_fwd(const float *wav, const float *window, const float *melmat, 
     hipStream_t st = (hipStream_t)stream;
     float *db = (float *)workspace;
     int *umax = (int *)((char *)workspace + align_up((size_t)B * T * n_mels * sizeof(float), 256));
+    int *band = (int *)((char *)umax + align_up((size_t)B * sizeof(int), 256));
     fbank_init_kernel<<<cdiv(B, 64), 64, 0, st>>>(umax, B);
-    fbank_kernel<<<dim3(cdiv(T, 4), B), 256, 0, st>>>(wav, window, melmat, db, umax, L, T, n_mels, hop, amin);
+    fbank_bands_kernel<<<cdiv(n_mels, 64), 64, 0, st>>>(melmat, band, n_mels);
+    fbank_kernel<<<dim3(cdiv(T, 4), B), 256, 0, st>>>(wav, window, melmat, db, umax, band, L, T, n_mels, hop, amin);
     const long long per = (long long)T * n_mels;
     dim3 g2((unsigned)min((long long)64, (per + 255) / 256), B);
     if (out_dtype == TSASR_F32) fbank_floor_kernel<float><<<g2, 256, 0, st>>>(db, umax, (float *)out, per, top_db);
@@ -168,12 +204,12 @@ int tsasr_sentence_norm_fwd(const void *x, const int32_t *lens, void *y, int B, 
                             void *stream) {
     TSASR_CHECK_ARG(x && lens && y, "tsasr_sentence_norm_fwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && F > 0 && F <= 256, "tsasr_sentence_norm_fwd: bad shape (F=%d must be <= 256)", F);
-    const size_t lds = (size_t)((256 / F) * F + 2 * F) * sizeof(float);
+    const size_t lds = (size_t)((SN_NT / F) * F + 2 * F) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (in_dtype == TSASR_F32 && out_dtype == TSASR_F32) sentence_norm_kernel<float, float><<<B, 256, lds, st>>>((const float *)x, lens, (float *)y, T, F, eps);
-    else if (in_dtype == TSASR_F32 && out_dtype == TSASR_BF16) sentence_norm_kernel<float, bf16_t><<<B, 256, lds, st>>>((const float *)x, lens, (bf16_t *)y, T, F, eps);
-    else if (in_dtype == TSASR_BF16 && out_dtype == TSASR_BF16) sentence_norm_kernel<bf16_t, bf16_t><<<B, 256, lds, st>>>((const bf16_t *)x, lens, (bf16_t *)y, T, F, eps);
-    else if (in_dtype == TSASR_BF16 && out_dtype == TSASR_F32) sentence_norm_kernel<bf16_t, float><<<B, 256, lds, st>>>((const bf16_t *)x, lens, (float *)y, T, F, eps);
+    if (in_dtype == TSASR_F32 && out_dtype == TSASR_F32) sentence_norm_kernel<float, float><<<B, SN_NT, lds, st>>>((const float *)x, lens, (float *)y, T, F, eps);
+    else if (in_dtype == TSASR_F32 && out_dtype == TSASR_BF16) sentence_norm_kernel<float, bf16_t><<<B, SN_NT, lds, st>>>((const float *)x, lens, (bf16_t *)y, T, F, eps);
+    else if (in_dtype == TSASR_BF16 && out_dtype == TSASR_BF16) sentence_norm_kernel<bf16_t, bf16_t><<<B, SN_NT, lds, st>>>((const bf16_t *)x, lens, (bf16_t *)y, T, F, eps);
+    else if (in_dtype == TSASR_BF16 && out_dtype == TSASR_F32) sentence_norm_kernel<bf16_t, float><<<B, SN_NT, lds, st>>>((const bf16_t *)x, lens, (float *)y, T, F, eps);
     else TSASR_CHECK_ARG(false, "tsasr_sentence_norm_fwd: bad dtypes %d %d", in_dtype, out_dtype);
     TSASR_CHECK_LAUNCH("tsasr_sentence_norm_fwd");
     return 0;
