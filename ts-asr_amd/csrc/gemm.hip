@@ -129,7 +129,33 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
                                               const EpiArgs &ep, int tile_y, int tile_z) {
     constexpr int RB = BM / 64, CB = BN / 64;
     bf16_t *lds = reinterpret_cast<bf16_t *>(smem);
-    if (OUT_MODE == 0 && ep.mode != 0) {   // fused elementwise epilogue: fp32 tile, one rounding at the end
+    if (OUT_MODE == 0 && ep.mode == 1) {
+        // bias + LeakyReLU + dropout applied to the accumulators IN REGISTERS (accumulator layout: lane = one column, 16 rows per
+        // 32x32 block), then the plain bf16 staging / 16-byte store path below: half the LDS traffic of the fp32-tile epilogue and
+        // no second pass over the tile. An element's keep-bit is the half of its column pair's hash word selected by the column
+        // parity (common.h): lanes r and r^1 evaluate the same hash - redundant but branch-free.
+        const int r = lane & 31, hh = lane >> 5;
+        unsigned long long seed = ep.seed;
+        if (ep.seed_dev) seed += *ep.seed_dev;
+        const unsigned thr = drop_thr16(ep.p);
+        const float ks = drop_scale16(thr);
+        const DropKey dk = drop_key(seed);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int n = n0 + wn * (BN / 2) + 32 * j + r;
+            const float bj = (ep.bias && n < N) ? ep.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int m = m0 + wm * (BM / 2) + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                    float t = acc[i][j][g] + bj;
+                    if (ep.slope >= 0.f) t = lrelu(t, ep.slope);
+                    if (ep.p > 0.f) t = drop_keep1((unsigned long long)m * N + n, dk, thr) ? t * ks : 0.f;
+                    acc[i][j][g] = t;
+                }
+        }
+    } else if (OUT_MODE == 0 && ep.mode != 0) {   // fused elementwise epilogue: fp32 tile, one rounding at the end
         const int r = lane & 31, hh = lane >> 5;
         constexpr int LDT = BN + 4;
         constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
