@@ -391,3 +391,56 @@ def greedy_decode(enc_proj, sd, cfg):
             m = upd[:, None]
             out_pn, h, c = torch.where(m, o2, out_pn), torch.where(m, h2, h), torch.where(m, c2, c)
     return hyps
+
+# ----------------------------------------------------------------------------------------------
+# f1  beam transducer search  (SB/decoders/transducer.py:220-373), per utterance, no LM:
+#   A = hypotheses still to be extended at this frame, B = hypotheses that emitted blank at this frame (next frame's A).
+#   Until |B| >= beam: take the best a in A by length-normalised score (logp / len(prediction), blank prefix included); stop when
+#   the best b in B (same key) has logp >= state_beam + logp(a); run the predictor on a's last token; take the beam best symbols
+#   of log_softmax(joint(enc[t], pn)); blank -> copy of a with the score added goes to B (state unchanged); a non-blank symbol
+#   within expand_beam of the best non-blank -> a extended (new predictor state) goes back to A.
+#   Result: best of B by the same key; reported score = logp / len(prediction).
+# ----------------------------------------------------------------------------------------------
+def beam_decode(enc_proj, sd, cfg, beam_size=4, state_beam=2.3, expand_beam=2.3):
+    B, T, _ = enc_proj.shape
+    V, blank = cfg["vocab_size"], cfg["blank_index"]
+    wi, wh = sd["decoder.rnn.weight_ih_l0"], sd["decoder.rnn.weight_hh_l0"]
+    bias = sd["decoder.rnn.bias_ih_l0"] + sd["decoder.rnn.bias_hh_l0"]
+    Hd = wh.shape[1]
+
+    def pn_step(tok, state):
+        h, c = state if state is not None else (torch.zeros(1, Hd), torch.zeros(1, Hd))
+        x = one_hot_embedding(torch.tensor([tok]), V, blank)
+        g = x @ wi.t() + bias + h @ wh.t()
+        i, f, gg, o = g.chunk(4, dim=-1)
+        c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h2 = torch.sigmoid(o) * torch.tanh(c2)
+        return linear(h2, sd, "decoder_proj."), (h2, c2)
+
+    def key(hyp):
+        return hyp[1] / len(hyp[0])
+
+    hyps_out, scores_out = [], []
+    for b in range(B):
+        beam = [([blank], 0.0, None)]            # (prediction, logp, predictor state)
+        for t in range(T):
+            A, beam = beam, []
+            while len(beam) < beam_size:
+                a = max(A, key=key)
+                if beam and max(beam, key=key)[1] >= state_beam + a[1]:
+                    break
+                A.remove(a)
+                out_pn, new_state = pn_step(a[0][-1], a[2])
+                lg = linear(F.leaky_relu(enc_proj[b, t][None] + out_pn, LRELU_SLOPE), sd, "transducer_head.")
+                logp, pos = torch.topk(torch.log_softmax(lg, -1).view(-1), k=beam_size)
+                best_nonblank = logp[0] if int(pos[0]) != blank else logp[1]
+                for j in range(beam_size):
+                    sc = a[1] + float(logp[j])
+                    if int(pos[j]) == blank:
+                        beam.append((a[0][:], sc, a[2]))
+                    elif logp[j] >= best_nonblank - expand_beam:
+                        A.append((a[0] + [int(pos[j])], sc, new_state))
+        best = max(beam, key=key)
+        hyps_out.append(best[0][1:])
+        scores_out.append(best[1] / len(best[0]))
+    return hyps_out, scores_out

@@ -186,3 +186,25 @@ def test_hip_graph_replay_equals_eager():
             assert brain._graph is not None
     assert losses["eager"][0] > losses["eager"][-1]            # it trains
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)
+
+@pytest.mark.parametrize("beam", [4, 15])
+def test_beam_search_fp32_vs_reference_golden(brain32, golden, beam):
+    """decoders.TransducerBeamSearcher (beam > 1) on the golden encoder output against the reference's own hypotheses
+    (tests/golden/c1_beam.npz): bit-exact token sequences, length-normalised log-scores to 1e-3."""
+    brain, h = brain32
+    g = golden["c1_beam"]
+    m = brain.modules
+    dec = importlib.import_module("ts-asr_amd.decoders")
+    bias = m.transducer_head.w.bias
+    shift = float(g["blank_bias"])
+    with torch.no_grad():
+        bias[0] += shift          # the fixture was generated with the head's blank bias raised (oracle/gen_golden_beam.py)
+        try:
+            searcher = dec.TransducerBeamSearcher([m.embedding, m.decoder, m.decoder_proj], m.joiner, [m.transducer_head], blank_id=0,
+                                                  beam_size=beam, nbest=1, state_beam=2.3, expand_beam=2.3)
+            hyps, _, _, scores = searcher(T(golden["c1_chain_cat"]["enc_proj"]).to(DEV))
+        finally:
+            bias[0] -= shift
+    for b in range(4):
+        assert hyps[b] == g[f"beam{beam}_hyps"][b, : g[f"beam{beam}_lens"][b]].tolist(), b
+        assert abs(scores[b][0] - g[f"beam{beam}_scores"][b]) < 1e-3

@@ -261,3 +261,18 @@ def test_full_chain_backward(golden):
             close(sd[name].grad, g[k], atol=2e-5, rtol=5e-3)
         checked += 1
     assert checked > 150
+
+@pytest.mark.parametrize("beam", [4, 15])
+def test_beam_search_vs_reference(golden, beam):
+    """oracle.beam_decode against the reference's TransducerBeamSearcher (tests/golden/c1_beam.npz, oracle/gen_golden_beam.py):
+    token sequences bit-exact, length-normalised scores to 1e-4. The fixture raised the head's blank bias (see the generator)."""
+    g = golden["c1_beam"]
+    sd = full_state_dict(CFG1, "cat")
+    sd["transducer_head.w.bias"] = sd["transducer_head.w.bias"].clone()
+    sd["transducer_head.w.bias"][0] += float(g["blank_bias"])
+    enc_proj = T(golden["c1_chain_cat"]["enc_proj"])
+    with torch.no_grad():
+        hyps, scores = R.beam_decode(enc_proj, sd, CFG1, beam_size=beam)
+    for b in range(4):
+        assert hyps[b] == g[f"beam{beam}_hyps"][b, : g[f"beam{beam}_lens"][b]].tolist(), b
+        assert abs(scores[b] - g[f"beam{beam}_scores"][b]) < 1e-4

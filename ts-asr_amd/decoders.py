@@ -1,10 +1,11 @@
-"""Greedy transducer search with the reference's constructor/return shape
-(speechbrain/decoders/transducer.py:14-218; beam_size=1 => transducer_greedy_decode).
+"""Transducer search with the reference's constructor/return shape (speechbrain/decoders/transducer.py:14-373).
 
-At most one symbol per encoder frame; the predictor state of an utterance advances only when it emitted a
-non-blank. The per-frame decision stays on the device (argmax + masked state update, no per-item Python loop as in
-transducer.py:187-194); only the final token table is read back. Beam search (beam_size > 1, transducer.py:220-373)
-is SURVEY.md section 8f row f1 = next round.
+beam_size = 1 -> greedy (transducer.py:138-218): at most one symbol per encoder frame; the predictor state of an utterance
+advances only when it emitted a non-blank. The per-frame decision stays on the device (argmax + masked state update, no
+per-item Python loop as in transducer.py:187-194); only the final token table is read back.
+beam_size > 1 -> the reference's per-utterance beam search with state_beam / expand_beam pruning (transducer.py:220-373,
+no LM fusion): host-side hypothesis bookkeeping exactly as specified there, device-side predictor /
+joint / head steps. Pinned to the reference's own hypotheses by tests/golden/c1_beam.npz.
 """
 import torch
 import torch.nn.functional as F
@@ -16,13 +17,14 @@ class TransducerBeamSearcher(torch.nn.Module):
         super().__init__()
         self.decode_network_lst, self.tjoint, self.classifier_network = decode_network_lst, tjoint, classifier_network
         self.blank_id, self.beam_size, self.nbest = blank_id, beam_size, nbest
+        self.state_beam, self.expand_beam = state_beam, expand_beam
         if lm_module is not None or lm_weight != 0.0:
             raise NotImplementedError("LM fusion is not part of the TS-ASR recipes")
 
     def forward(self, tn_output):
         if self.beam_size <= 1:
             return self.transducer_greedy_decode(tn_output)
-        raise NotImplementedError("beam search (beam_size > 1) is SURVEY.md section 8f row f1; use beam_size=1")
+        return self.transducer_beam_search_decode(tn_output)
 
     def _pn(self, tok, hidden):
         emb, dec, proj = self.decode_network_lst
@@ -54,3 +56,42 @@ class TransducerBeamSearcher(torch.nn.Module):
         table = preds.cpu()
         hyps = [[int(x) for x in row[row >= 0]] for row in table]
         return hyps, logp_sum.exp().mean(), None, None
+
+    @torch.no_grad()
+    def transducer_beam_search_decode(self, tn_output):
+        """Returns (best hyps, mean exp(normalised score), n-best hyps, n-best normalised log-scores) like the reference.
+        A = hypotheses still to be extended at this frame, B = those that emitted blank here (the next frame's A). Until
+        |B| >= beam: take the best a in A by logp / len(prediction); stop once the best b in B has logp >= state_beam + logp(a);
+        run the predictor on a's last token, score the beam best symbols of the joint at this frame; blank closes a copy of
+        a into B, a non-blank symbol within expand_beam of the best non-blank extends a (new predictor state) back into A."""
+        dev = tn_output.device
+        key = lambda hyp: hyp[1] / len(hyp[0])  # noqa: E731
+        nbest_batch, nbest_scores = [], []
+        for b in range(tn_output.shape[0]):
+            beam = [([self.blank_id], 0.0, None)]           # (prediction incl. the blank prefix, logp, predictor state)
+            for t in range(tn_output.shape[1]):
+                A, beam = beam, []
+                frame = tn_output[b, t, :].view(1, 1, 1, -1)
+                while len(beam) < self.beam_size:
+                    a = max(A, key=key)
+                    if beam and max(beam, key=key)[1] >= self.state_beam + a[1]:
+                        break
+                    A.remove(a)
+                    tok = torch.full((1, 1), a[0][-1], dtype=torch.long, device=dev)
+                    out_pn, new_state = self._pn(tok, a[2])
+                    j = self.tjoint(frame, out_pn.unsqueeze(0))
+                    for layer in self.classifier_network:
+                        j = layer(j)
+                    logp, pos = torch.topk(F.log_softmax(j.float(), dim=-1).view(-1), k=self.beam_size)
+                    logp, pos = logp.tolist(), pos.tolist()      # one host read per expansion (the reference: one per symbol)
+                    best_nonblank = logp[0] if pos[0] != self.blank_id else logp[1]
+                    for lp, sym in zip(logp, pos):
+                        if sym == self.blank_id:
+                            beam.append((a[0][:], a[1] + lp, a[2]))
+                        elif lp >= best_nonblank - self.expand_beam:
+                            A.append((a[0] + [sym], a[1] + lp, new_state))
+            ranked = sorted(beam, key=key, reverse=True)[: self.nbest]
+            nbest_batch.append([h[0][1:] for h in ranked])
+            nbest_scores.append([h[1] / len(h[0]) for h in ranked])
+        best = [n[0] for n in nbest_batch]
+        return best, torch.tensor([s_[0] for s_ in nbest_scores]).exp().mean(), nbest_batch, nbest_scores
