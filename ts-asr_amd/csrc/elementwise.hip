@@ -22,6 +22,7 @@ template <> __device__ __forceinline__ void ldv<float, 4>(const float *p, float 
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
 }
 template <> __device__ __forceinline__ void ldv<bf16_t, 8>(const bf16_t *p, float (&o)[8]) { ld8(p, o); }
+template <> __device__ __forceinline__ void ldv<float, 8>(const float *p, float (&o)[8]) { ld8(p, o); }   // fp32 parameters beside bf16 rows
 template <typename T, int N> __device__ __forceinline__ void stv(T *p, const float (&v)[N]);
 template <> __device__ __forceinline__ void stv<float, 4>(float *p, const float (&v)[4]) {
     *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -452,14 +453,15 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * 64 + l) * N;
         if (c < D) {
-            float xv[N], rv[N];
+            float xv[N], rv[N], bv[N];
             ldv<T, N>(x + row * D + c, xv);
             ldv<T, N>(res + row * D + c, rv);
+            if (bias) ldv<float, N>(bias + c, bv);   // 16-byte parameter loads, requested together with the row
             const unsigned long long idx = (unsigned long long)row * D + c;
             const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float t = xv[j] + (bias ? bias[c + j] : 0.f);
+                float t = xv[j] + (bias ? bv[j] : 0.f);
                 if (p > 0.f) t = ((km >> j) & 1u) ? t * ks : 0.f;
                 t = live ? t * alpha : 0.f;
                 t += rv[j];
@@ -486,9 +488,11 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * 64 + l) * N;
         if (c < D) {
-            float o[N];
+            float o[N], gv[N], bt[N];
+            ldv<float, N>(gamma + c, gv);
+            ldv<float, N>(beta + c, bt);
 #pragma unroll
-            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu) * rs * gamma[c + j] + beta[c + j];
+            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu) * rs * gv[j] + bt[j];
             stv<T, N>(y + row * D + c, o);
         }
     }
