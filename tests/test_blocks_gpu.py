@@ -470,6 +470,46 @@ def test_lstm_hip_path_vs_oracle(ops, B, U, H):
         assert float((a - r_).norm() / r_.norm()) < 3e-2, k
 
 
+def test_lstm_persistent_kernels_survive_graph_replay_with_dirty_workspace():
+    """The whole-sequence kernels rely on arrival counters in the first 256 workspace bytes being zero at launch. Inside a
+    replayed hipGraph the workspace is recycled memory: fill it (counters AND exchange payload) with 0xFF between replays; every
+    replay must give the bits of the eager call (a captured hipMemsetAsync node failed exactly this from the 2nd replay on)."""
+    from importlib import import_module
+    C = import_module("ts-asr_amd._capi")
+    B, U, H = 32, 33, 512
+    g = torch.Generator().manual_seed(3)
+    gates0 = (torch.randn(B, U, H, 4, generator=g) * 0.5).to(DEV)
+    whh = (torch.randn(4 * H, H, generator=g) * 0.04).to(DEV).to(torch.bfloat16)
+    whhT = whh.t().contiguous()
+    dout = torch.randn(B, U, H, generator=g).to(DEV).to(torch.bfloat16)
+    lib = C.lib()
+    nb = lib.tsasr_lstm_seq_workspace_bytes(B, U, H)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    gates, c = torch.empty_like(gates0), torch.empty(B, U, H, device=DEV)
+    h, dgates = torch.empty(B, U, H, dtype=torch.bfloat16, device=DEV), torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=DEV)
+
+    def run():
+        gates.copy_(gates0)
+        C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh), B, U, H, C.BF16, C.ptr(ws), nb, C.stream_ptr()), "fwd")
+        C.check(lib.tsasr_lstm_seq_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), B, U, H, C.BF16, C.ptr(ws), nb,
+                                       C.stream_ptr()), "bwd")
+
+    run()
+    torch.cuda.synchronize()
+    h_ref, dg_ref = h.clone(), dgates.clone()
+    assert torch.isfinite(h_ref.float()).all() and torch.isfinite(dg_ref.float()).all()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for _ in range(4):
+        ws.fill_(0xFF)
+        h.zero_()
+        dgates.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(h, h_ref) and torch.equal(dgates, dg_ref)
+
+
 def test_fbank_and_sentence_norm_known_answers(nn_, ops):
     """Reference known answers (vendor/speechbrain/tests/unittests/test_features.py:57-113) on the HIP kernels + oracle parity."""
     from oracle import tsasr_ref as R

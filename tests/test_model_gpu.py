@@ -166,26 +166,30 @@ def test_bf16_step_close_to_fp32_oracle_and_updates_weights():
     assert brain.flush_nonfinite() == 0
 
 
-def test_hip_graph_replay_equals_eager():
+@pytest.mark.parametrize("accum", [1, 2])
+def test_hip_graph_replay_equals_eager(accum):
     """The captured hipGraph step (forward, loss, backward, clip+AdamW) must reproduce the eager steps bit for bit
-    (dropout = 0 in this config; every kernel is deterministic), including the Noam schedule acting through device memory."""
+    (dropout = 0 in this config; every kernel is deterministic), including the Noam schedule acting through device memory.
+    accum = 2: two captured flavours (accumulate-only micro-step, stepping micro-step) replayed alternately."""
     inp = golden_inputs()
     losses = {}
     for mode in ("eager", "graph"):
         brain, h = entry._config1_brain(DEV, "bf16")
+        brain.grad_accumulation_factor = accum
         brain.modules.train()
         if mode == "graph":
             brain.enable_hip_graph(warmup_steps=2)
         batch = make_batch(inp).to(DEV)
         ls = []
-        for _ in range(6):
+        for _ in range(8):
             ls.append(float(brain.fit_batch(batch)))
         losses[mode] = ls
-        assert brain.optimizer_step == 6
+        assert brain.optimizer_step == 8 // accum
         if mode == "graph":
-            assert brain._graph is not None
+            assert brain._graph is not None and len(brain._graphs) == (1 if accum == 1 else 2)
     assert losses["eager"][0] > losses["eager"][-1]            # it trains
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)
+
 
 @pytest.mark.parametrize("beam", [4, 15])
 def test_beam_search_fp32_vs_reference_golden(brain32, golden, beam):

@@ -1,0 +1,15 @@
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+bench = importlib.import_module("bench")
+batch_mod = importlib.import_module(bench.PKG + ".batch")
+brain, h, _ = bench.build_brain("cuda:0", "bf16", 100)
+batch = batch_mod.synthetic_batch(bench.B_LOCAL, bench.T_MEL, bench.T_ENROLL, bench.U, feats=True, seed=1234).to("cuda:0")
+brain.enable_hip_graph(warmup_steps=3)
+for i in range(9):
+    loss = brain.fit_batch(batch)
+    torch.cuda.synchronize()
+    bad = [n for n, p in brain.modules.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    a = brain.arena
+    print(i, float(loss), "graphs", list(brain._graphs), "bad grads", bad[:6], len(bad),
+          "shadowT finite", bool(torch.isfinite(a.flat_params16_t.float()).all()), flush=True)

@@ -151,7 +151,7 @@ class Brain:
         self.optimizer = None
         self.arena = None
         self._graph_mode, self._graph, self._graph_warmup, self._eager_steps = False, None, 3, 0
-        self._static_batch = self._static_loss = None
+        self._static_batch, self._static_loss, self._graphs, self._graph_pool, self._eager_stepped = None, {}, {}, None, False
         self.rank = int(os.environ.get("RANK", 0))
         self.distributed = bool(self.distributed_launch) and _dp.is_initialized()
 
@@ -217,8 +217,8 @@ class Brain:
             self.on_fit_start()
         self.valid_step += 1
         should_step = (self.valid_step % self.grad_accumulation_factor) == 0
-        if self._graph_mode and self.grad_accumulation_factor == 1:
-            loss, outputs = self._fit_batch_graph(batch), None
+        if self._graph_mode:
+            loss, outputs = self._fit_batch_graph(batch, should_step), None
         else:
             with self.no_sync(not should_step):
                 loss, outputs = self._device_step(batch, should_step, comm=True)
@@ -251,31 +251,48 @@ class Brain:
         gradient all-reduce runs between two graphs (forward+backward | optimizer)."""
         self._graph_mode, self._graph_warmup = True, int(warmup_steps)
 
-    def _fit_batch_graph(self, batch):
-        if self._graph is None:
-            if self._eager_steps < self._graph_warmup:
-                self._eager_steps += 1
-                loss, _ = self._device_step(batch, True, comm=True)
+    def _fit_batch_graph(self, batch, should_step=True):
+        """Two graphs at most: the micro-step that only accumulates gradients and the one that also clips / steps / clears
+        (gradient accumulation: grad_accumulation_factor - 1 replays of the first, one of the second)."""
+        if self._eager_steps < self._graph_warmup or not self._eager_stepped:
+            # eager until the allocator is warm AND one optimizer step has run: the arena re-lays itself out in backward order when
+            # the gradients are first cleared, which must not happen inside a capture
+            self._eager_steps += 1
+            with self.no_sync(not should_step):
+                loss, _ = self._device_step(batch, should_step, comm=True)
+            if should_step:
                 self.optimizer_step += 1
-                return loss
-            self._capture(batch)
+                self._eager_stepped = True
+            return loss
+        flavour = "step" if should_step else "accumulate"
+        if should_step:
+            self.optimizer.prepare()            # host half (step count, lr -> device); also allocates its buffers before a capture
+        if flavour not in self._graphs:
+            self._capture(batch, should_step)
         else:
             self._copy_batch(batch)
-        self.optimizer.prepare()
-        self._graph.replay()
-        if self.distributed:                    # one big averaged all-reduce between the two halves of the step
-            self.arena.allreduce_all()
-            self.optimizer.launch()
-            self.arena.zero_()
-        self.optimizer_step += 1
-        return self._static_loss
+        self._graphs[flavour].replay()
+        if should_step:
+            if self.distributed:                # one big averaged all-reduce between the two halves of the step
+                self.arena.allreduce_all()
+                self.optimizer.launch()
+                self.arena.zero_()
+            self.optimizer_step += 1
+        return self._static_loss[flavour]
 
-    def _capture(self, batch):
-        self._static_batch = batch.to(self.device)
+    def _capture(self, batch, should_step=True):
+        if self._static_batch is None:
+            self._static_batch = batch.to(self.device)
+        else:
+            self._copy_batch(batch)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._static_loss, _ = self._device_step(self._static_batch, True, comm=False)
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            loss, _ = self._device_step(self._static_batch, should_step, comm=False)
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        flavour = "step" if should_step else "accumulate"
+        self._graphs[flavour], self._static_loss[flavour] = g, loss
         self._graph = g
 
     def _copy_batch(self, batch):

@@ -6,6 +6,8 @@
 // Layout: gates [B, U, H, 4] fp32 - the four gates (i,f,g,o) of a unit are ONE float4 (the caller permutes the rows of W_ih
 // accordingly; pre-activations in, ACTIVATED gates out - kept for the backward); dgates [B, U, 4H] gate-major; c [B, U, H] fp32,
 // h [B, U, H] in the activation dtype (it is the next step's GEMM operand and the layer output).
+#include <algorithm>
+
 #include "common.h"
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: 5 transcendentals per cell sit on the recurrence's critical path
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
 //     consumer: ONE lane polls the counter with sc1 loads (s_sleep between polls, bounded) -> workgroup barrier -> every
 //               load of the payload is an sc1 16-byte buffer load straight to registers (MFMA B-fragments).
 //   (gfx950's eight XCD-private L2s are not coherent with each other: plain loads of another workgroup's stores are stale.)
-//   Each step's payload has its own location (no reuse inside a launch); the counter is zeroed by a memset node ahead of the
+//   Each step's payload has its own location (no reuse inside a launch); the counter is zeroed by a tiny fill kernel ahead of the
 //   launch. Grid = (H/32, ceil(B/16)) <= the CU count, 1 workgroup per CU (96 KB of dynamic LDS keeps a second one away), so
 //   every workgroup is resident and the per-step waits cannot deadlock; a poll that never matches gives up after ~1 s,
 //   raises the error word and poisons the output with NaN (the step's finite-check then rejects the update).
@@ -409,12 +411,22 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 
 #define LQ_BR 16   // batch rows per exchange group
 
+// Zero-fill by a kernel, NOT hipMemsetAsync: a memset node captured into a hipGraph wrote stale host bytes instead of zeros from
+// the second replay on (ROCm 7.2, 256-byte fill: the arrival counters then started at garbage and the waits passed early).
+__global__ void zero_words_kernel(unsigned *p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static void zero_async(void *p, size_t bytes, hipStream_t st) {   // bytes % 4 == 0
+    const size_t n = bytes / 4;
+    zero_words_kernel<<<(unsigned)std::min<size_t>(1024, (n + 255) / 256), 256, 0, st>>>((unsigned *)p, n);
+}
+
 template <int H>
 static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
     auto kern = lstm_seq_fwd_kernel<H, LQ_BR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
-    (void)hipMemsetAsync(ws, 0, 256, st);
+    zero_async(ws, 256, st);
     kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
 }
 template <int H>
@@ -422,7 +434,7 @@ static void launch_seq_bwd(const float *gates, const float *c, const void *dout,
     auto kern = lstm_seq_bwd_kernel<H, LQ_BR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
-    (void)hipMemsetAsync(ws, 0, 256, st);
+    zero_async(ws, 256, st);
     kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
 }
 
@@ -518,7 +530,7 @@ int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, voi
     }
     const size_t G = (size_t)cdiv(B, 32);
     float *dc_io = (float *)((char *)workspace + 256 + align_up(G * U * 32 * 4 * (size_t)H * sizeof(bf16_t), 256));
-    (void)hipMemsetAsync(dc_io, 0, (size_t)B * H * sizeof(float), st);
+    zero_async(dc_io, (size_t)B * H * sizeof(float), st);
     for (int t = U - 1; t >= 0; --t) {
         const int rc = tsasr_lstm_step_bwd(gates, c, dout, dgates, whhT, dc_io, B, U, H, t, io_dtype, stream);
         if (rc) return rc;

@@ -74,10 +74,11 @@ class GradArena:
         if self.device.type == "cuda":
             # pinned / device job tables are created NOW: their first use may be inside a hipGraph capture (multi-rank runs only
             # defer inside the captured step), where a host allocation is not permitted
-            cap = max(1024, 2 * len(params)) * 20
-            self._defer_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self._defer_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
             from . import ops
+            cap = max(1024, 2 * len(params)) * 20
+            self._defer_host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(ops._TABLE_PAIRS)]
+            self._defer_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(ops._TABLE_PAIRS)]
+            self._defer_state = {"captures": 0}
             ops.reduce_defer_prepare(self.device)
 
     # ---- layout ---------------------------------------------------------------------------------------
@@ -173,20 +174,26 @@ class GradArena:
         import numpy as np
         from . import _capi as C
         n = len(self._deferred)
-        if self._defer_host is None or self._defer_host.numel() < n * 20:
+        from . import ops
+        if self._defer_host is None:            # CPU-constructed arena moved to the GPU later: allocate on first (eager) use
             cap = max(1024, 2 * n) * 20
-            self._defer_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self._defer_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self._defer_host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(ops._TABLE_PAIRS)]
+            self._defer_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(ops._TABLE_PAIRS)]
+            self._defer_state = {"captures": 0}
+        k = ops.table_slot(self._defer_state)   # slot 0 eagerly, a fresh pair per captured graph (its memcpy node re-reads the host table)
+        host, dev = self._defer_host[k], self._defer_dev[k]
+        if host.numel() < n * 20:
+            raise RuntimeError("deferred-gradient table too small")
         tab = np.empty(n * 20, np.uint8)
         tab[:n * 8].view(np.uint64)[:] = [g.data_ptr() for g, _ in self._deferred]
         tab[n * 8:n * 16].view(np.uint64)[:] = [p.grad.data_ptr() for _, p in self._deferred]
         tab[n * 16:].view(np.int32)[:] = [g.numel() for g, _ in self._deferred]
-        key = tab.tobytes()
-        if key != self._defer_key:          # same pointers as last step (always true under graph replay): skip the upload
-            self._defer_host[:n * 20].copy_(torch.from_numpy(tab))
-            self._defer_dev[:n * 20].copy_(self._defer_host[:n * 20], non_blocking=True)
+        key = (k, tab.tobytes())
+        if key != self._defer_key or k > 0:     # same pointers as the last eager step: skip the upload
+            host[:n * 20].copy_(torch.from_numpy(tab))
+            dev[:n * 20].copy_(host[:n * 20], non_blocking=True)
             self._defer_key = key
-        C.check(C.lib().tsasr_accumulate_many(C.ptr(self._defer_dev), n, C.stream_ptr()), "tsasr_accumulate_many")
+        C.check(C.lib().tsasr_accumulate_many(C.ptr(dev), n, C.stream_ptr()), "tsasr_accumulate_many")
         self._keepalive = self._deferred    # the temporaries must outlive the launch
         self._deferred = []
 

@@ -67,12 +67,26 @@ def _keep(*tensors):
         _DEFER["keep"].extend(t for t in tensors if t is not None)
 
 
+_TABLE_PAIRS = 4   # slot 0: eager flushes; slots 1.. : one per captured graph (a replayed memcpy node re-reads ITS host table)
+
+
 def reduce_defer_prepare(device):
     """Allocate the job tables (pinned host + device) outside of any graph capture."""
     if torch.device(device).type == "cuda" and _DEFER["host"] is None:
         nb = C.lib().tsasr_reduce_table_bytes(_DEFER_MAX_JOBS)
-        _DEFER["host"] = torch.empty(nb, dtype=torch.uint8).pin_memory()
-        _DEFER["dev"] = torch.empty(nb, dtype=torch.uint8, device=device)
+        _DEFER["host"] = [torch.empty(nb, dtype=torch.uint8).pin_memory() for _ in range(_TABLE_PAIRS)]
+        _DEFER["dev"] = [torch.empty(nb, dtype=torch.uint8, device=device) for _ in range(_TABLE_PAIRS)]
+        _DEFER["captures"] = 0
+
+
+def table_slot(state):
+    """Index of the (pinned host, device) table pair to use now: 0 when executing eagerly, a fresh one per stream capture."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    state["captures"] += 1
+    if state["captures"] >= _TABLE_PAIRS:
+        raise RuntimeError("more captured graphs than job-table slots (ops._TABLE_PAIRS)")
+    return state["captures"]
 
 
 def reduce_defer_begin(device):
@@ -89,7 +103,10 @@ def reduce_flush():
         return
     if C.lib().tsasr_reduce_pending() > _DEFER_MAX_JOBS:
         raise C.TsasrHipError("more queued reductions than the job table holds")
-    C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"]), C.ptr(_DEFER["dev"]), _DEFER["host"].numel(), C.stream_ptr()), "tsasr_reduce_flush")
+    if C.lib().tsasr_reduce_pending() > 0:
+        k = table_slot(_DEFER)
+        C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
+                "tsasr_reduce_flush")
     _DEFER["keep"] = []
 
 
