@@ -178,7 +178,7 @@ def main():
         torch.cuda.synchronize()
         prof.ENABLED = False
         brain._graph_mode = True
-    feat_ms = None
+    feat_ms, aug_ms = None, {}
     if rank == 0:   # Fbank + sentence norm are timed separately, on wav ~ N(0, 0.1^2) [32, 159840] (the step is fed features)
         wav = torch.randn(B_LOCAL, T_MEL * 160 - 160, device=device) * 0.1
         wlens = torch.ones(B_LOCAL, device=device)
@@ -193,6 +193,20 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             feat_ms = e0.elapsed_time(e1) / 10
+            # the two augmenters of compute_forward (`augment: True`), same shapes: SpecAugment on [32,1000,80] features (draw + warp +
+            # masks), speed perturbation of the [32,159840] waveform to 95 % (the headline step runs with the YAML default augment: False)
+            feats = nm(fx(wav), wlens, epoch=0)
+            aug_ms = {}
+            for name, fn in (("specaugment_ms", lambda: brain.modules.augmentation(feats)),
+                             ("speed_perturb_ms", lambda: brain.modules.speed_perturb.resamplers[0](wav))):
+                for _ in range(3):
+                    fn()
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                aug_ms[name] = round(e0.elapsed_time(e1) / 10, 4)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -243,6 +257,7 @@ def main():
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 1),
             "rnnt_joint_loss_ms": round(rnnt_ms, 4),
             "fbank_sentnorm_ms": None if feat_ms is None else round(feat_ms, 4),
+            **aug_ms,
             "loss": round(float(loss), 4), "nonfinite_steps": nonfinite,
             "hip_kernels": fam,
             "roofline": roof,

@@ -272,6 +272,30 @@ int tsasr_reduce_pending(void);
 size_t tsasr_reduce_table_bytes(int max_jobs);
 int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 
+/* SpecAugment on the normalised features (speechbrain/lobes/augment.py:32-201, applied at train_librispeechmix_scratch.py:91-94;
+ * recipe settings conformer-t_scratch.yaml:132-142). tsasr_specaug_draw produces every random number of one call on the device
+ * (params: tsasr_specaug_params_words(B, n_freq_mask, n_time_mask) int32 = {c, w, freq widths [B][nf], freq starts, time widths
+ * [B][nt], time starts}; c ~ U[window, T-window), w ~ U[c-window, c+window)+1, width ~ U[lo, hi), start ~ U[0, max(1, D - max width
+ * over the batch)); window == 0 or T - window <= window: c = w = 0 = no warp). tsasr_specaug_apply: y = masks(warp(x)) for x, y
+ * [B,T,F] (y != x): bicubic (cubic convolution, align_corners) resize of [0,c) -> [0,w) and [c,T) -> [w,T) along time, then frequency
+ * masks filled with mean(warped) and time masks filled with mean(frequency-masked) (0 when replace_with_zero). At most 8 masks per
+ * axis. No host synchronisation anywhere (the reference syncs once per mask axis on mask_len.max()). */
+size_t tsasr_specaug_params_words(int B, int n_freq_mask, int n_time_mask);
+int tsasr_specaug_draw(int32_t *params, int B, int T, int F, int window, int n_freq_mask, int f_lo, int f_hi, int n_time_mask, int t_lo,
+                       int t_hi, unsigned long long seed, const unsigned long long *seed_dev, void *stream);
+size_t tsasr_specaug_workspace_bytes(void);
+int tsasr_specaug_apply(const void *x, void *y, const int32_t *params, int B, int T, int F, int n_freq_mask, int n_time_mask,
+                        int replace_with_zero, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Speed perturbation = polyphase windowed-sinc resampling of the waveform (speechbrain/processing/speech_augmentation.py:435-820,
+ * applied at train_librispeechmix_scratch.py:82-85; recipe: 16 kHz -> 15.2 / 16 / 16.8 kHz). x [B,L] fp32 -> y [B,n_out] with
+ * n_out = tsasr_resample_out_len(L, orig, new); weights [P,W] fp32 / first [P] int32 (device) are the filter bank and first input
+ * index per phase (P = new/gcd phases, stride = orig/gcd input samples per unit), built by the host as Resample._indices_and_weights
+ * does. Output n = q*P + i is sum_j weights[i][j] * x[first[i] + q*stride + j] with zeros outside the signal. */
+long long tsasr_resample_out_len(long long n_in, int orig_freq, int new_freq);
+int tsasr_resample_fwd(const float *x, float *y, const float *weights, const int32_t *first, int B, int L, int n_out, int P, int stride,
+                       int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

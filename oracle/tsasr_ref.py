@@ -444,3 +444,131 @@ def beam_decode(enc_proj, sd, cfg, beam_size=4, state_beam=2.3, expand_beam=2.3)
         hyps_out.append(best[0][1:])
         scores_out.append(best[1] / len(best[0]))
     return hyps_out, scores_out
+
+
+# ----------------------------------------------------------------------------------------------
+# A17  SpecAugment  (SB/lobes/augment.py:32-201; recipe settings conformer-t_scratch.yaml:132-142;
+#      applied to the normalised features in TRAIN stage, train_librispeechmix_scratch.py:91-94)
+# ----------------------------------------------------------------------------------------------
+def _cubic_taps(t, A=-0.75):
+    """Cubic-convolution weights of the four taps around a source position with fractional part ``t`` (what
+    F.interpolate(mode="bicubic") uses; float32 throughout like its CPU kernel)."""
+    import numpy as np
+    t = t.astype(np.float32)
+    A = np.float32(A)
+    one, two, three, four, five, eight = (np.float32(v) for v in (1, 2, 3, 4, 5, 8))
+
+    def near(x):   # |x| <= 1
+        return ((A + two) * x - (A + three)) * x * x + one
+
+    def far(x):    # 1 < |x| < 2
+        return ((A * x - five * A) * x + eight * A) * x - four * A
+
+    return far(t + one), near(t), near(one - t), far(two - t)
+
+
+def time_resize_bicubic(x, out_len):
+    """x [B,Tin,F] -> [B,out_len,F]: F.interpolate(x[:,None], (out_len, F), mode="bicubic", align_corners=True) restated. The
+    feature axis keeps its size, so with align_corners its taps are exactly (0,1,0,0): a 1-D cubic along time. Source position
+    of output row i is i*(Tin-1)/(out_len-1); taps are clamped at the borders (augment.py:138-149)."""
+    import numpy as np
+    xn = x.detach().cpu().numpy().astype(np.float32)
+    Tin = xn.shape[1]
+    scale = np.float32(Tin - 1) / np.float32(out_len - 1) if out_len > 1 else np.float32(0)
+    src = scale * np.arange(out_len, dtype=np.float32)
+    i0 = np.minimum(np.floor(src).astype(np.int64), Tin - 1)
+    t = np.clip(src - i0.astype(np.float32), 0, 1)
+    w = _cubic_taps(t)
+    out = None
+    for k in range(4):
+        idx = np.clip(i0 - 1 + k, 0, Tin - 1)
+        term = w[k][None, :, None] * xn[:, idx, :]
+        out = term if out is None else out + term
+    return torch.from_numpy(out.astype(np.float32))
+
+
+def spec_augment(x, c=None, w=None, flen=None, fpos=None, tlen=None, tpos=None, window=5, replace_with_zero=False):
+    """SpecAugment.forward with the random draws given: ``c`` = warp centre, ``w`` = its new position (both None = no warp),
+    ``flen/fpos`` [B,n_freq_mask] and ``tlen/tpos`` [B,n_time_mask] = mask widths / starts (None = that mask is off).
+    Order as the reference: warp, frequency masks (fill = mean of the warped tensor), time masks (fill = mean of the
+    frequency-masked tensor) - augment.py:106-114,151-199."""
+    x = x.clone().float()
+    B, T, Fd = x.shape
+    if c is not None and T - window > window:
+        c, w = int(c), int(w)
+        x = torch.cat([time_resize_bicubic(x[:, :c], w), time_resize_bicubic(x[:, c:], T - w)], dim=1)
+    for lens, pos, dim in ((flen, fpos, 2), (tlen, tpos, 1)):
+        if lens is None:
+            continue
+        D = x.shape[dim]
+        lens, pos = torch.as_tensor(lens).view(B, -1, 1), torch.as_tensor(pos).view(B, -1, 1)
+        ar = torch.arange(D).view(1, 1, -1)
+        mask = ((pos <= ar) & (ar < pos + lens)).any(dim=1)
+        mask = mask.unsqueeze(2) if dim == 1 else mask.unsqueeze(1)
+        val = 0.0 if replace_with_zero else float(x.mean())
+        x = x.masked_fill(mask, val)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# A18  SpeedPerturb / Resample  (SB/processing/speech_augmentation.py:435-820; recipe: speeds [95,100,105] at 16 kHz,
+#      conformer-t_scratch.yaml:144-146; applied to the mixture waveform, train_librispeechmix_scratch.py:82-85)
+# ----------------------------------------------------------------------------------------------
+def resample_filters(orig_freq, new_freq, lowpass_filter_width=6):
+    """(first_indices [P] float, weights [P,W] float32): the polyphase windowed-sinc bank of Resample._indices_and_weights
+    (:758-820). P = new/gcd output samples per unit of orig/gcd input samples; cutoff 0.99 * Nyquist of the lower rate,
+    Hann window of half-width lowpass_filter_width / (2 cutoff)."""
+    base = math.gcd(orig_freq, new_freq)
+    P = new_freq // base
+    cutoff = 0.99 * 0.5 * min(orig_freq, new_freq)
+    half = lowpass_filter_width / (2.0 * cutoff)
+    out_t = torch.arange(0.0, P) / new_freq
+    lo = torch.ceil((out_t - half) * orig_freq)
+    hi = torch.floor((out_t + half) * orig_freq)
+    width = int((hi - lo + 1).max())
+    idx = lo[:, None] + torch.arange(width)[None, :]
+    dt = idx / orig_freq - out_t[:, None]
+    wts = torch.zeros_like(dt)
+    inside = dt.abs() < half
+    wts[inside] = 0.5 * (1 + torch.cos(2 * math.pi * cutoff / lowpass_filter_width * dt[inside]))
+    nz = dt != 0
+    wts[nz] *= torch.sin(2 * math.pi * cutoff * dt[nz]) / (math.pi * dt[nz])
+    wts[~nz] *= 2 * cutoff
+    return lo, wts / orig_freq
+
+
+def resample_out_len(n_in, orig_freq, new_freq):
+    """Resample._output_samples (:705-756): number of output instants k/new_freq inside [0, n_in/orig_freq)."""
+    if n_in <= 0:
+        return 0
+    tick = orig_freq * new_freq // math.gcd(orig_freq, new_freq)
+    span, per_out = n_in * (tick // orig_freq), tick // new_freq
+    last = span // per_out
+    if last * per_out == span:
+        last -= 1
+    return last + 1
+
+
+def resample(wav, orig_freq, new_freq, lowpass_filter_width=6):
+    """wav [B,L] -> [B,resample_out_len(L)]. Output sample n = q*P + i (phase i of unit q) is the dot product of filter i with
+    the input starting at first_indices[i] + q*stride, zeros outside the signal (Resample._perform_resample :618-703, which
+    reaches the same sums through one strided conv1d per phase scattered by a transposed conv)."""
+    import numpy as np
+    if orig_freq == new_freq:
+        return wav
+    base = math.gcd(orig_freq, new_freq)
+    stride, P = orig_freq // base, new_freq // base
+    first, wts = resample_filters(orig_freq, new_freq, lowpass_filter_width)
+    first, wts = first.numpy().astype(np.int64), wts.numpy().astype(np.float32)
+    x = wav.detach().cpu().numpy().astype(np.float32)
+    B, L = x.shape
+    n_out = resample_out_len(L, orig_freq, new_freq)
+    n = np.arange(n_out)
+    start = first[n % P] + (n // P) * stride
+    W = wts.shape[1]
+    y = np.zeros((B, n_out), np.float32)
+    for j in range(W):                       # same tap order as a conv1d accumulating left to right
+        pos = start + j
+        ok = (pos >= 0) & (pos < L)
+        y += np.where(ok[None, :], x[:, np.clip(pos, 0, L - 1)], np.float32(0)) * wts[n % P, j][None, :]
+    return torch.from_numpy(y)

@@ -563,3 +563,108 @@ def test_fused_ffn_core(ops, p):
     if p == 0.0:  # and against plain fp32 math
         ref = torch.nn.functional.leaky_relu(x.float() @ w1.to(torch.bfloat16).float().t() + b1, 0.01).to(torch.bfloat16).float() @ w2.to(torch.bfloat16).float().t()
         assert float((outs[0][0] - ref).norm() / ref.norm()) < 6e-3
+
+
+# ---------------------------------------------------------------------------------------------- augmenters (compute_forward, TRAIN)
+def _sa_table(g, key, B, nf, nt, dev=DEV):
+    """Device draw table (layout of include/tsasr_hip.h) from the reference draws stored in the fixture."""
+    warp = key + "_c" in g.files
+    words = [int(g[key + "_c"][0]) if warp else 0, int(g[key + "_w"][0]) if warp else 0]
+    for k in ("_flen", "_fpos", "_tlen", "_tpos"):
+        words += g[key + k].reshape(-1).tolist()
+    t = torch.tensor(words, dtype=torch.int32, device=dev)
+    assert t.numel() == 2 + 2 * B * (nf + nt)
+    return t
+
+
+@pytest.mark.parametrize("name,nf,nt,zero", [("recipe", 2, 2, False), ("zero", 2, 2, True), ("nowarp", 3, 1, False)])
+@pytest.mark.parametrize("rep", [0, 1, 2])
+def test_spec_augment_kernels_vs_reference_golden(golden, ops, name, nf, nt, zero, rep):
+    """tsasr_specaug_apply with the REFERENCE's draws against the reference's output (tests/golden/c1_augment.npz): bicubic time
+    warp + frequency masks + time masks with the running global mean as fill. fp32; 1e-5 (cubic taps via FMA, mean via partials)."""
+    g = golden["c1_augment"]
+    x = T(g["sa_x"]).to(DEV)
+    y = ops.spec_augment_apply(x, _sa_table(g, f"sa_{name}_{rep}", 4, nf, nt), nf, nt, zero)
+    close(y, g[f"sa_{name}_{rep}_y"], 1e-5, 1e-5)
+    assert torch.equal(x.cpu(), T(g["sa_x"]))                 # the input is left untouched
+
+
+def test_spec_augment_module_draws_and_graph_replay(nn_, ops):
+    """nnet.SpecAugment end to end: (1) the device draws respect the reference's ranges (SB/lobes/augment.py:131-136,173-180) and
+    their empirical means match the uniform laws; (2) output == oracle.spec_augment fed with those very draws (fp32 and bf16 io);
+    (3) too-short inputs skip the warp; (4) captured into a hipGraph, every replay draws new numbers."""
+    from oracle import tsasr_ref as R
+    aug = nn_.SpecAugment(time_warp=True, time_warp_window=5, freq_mask=True, n_freq_mask=2, time_mask=True, n_time_mask=2,
+                          replace_with_zero=False, freq_mask_width=30, time_mask_width=20).to(DEV)
+    B, Tn, Fq = 64, 300, 80
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Tn, Fq, generator=g)
+    cs, ws, fl, tl, fp_, tp = [], [], [], [], [], []
+    for _ in range(40):
+        ops.begin_step(torch.device(DEV))
+        p = aug.draw(x.to(DEV)).cpu().numpy()
+        c, w = int(p[0]), int(p[1])
+        flen, fpos, tlen, tpos = (p[2 + i * 2 * B: 2 + (i + 1) * 2 * B].reshape(B, 2) for i in range(4))
+        assert 5 <= c < Tn - 5 and c - 5 + 1 <= w <= c + 5
+        assert flen.min() >= 0 and flen.max() < 30 and tlen.min() >= 0 and tlen.max() < 20
+        assert fpos.min() >= 0 and fpos.max() < max(1, Fq - flen.max()) and tpos.min() >= 0 and tpos.max() < max(1, Tn - tlen.max())
+        cs.append(c); ws.append(w - c); fl.append(flen); tl.append(tlen); fp_.append(fpos); tp.append(tpos)
+    assert len(set(cs)) > 20                                             # fresh numbers per step
+    assert abs(np.mean(fl) - 14.5) < 0.6 and abs(np.mean(tl) - 9.5) < 0.4     # U{0..29}, U{0..19}: sd/sqrt(5120) = 0.12 / 0.08
+    assert abs(np.mean(tp) - (Tn - 19 - 1) / 2) < 6 and abs(np.mean(ws) - 0.5) < 1.5
+    # (2) same draws through the oracle
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 4e-2)):
+        xd = x.to(DEV).to(dtype)
+        p = aug.draw(xd)
+        y = aug(xd, params=p)
+        pc = p.cpu().numpy()
+        ref = R.spec_augment(xd.float().cpu(), int(pc[0]), int(pc[1]), *(pc[2 + i * 2 * B: 2 + (i + 1) * 2 * B].reshape(B, 2) for i in range(4)),
+                             window=5, replace_with_zero=False)
+        assert y.dtype == dtype and y.shape == x.shape
+        close(y, ref, tol, tol)
+    # (3) time - window <= window: no warp, c = w = 0
+    xs = torch.randn(2, 10, 80, generator=g).to(DEV)
+    only_warp = nn_.SpecAugment(time_warp=True, time_warp_window=5, freq_mask=False, time_mask=False)
+    assert only_warp.draw(xs)[:2].tolist() == [0, 0] and torch.equal(only_warp(xs), xs)
+    # (4) graph capture: the stream id is frozen, the device step counter moves
+    xd = x.to(DEV)
+    ops.begin_step(torch.device(DEV))
+    aug(xd)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.begin_step(torch.device(DEV))
+        p_static = aug.draw(xd)
+        y_static = ops.spec_augment_apply(xd, p_static, 2, 2, False)
+    seen = set()
+    for _ in range(5):
+        graph.replay()
+        torch.cuda.synchronize()
+        pc = p_static.cpu().numpy()
+        seen.add(tuple(pc[:6].tolist()))
+        ref = R.spec_augment(x, int(pc[0]), int(pc[1]), *(pc[2 + i * 2 * B: 2 + (i + 1) * 2 * B].reshape(B, 2) for i in range(4)),
+                             window=5, replace_with_zero=False)
+        close(y_static, ref, 1e-5, 1e-5)
+    assert len(seen) == 5
+
+
+@pytest.mark.parametrize("speed", [95, 105, 50])
+def test_resample_kernel_vs_reference_golden(golden, nn_, speed):
+    """nnet.Resample (one HIP launch) against the reference's Resample output, incl. the partial windows at both signal ends;
+    plus the reference's own unit test (half speed of a sine ~ every second sample, tests/unittests/test_augment.py:110-113)."""
+    g = golden["c1_augment"]
+    rs = nn_.Resample(16000, 16000 * speed // 100)
+    y = rs(T(g["sp_x"]).to(DEV))
+    assert y.shape == g[f"sp_{speed}_y"].shape
+    close(y, g[f"sp_{speed}_y"], 1e-6, 1e-5)
+    y3 = rs(T(g["sp_x"]).t().contiguous()[None].to(DEV))              # [1, L, 3 channels]
+    close(y3[0].t(), g[f"sp_{speed}_y"], 1e-6, 1e-5)
+    if speed == 50:
+        sine = torch.sin(torch.arange(16000.0)).unsqueeze(0).to(DEV)
+        half = nn_.SpeedPerturb(16000, speeds=[50]).to(DEV)(sine)
+        close(half, g["sp_sine_half"], 2e-6, 1e-5)
+        assert half.allclose(sine[:, ::2], atol=3e-1)
+    L = 159840 + 77                                                    # BASELINE utterance length, ragged against the 20-sample unit
+    from oracle import tsasr_ref as R
+    wav = torch.randn(2, L, generator=torch.Generator().manual_seed(1)) * 0.1
+    close(rs(wav.to(DEV)), R.resample(wav, 16000, rs.new_freq), 1e-6, 1e-5)

@@ -70,7 +70,11 @@ def test_reference_yaml_files_load_unchanged(name):
     h = _load(f"/root/reference/hparams/LibriSpeechMix/{name}.yaml", {"data_folder": "/nonexistent"})
     n = sum(p.numel() for m in h["modules"].values() if isinstance(m, torch.nn.Module) for p in m.parameters() if p.requires_grad)
     assert n == {"conformer-t_scratch": 51022749}.get(name, n)     # trainable total of the scratch recipe
-    assert type(h["augmentation"]).__name__ == "Unavailable"
+    assert type(h["augmentation"]).__name__ == "SpecAugment" and type(h["speed_perturb"]).__name__ == "SpeedPerturb"
+    aug = h["augmentation"]               # conformer-t_scratch.yaml:132-142
+    assert (aug.time_warp_window, aug.freq_mask_width, aug.time_mask_width, aug.replace_with_zero) == (5, (0, 30), (0, 20), False)
+    assert [r.new_freq for r in h["speed_perturb"].resamplers] == [15200, 16000, 16800]
+    assert type(h["train_logger"]).__name__ == "Unavailable"      # off the hot path: placeholder that raises only when used
     with pytest.raises(ValueError):
         _load(f"/root/reference/hparams/LibriSpeechMix/{name}.yaml")  # !PLACEHOLDER data_folder must be overridden
 
@@ -191,3 +195,30 @@ def test_brain_counts_nonfinite_losses_on_cpu():
     brain.fit_batch(torch.ones(1, 2))
     with pytest.raises(ValueError):
         brain.flush_nonfinite()
+
+
+def test_resampler_host_side_matches_reference(golden):
+    """Host logic of speed perturbation: the filter bank nnet.Resample builds equals the reference's (golden, bit for bit), the
+    C-ABI's output-length rule equals the oracle's for ragged lengths, and SpeedPerturb follows torch's CPU generator exactly like
+    the reference (tests/golden/c1_augment.npz: 64 draws after torch.manual_seed(11))."""
+    from oracle import tsasr_ref as R
+    nn_ = importlib.import_module("ts-asr_amd.nnet")
+    capi = importlib.import_module("ts-asr_amd._capi")
+    g = golden["c1_augment"]
+    for speed in (95, 105, 50):
+        rs = nn_.Resample(16000, 16000 * speed // 100)
+        w, first = rs._filters(torch.device("cpu"))
+        assert np.array_equal(w.numpy(), g[f"sp_{speed}_weights"]) and np.array_equal(first.numpy(), g[f"sp_{speed}_first"].astype(np.int32))
+        for n in (0, 1, 19, 20, 21, 3999, 4000, 159840, 159999):
+            assert capi.lib().tsasr_resample_out_len(n, 16000, rs.new_freq) == R.resample_out_len(n, 16000, rs.new_freq)
+    sp = nn_.SpeedPerturb(16000, speeds=[95, 100, 105])
+    picks = []
+    torch.manual_seed(11)
+    for _ in range(64):
+        assert float(torch.rand(1)) <= 1.0                       # the reference's perturb_prob draw comes first
+        picks.append(int(torch.randint(len(sp.speeds), (1,))[0]))
+    assert picks == g["sp_index_draws"].tolist()
+    no = nn_.SpeedPerturb(16000, perturb_prob=0.0)               # edge cases of the reference's unit test (test_augment.py:105-108)
+    x = torch.sin(torch.arange(1600.0)).unsqueeze(0)
+    assert torch.equal(no(x), x) and no(x) is not x
+    assert nn_.SpeedPerturb(16000, speeds=[100])(x) is x

@@ -221,3 +221,27 @@ def test_beam_search_fp32_vs_reference_golden(brain32, golden, beam):
         assert hyps[b] == ref or abs(scores[b][0] - g[f"beam{beam}_scores"][b]) < 5e-4, b
         assert abs(scores[b][0] - g[f"beam{beam}_scores"][b]) < 1e-3
     assert exact >= 2
+
+
+def test_training_step_with_augmentation_on():
+    """``augment: True`` (what tasks/*.sh train with): speed perturbation on the mixture waveform and SpecAugment on the normalised
+    features run inside compute_forward in TRAIN stage only (train_librispeechmix_scratch.py:82-94)."""
+    inp = golden_inputs()
+    brain, h = entry._config1_brain(DEV, "bf16")
+    assert "augmentation" in brain.modules and "speed_perturb" in brain.modules
+    brain.hparams.augment = True
+    brain.modules.train()
+    batch = make_batch(inp).to(DEV)
+    torch.manual_seed(3)
+    seen, losses = set(), []
+    for _ in range(6):
+        losses.append(float(brain.fit_batch(batch)))
+        seen.add(int(brain.modules.speed_perturb.samp_index))
+    assert all(np.isfinite(losses)) and len(seen) >= 2          # several of the three speeds were drawn
+    assert len({round(v, 4) for v in losses}) == 6              # every step saw different masks / warps
+    brain.modules.eval()
+    Stage = importlib.import_module("ts-asr_amd.core").Stage
+    with torch.no_grad():
+        a, _ = brain.compute_forward(batch, Stage.VALID)
+        b, _ = brain.compute_forward(batch, Stage.VALID)
+    assert torch.equal(a, b)                                    # evaluation is never augmented

@@ -276,3 +276,48 @@ def test_beam_search_vs_reference(golden, beam):
     for b in range(4):
         assert hyps[b] == g[f"beam{beam}_hyps"][b, : g[f"beam{beam}_lens"][b]].tolist(), b
         assert abs(scores[b] - g[f"beam{beam}_scores"][b]) < 1e-4
+
+
+SA_CASES = {"recipe": dict(replace_with_zero=False), "zero": dict(replace_with_zero=True), "nowarp": dict(replace_with_zero=False)}
+
+
+def sa_draws(g, name, rep, B=4):
+    k = f"sa_{name}_{rep}"
+    warp = k + "_c" in g.files
+    return dict(c=int(g[k + "_c"][0]) if warp else None, w=int(g[k + "_w"][0]) if warp else None,
+                flen=g[k + "_flen"].reshape(B, -1), fpos=g[k + "_fpos"].reshape(B, -1),
+                tlen=g[k + "_tlen"].reshape(B, -1), tpos=g[k + "_tpos"].reshape(B, -1)), g[k + "_y"]
+
+
+@pytest.mark.parametrize("name", list(SA_CASES))
+@pytest.mark.parametrize("rep", [0, 1, 2])
+def test_spec_augment_vs_reference(golden, name, rep):
+    """oracle.spec_augment with the reference's own draws (recorded by oracle/gen_golden_aug.py) against the reference's output:
+    recipe settings (fill with the mean), replace_with_zero, and masks only. 1e-5: cubic taps are summed in a different order."""
+    g = golden["c1_augment"]
+    draws, y = sa_draws(g, name, rep)
+    close(R.spec_augment(T(g["sa_x"]), **draws, **SA_CASES[name]), y, atol=1e-5)
+
+
+def test_spec_augment_skips_warp_on_short_inputs(golden):
+    g = golden["c1_augment"]          # time - window <= window (SB/lobes/augment.py:131-132)
+    close(R.spec_augment(T(g["sa_short_x"]), c=5, w=6), g["sa_short_y"], atol=0)
+
+
+@pytest.mark.parametrize("speed", [95, 100, 105, 50])
+def test_resample_vs_reference(golden, speed):
+    """The polyphase restatement against the reference's Resample (filter bank bit-equal, output to 1e-6), at the recipe's three
+    speeds and the reference unit test's half speed (vendor/speechbrain/tests/unittests/test_augment.py:100-113)."""
+    g = golden["c1_augment"]
+    new = 16000 * speed // 100
+    y = R.resample(T(g["sp_x"]), 16000, new)
+    assert y.shape[1] == R.resample_out_len(4000, 16000, new) == g[f"sp_{speed}_y"].shape[1]
+    close(y, g[f"sp_{speed}_y"], atol=1e-6)
+    if speed != 100:
+        first, w = R.resample_filters(16000, new)
+        assert np.array_equal(first.numpy(), g[f"sp_{speed}_first"]) and np.array_equal(w.numpy(), g[f"sp_{speed}_weights"])
+    if speed == 50:
+        sine = torch.sin(torch.arange(16000.0)).unsqueeze(0)
+        half = R.resample(sine, 16000, 8000)
+        close(half, g["sp_sine_half"], atol=2e-6)
+        assert half.allclose(sine[:, ::2], atol=3e-1)          # the reference's own assertion

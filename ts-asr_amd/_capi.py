@@ -86,6 +86,12 @@ _PROTOS = {
     "tsasr_reduce_pending": (c_int, []),
     "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
     "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_specaug_params_words": (c_size_t, [c_int] * 3),
+    "tsasr_specaug_draw": (c_int, [c_void_p] + [c_int] * 10 + [c_ull, c_void_p, c_void_p]),
+    "tsasr_specaug_workspace_bytes": (c_size_t, []),
+    "tsasr_specaug_apply": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_resample_out_len": (c_ll, [c_ll, c_int, c_int]),
+    "tsasr_resample_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
 }
 
 

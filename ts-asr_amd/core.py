@@ -135,7 +135,7 @@ class Brain:
         self.device = str(self.device)
         if "cuda" in self.device:
             torch.cuda.set_device(int(self.device.split(":")[1]) if ":" in self.device else 0)
-        # components without a mirror on the hot path (augmenters, ...) arrive as hparams.Unavailable: not modules
+        # components without a mirror on the hot path (loggers, ...) arrive as hparams.Unavailable: not modules
         mods = {k: m for k, m in (modules or {}).items() if isinstance(m, torch.nn.Module)}
         self.skipped_modules = sorted(set(modules or {}) - set(mods))
         self.modules = torch.nn.ModuleDict(mods).to(self.device)

@@ -5,7 +5,7 @@ tags: ``!new:``, ``!name:``, ``!apply:``, ``!ref`` (with ``<key>`` interpolation
 ``<vocab_size> - 1``) and ``!PLACEHOLDER``, plus tuple-like strings ``(128, 128)``. This reader supports
 exactly those. Class paths that point into the reference's Python packages are re-pointed to their MI355X
 mirrors through ``ALIASES`` - so ``!new:speechbrain.lobes.features.Fbank`` builds ``ts-asr_amd.nnet.Fbank``.
-Paths with no mirror on the hot path (augmentation, checkpointing, WER statistics, ...) become ``Unavailable``
+Paths with no mirror on the hot path (checkpointing, WER statistics, ...) become ``Unavailable``
 placeholders that raise only when used (out of scope).
 """
 import ast
@@ -21,6 +21,9 @@ ALIASES = {
     "speechbrain.lobes.features.Fbank": _PKG + ".nnet.Fbank",
     "speechbrain.processing.features.InputNormalization": _PKG + ".nnet.InputNormalization",
     "speechbrain.lobes.models.convolution.ConvolutionFrontEnd": _PKG + ".nnet.ConvolutionFrontEnd",
+    "speechbrain.lobes.augment.SpecAugment": _PKG + ".nnet.SpecAugment",
+    "speechbrain.processing.speech_augmentation.SpeedPerturb": _PKG + ".nnet.SpeedPerturb",
+    "speechbrain.processing.speech_augmentation.Resample": _PKG + ".nnet.Resample",
     "models.conformer.ConformerEncoder": _PKG + ".conformer.ConformerEncoder",
     "speechbrain.nnet.linear.Linear": _PKG + ".nnet.Linear",
     "speechbrain.nnet.embedding.Embedding": _PKG + ".nnet.Embedding",

@@ -189,6 +189,108 @@ class InputNormalization(nn.Module):
         return ops.sentence_norm(x, abs_lengths_round(lengths, x.shape[1]), self.eps)
 
 
+
+# ------------------------------------------------------------------------------------------------------
+# A17 / A18 the two augmenters of compute_forward (TRAIN stage, ``augment: True``; train_librispeechmix_scratch.py:82-94)
+# ------------------------------------------------------------------------------------------------------
+class SpecAugment(nn.Module):
+    """speechbrain.lobes.augment.SpecAugment (SB/lobes/augment.py:32-201), same constructor. Differences: the draws come from a
+    device-side counter generator (one tiny kernel) instead of torch's CPU/GPU generators - distribution-identical, no host
+    synchronisation, capturable into the step's hipGraph - and the result is a new tensor (the reference warps in place)."""
+
+    def __init__(self, time_warp=True, time_warp_window=5, time_warp_mode="bicubic", freq_mask=True, freq_mask_width=(0, 20),
+                 n_freq_mask=2, time_mask=True, time_mask_width=(0, 100), n_time_mask=2, replace_with_zero=True):
+        super().__init__()
+        assert time_warp or freq_mask or time_mask, "at least one of time_warp, time_mask, or freq_mask should be applied"
+        if time_warp and time_warp_mode != "bicubic":
+            raise NotImplementedError("ts-asr_amd.SpecAugment implements time_warp_mode='bicubic' (the default and all TS-ASR YAMLs)")
+        as_range = lambda w: (0, w) if isinstance(w, int) else tuple(w)  # noqa: E731
+        self.apply_time_warp, self.time_warp_window, self.time_warp_mode = time_warp, time_warp_window, time_warp_mode
+        self.freq_mask, self.freq_mask_width, self.n_freq_mask = freq_mask, as_range(freq_mask_width), n_freq_mask
+        self.time_mask, self.time_mask_width, self.n_time_mask = time_mask, as_range(time_mask_width), n_time_mask
+        self.replace_with_zero = replace_with_zero
+
+    def _counts(self):
+        return (self.n_freq_mask if self.freq_mask else 0), (self.n_time_mask if self.time_mask else 0)
+
+    def draw(self, x):
+        """Device int32 table of this call's random numbers (layout: include/tsasr_hip.h, tsasr_specaug_draw)."""
+        B, T, Fq = x.shape[0], x.shape[-2], x.shape[-1]
+        nf, nt = self._counts()
+        return ops.spec_augment_draw(B, T, Fq, self.time_warp_window if self.apply_time_warp else 0, nf, self.freq_mask_width, nt,
+                                     self.time_mask_width, x.device)
+
+    def forward(self, x, params=None):
+        C.require_gpu(x)
+        shape = x.shape
+        if x.dim() == 4:                      # [B,C,T,F]: masks are drawn per (batch x channel) row, as the reference's view does
+            x = x.reshape(-1, shape[2], shape[3])
+        nf, nt = self._counts()
+        y = ops.spec_augment_apply(x, self.draw(x) if params is None else params, nf, nt, self.replace_with_zero)
+        return y.view(shape)
+
+
+class Resample(nn.Module):
+    """speechbrain.processing.speech_augmentation.Resample (SB/processing/speech_augmentation.py:504-820): windowed-sinc
+    polyphase resampling. The filter bank is built once on the host with the reference's formulas; the resampling itself is one
+    HIP launch instead of one conv1d + conv_transpose1d + two pads per phase."""
+
+    def __init__(self, orig_freq=16000, new_freq=16000, lowpass_filter_width=6):
+        super().__init__()
+        self.orig_freq, self.new_freq, self.lowpass_filter_width = int(orig_freq), int(new_freq), lowpass_filter_width
+        base = math.gcd(self.orig_freq, self.new_freq)
+        self.conv_stride, self.output_samples = self.orig_freq // base, self.new_freq // base
+        self.conv_transpose_stride = self.output_samples
+        self._bank = {}
+
+    def _filters(self, device):
+        """(weights [P,W] fp32, first [P] int32) on ``device``: Hann-windowed sinc, cutoff 0.99 x the lower Nyquist (:758-820)."""
+        if device not in self._bank:
+            cutoff = 0.99 * 0.5 * min(self.orig_freq, self.new_freq)
+            half = self.lowpass_filter_width / (2.0 * cutoff)
+            out_t = torch.arange(0.0, self.output_samples) / self.new_freq
+            lo = torch.ceil((out_t - half) * self.orig_freq)
+            hi = torch.floor((out_t + half) * self.orig_freq)
+            taps = torch.arange(int((hi - lo + 1).max()))
+            dt = (lo[:, None] + taps[None, :]) / self.orig_freq - out_t[:, None]
+            w = torch.where(dt.abs() < half, 0.5 * (1 + torch.cos(2 * math.pi * cutoff / self.lowpass_filter_width * dt)), torch.zeros_like(dt))
+            safe = torch.where(dt == 0, torch.ones_like(dt), dt)
+            w = w * torch.where(dt == 0, torch.full_like(dt, 2 * cutoff), torch.sin(2 * math.pi * cutoff * safe) / (math.pi * safe))
+            self.first_indices, self.weights = lo, w / self.orig_freq
+            self._bank[device] = (self.weights.to(device).contiguous(), lo.to(torch.int32).to(device))
+        return self._bank[device]
+
+    def forward(self, waveforms):
+        if self.orig_freq == self.new_freq:
+            return waveforms
+        C.require_gpu(waveforms)
+        if waveforms.dim() == 2:
+            w, f = self._filters(waveforms.device)
+            return ops.resample(waveforms, w, f, self.orig_freq, self.new_freq)
+        if waveforms.dim() == 3:              # [B,L,C]: channels are resampled independently
+            B, L, Cn = waveforms.shape
+            w, f = self._filters(waveforms.device)
+            y = ops.resample(waveforms.transpose(1, 2).reshape(B * Cn, L), w, f, self.orig_freq, self.new_freq)
+            return y.view(B, Cn, -1).transpose(1, 2)
+        raise ValueError("Input must be 2 or 3 dimensions")
+
+
+class SpeedPerturb(nn.Module):
+    """speechbrain.processing.speech_augmentation.SpeedPerturb (:435-501): one of ``speeds`` (percent) is picked per batch with
+    the same CPU draws as the reference (torch.rand(1), torch.randint(len(speeds), (1,))) and applied by ``Resample``."""
+
+    def __init__(self, orig_freq, speeds=[90, 100, 110], perturb_prob=1.0):  # noqa: B006  (reference signature)
+        super().__init__()
+        self.orig_freq, self.speeds, self.perturb_prob = orig_freq, list(speeds), perturb_prob
+        self.samp_index = 0
+        self.resamplers = [Resample(orig_freq=orig_freq, new_freq=orig_freq * speed // 100) for speed in self.speeds]
+
+    def forward(self, waveform):
+        if torch.rand(1) > self.perturb_prob:
+            return waveform.clone()
+        self.samp_index = int(torch.randint(len(self.speeds), (1,))[0])
+        return self.resamplers[self.samp_index](waveform)
+
 # ------------------------------------------------------------------------------------------------------
 # A3 convolutional front-end
 # ------------------------------------------------------------------------------------------------------

@@ -630,6 +630,54 @@ def sentence_norm(x, abs_lens, eps, out_dtype=None):
     return y
 
 
+def spec_augment_draw(B, T, Fq, window, n_freq, f_range, n_time, t_range, device):
+    """All random numbers of one SpecAugment call, drawn by a HIP kernel into a device int32 table (no host round trip; the
+    stream id comes from ``next_seed`` + the device step counter, so a captured call draws afresh on every replay)."""
+    lib = C.lib()
+    params = torch.empty(lib.tsasr_specaug_params_words(B, n_freq, n_time), dtype=torch.int32, device=device)
+    C.require_gpu(params)
+    C.check(lib.tsasr_specaug_draw(C.ptr(params), B, T, Fq, int(window), n_freq, int(f_range[0]), int(f_range[1]), n_time,
+                                   int(t_range[0]), int(t_range[1]), next_seed(), C.ptr(seed_state(params.device)), C.stream_ptr()),
+            "tsasr_specaug_draw")
+    return params
+
+
+def spec_augment_apply(x, params, n_freq, n_time, replace_with_zero):
+    """y = time masks(frequency masks(time warp(x))) for x [B,T,F] with the draws of ``params`` (layout: include/tsasr_hip.h)."""
+    C.require_gpu(x, params)
+    xc = x.detach().contiguous()
+    B, T, Fq = xc.shape
+    lib = C.lib()
+    if params.numel() != lib.tsasr_specaug_params_words(B, n_freq, n_time) or params.dtype != torch.int32:
+        raise ValueError("spec_augment_apply: params must be the int32 table of spec_augment_draw for this batch and mask counts")
+    y = torch.empty_like(xc)
+    ws = _ws(lib.tsasr_specaug_workspace_bytes(), xc.device)
+    with prof.region("spec_augment"):
+        C.check(lib.tsasr_specaug_apply(C.ptr(xc), C.ptr(y), C.ptr(params), B, T, Fq, n_freq, n_time, int(bool(replace_with_zero)),
+                                        C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_specaug_apply")
+    return y
+
+
+def resample_out_len(n_in, orig_freq, new_freq):
+    return int(C.lib().tsasr_resample_out_len(int(n_in), int(orig_freq), int(new_freq)))
+
+
+def resample(wav, weights, first, orig_freq, new_freq):
+    """Polyphase resampling of wav [B,L] fp32 with the filter bank ``weights`` [P,W] / ``first`` [P] (device tensors)."""
+    import math
+    C.require_gpu(wav, weights, first)
+    x = wav.detach().float().contiguous()
+    B, L = x.shape
+    base = math.gcd(orig_freq, new_freq)
+    P, stride = new_freq // base, orig_freq // base
+    n_out = resample_out_len(L, orig_freq, new_freq)
+    y = torch.empty(B, n_out, dtype=torch.float32, device=x.device)
+    with prof.region("resample"):
+        C.check(C.lib().tsasr_resample_fwd(C.ptr(x), C.ptr(y), C.ptr(weights), C.ptr(first), B, L, n_out, P, stride, weights.shape[1],
+                                           C.stream_ptr()), "tsasr_resample_fwd")
+    return y
+
+
 def _out_len(n):
     return (n - 1) // 2 + 1
 

@@ -49,11 +49,16 @@ class TSASR(core.Brain):
         tokens_bos, tokens_bos_lens = batch.tokens_bos
         speaker_embs, enroll_lens = self._speaker_embedding(batch, epoch)
 
+        augment = bool(getattr(hp, "augment", False)) and stage == Stage.TRAIN
         if getattr(hp, "input_is_feats", False):
             feats = mixed
         else:
+            if augment and "speed_perturb" in self.modules:      # train_librispeechmix_scratch.py:82-85
+                mixed = self.modules.speed_perturb(mixed)
             feats = self.modules.feature_extractor(mixed)
             feats = self.modules.normalizer(feats, mixed_lens, epoch=epoch)
+        if augment and "augmentation" in self.modules:           # train_librispeechmix_scratch.py:91-94
+            feats = self.modules.augmentation(feats)
         feats = self.modules.frontend(feats)
         enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
         enc_out = self.modules.encoder_proj(enc_out)
