@@ -92,6 +92,7 @@ class ConformerEncoder(nn.Module):
         valid = abs_lengths_round(wav_len, T) if wav_len is not None else None
         x = self.custom_src_module(_cd(src))
         if -1 in self.injection_after and speaker_embs is not None:
+            speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
             x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
         pos = self.positional_encoding(x)
         attns = []
@@ -100,6 +101,9 @@ class ConformerEncoder(nn.Module):
             if return_attn:
                 attns.append(attn.detach())
             if i in self.injection_after and speaker_embs is not None:
+                # a callable = "not needed before this point": the recipe computes the speaker branch on a second HIP stream and
+                # joins it here, so it overlaps the mixture's front-end and the layers before the injection
+                speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
                 x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
         x = self.norm(x)
         return (x, attns) if return_attn else x

@@ -152,6 +152,7 @@ class Brain:
         self.arena = None
         self._graph_mode, self._graph, self._graph_warmup, self._eager_steps = False, None, 3, 0
         self._static_batch, self._static_loss, self._graphs, self._graph_pool, self._eager_stepped = None, {}, {}, None, False
+        self._aux_streams = []
         self.rank = int(os.environ.get("RANK", 0))
         self.distributed = bool(self.distributed_launch) and _dp.is_initialized()
 
@@ -236,6 +237,11 @@ class Brain:
         loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
         self.check_gradients(loss)
         (loss / self.grad_accumulation_factor).backward()
+        # Streams the recipe forked in forward also ran their share of backward. autograd joins only the streams its LEAF
+        # (AccumulateGrad) nodes ran on - and most parameter gradients here bypass those nodes (GEMMs accumulate straight into
+        # the arena, small gradients are queued for one batched add) - so join explicitly before anything reads the gradients.
+        for s in self._aux_streams:
+            torch.cuda.current_stream().wait_stream(s)
         self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
         if should_step and (comm or not self.distributed):
             if comm:

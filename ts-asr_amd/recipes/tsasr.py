@@ -41,13 +41,47 @@ class TSASR(core.Brain):
             embs = (embs * mask).sum(dim=-2, keepdim=True) / mask.sum(dim=-2, keepdim=True)
         return self.modules.speaker_proj(embs), enroll_lens
 
+    def _predictor(self, tokens_bos, tokens_bos_lens):
+        embs = self.modules.embedding(tokens_bos)
+        dec_out, _ = self.modules.decoder(embs, lengths=tokens_bos_lens)
+        return self.modules.decoder_proj(dec_out)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._aux_streams.append(self._side)      # Brain joins it after backward
+        return self._side
+
     def compute_forward(self, batch, stage):
         hp = self.hparams
         epoch = hp.epoch_counter.current if hasattr(hp, "epoch_counter") else 0
         batch = batch.to(self.device)
         mixed, mixed_lens = batch.mixed_sig
         tokens_bos, tokens_bos_lens = batch.tokens_bos
-        speaker_embs, enroll_lens = self._speaker_embedding(batch, epoch)
+        # Two parts of the forward do not depend on the mixture encoder: the speaker branch (6 encoder layers over the enrollment,
+        # half-filled grids; needed at the injection point) and the predictor (embedding -> LSTM -> projection; its persistent
+        # recurrence kernels occupy 32 of 256 CUs for 0.4 + 0.7 ms; needed at the joint). Both run on a second HIP stream; the
+        # encoder joins the first lazily at the injection, the joint waits for the second. Backward follows by itself (autograd
+        # runs a node on the stream of its forward): the predictor's backward overlaps the last encoder layers', the speaker
+        # branch's overlaps layer 0 / the front-end's. Works the same inside a captured hipGraph (fork / join become edges).
+        overlap = (stage == Stage.TRAIN and self.variant == "scratch" and getattr(self, "overlap_branches", True)
+                   and torch.device(self.device).type == "cuda")
+        dec_out = None
+        if overlap:
+            cur, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                spk, enroll_lens = self._speaker_embedding(batch, epoch)
+                spk_ready = torch.cuda.Event()
+                spk_ready.record(side)
+                dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+
+            def speaker_embs():
+                cur.wait_event(spk_ready)
+                spk.record_stream(cur)
+                return spk
+        else:
+            speaker_embs, enroll_lens = self._speaker_embedding(batch, epoch)
 
         augment = bool(getattr(hp, "augment", False)) and stage == Stage.TRAIN
         if getattr(hp, "input_is_feats", False):
@@ -63,9 +97,11 @@ class TSASR(core.Brain):
         enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
         enc_out = self.modules.encoder_proj(enc_out)
 
-        embs = self.modules.embedding(tokens_bos)
-        dec_out, _ = self.modules.decoder(embs, lengths=tokens_bos_lens)
-        dec_out = self.modules.decoder_proj(dec_out)
+        if dec_out is None:
+            dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+        else:
+            cur.wait_stream(side)
+            dec_out.record_stream(cur)
 
         # joiner + transducer_head fused (train_librispeechmix_scratch.py:132-135)
         head = self.modules.transducer_head.w
