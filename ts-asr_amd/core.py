@@ -196,6 +196,7 @@ class Brain:
         # one flat fp32 gradient arena for every module; parameters ordered so that buckets complete in the order
         # backward produces them (dp.GradArena docstring)
         self.arena = _dp.GradArena(self.modules, world_size=_dp.world_size() if self.distributed else 1)
+        self.arena.aux_streams = self._aux_streams     # same list object: streams the recipe forks register themselves there
         self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm)
         from . import ops as _ops
         _ops.set_grad_sink(self.arena)

@@ -66,6 +66,7 @@ class GradArena:
         self._sync_this_step = False
         self._order_seen, self._order_final = [], False
         self._handles = []
+        self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_host, self._defer_dev, self._defer_key = [], None, None, None, None
         self._reorder_pending = False
@@ -200,6 +201,7 @@ class GradArena:
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):
         self.in_backward = True
+        self._main_stream = torch.cuda.current_stream() if self.device.type == "cuda" else None
         self._sync_this_step = bool(will_sync) and self.sync_enabled and self.world_size > 1
         if not self._sync_this_step and self.device.type == "cuda":   # (a bucket may only be sent once its gradients are final)
             from . import ops
@@ -223,6 +225,13 @@ class GradArena:
             return
         b["sent"] = True
         chunk = self.grads[b["lo"]:b["hi"]]
+        if self.device.type == "cuda":
+            # the collective is ordered after the CURRENT stream only; a bucket may hold gradients written on another stream
+            # of this step (the recipe runs two branches of the model on a second stream, backward follows the forward's streams)
+            cur = torch.cuda.current_stream()
+            for st in [self._main_stream] + list(self.aux_streams):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
         if dist.get_backend(self.group) == "nccl":
             self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:  # gloo has no AVG
