@@ -106,6 +106,13 @@ struct StagePieces {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rr = (int)(threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+            if (sizeof(T) == 2 && (Dh % 8) == 0) {   // bf16 source, whole 16-byte pieces: straight to LDS, no fp32 round trip
+                const bool ok = r >= lo && r < hi && c < Dh;
+                uint4 w = raw[it][0];
+                if (!ok) w = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4 *>(lds + rr * AT_LD + c) = w;
+                continue;
+            }
             float v[8];
             if (sizeof(T) == 2) {
 #pragma unroll
