@@ -149,7 +149,7 @@ def main():
         torch.cuda.synchronize()
 
     # fp32 is the parity mode: its GEMMs are the library's exact fp32 path (hipBLASLt), which cannot be stream-captured
-    use_graph = (not args.eager) and not args.ragged and args.dtype == "bf16"
+    use_graph = (not args.eager) and args.dtype == "bf16"
     if use_graph:
         brain.enable_hip_graph(warmup_steps=min(3, max(2, args.warmup - 1)))
     for i in range(max(args.warmup, 4 if use_graph else 0)):   # graph mode: >= 3 eager steps + the capture step are warm-up
