@@ -37,6 +37,23 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // block and is waited for where it stands, so a prologue of 160 guarded element loads or a staging loop of six guarded row
 // pieces costs that many serialized memory round trips (the same finding as in csrc/rnnt.hip's backward kernels).
 
+// four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) {
+    bf16x4 o;
+    o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4 *>(p) = o;
+}
+// sum over the 32 lanes of this lane's half of the wave (hh = lane >> 5): DPP inside the 16-lane rows, two readlanes per half
+__device__ __forceinline__ float half_sum(float v, int hh) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    const float lo = lane_bcast(v, 0) + lane_bcast(v, 16), hi = lane_bcast(v, 32) + lane_bcast(v, 48);
+    return hh ? hi : lo;
+}
+
 // 8 consecutive elements row[d0 .. d0+8), zero at and beyond Dh. fast: Dh % 8 == 0 (16-byte aligned pieces)
 template <typename T>
 __device__ __forceinline__ void load8_clamped(const T *__restrict__ row, int d0, int Dh, bool fast, float (&v)[8]) {
@@ -324,7 +341,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                                                                 const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                 const int32_t *__restrict__ key_lens, const T *__restrict__ out,
                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
-                                                                T *__restrict__ dqkv, T *__restrict__ dbd, float *__restrict__ slab_uv,
+                                                                T *__restrict__ dqkv, T *__restrict__ pd_out, T *__restrict__ ds_out,
+                                                                float *__restrict__ slab_uv, int Tp,
                                                                 int Bn, int Tn, int H, int Dh, float scale, int causal, float pdrop,
                                                                 unsigned long long seed, const unsigned long long *__restrict__ seed_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -384,11 +402,18 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     const bool pipe = (Dh % 8) == 0;
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
+#ifdef AT_PROFILE
+    long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
+#define AT_STAMP(i) do { const long long n_ = clock64(); acc_t[i] += n_ - t_prev; t_prev = n_; } while (0)
+#else
+#define AT_STAMP(i)
+#endif
     if (pipe && j_end > 0) {
         sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
         sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
         sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
     }
+    AT_STAMP(0);   // prologue (q, do, o loads; first tile requests)
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();
         const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
@@ -408,6 +433,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
             stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
         }
         __syncthreads();
+        AT_STAMP(1);   // staging: wait for the tile, LDS stores, next requests, two barriers
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int jb = j0 + 32 * sub;
@@ -434,7 +460,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                 for (int g = 0; g < 16; ++g) g_lds[(32 * rb + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = g_acc[g];
             }
             __builtin_amdgcn_wave_barrier();
-            float ds[16];
+            AT_STAMP(2);   // S, dP, G MFMAs + G tile to LDS
+            float ds[16], pdv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -442,12 +469,23 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                 const int j = jb + jl;
                 const bool masked = (j >= len) || (causal && j > iq);
                 const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
-                float dp = dpd[g];
+                float keep = 1.f;
                 if (pdrop > 0.f) {
                     const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                    dp = drop_keep1(idx, dkey, thr) ? dp * keep_scale : 0.f;
+                    keep = drop_keep1(idx, dkey, thr) ? keep_scale : 0.f;
                 }
-                ds[g] = q_ok ? p * (dp - delta) * scale : 0.f;
+                pdv[g] = q_ok ? p * keep : 0.f;
+                ds[g] = q_ok ? p * (dpd[g] * keep - delta) * scale : 0.f;
+            }
+            // P_d and scale*dS of this lane's query, 4 consecutive keys per store: the key-major pass (dK, dV) and d(pk) read them
+            if (q_ok) {
+                T *prow = pd_out + (((long long)b * H + h) * Tn + iq) * Tp + jb + 4 * hh;
+                T *srow = ds_out + (((long long)b * H + h) * Tn + iq) * Tp + jb + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    st4(prow + 8 * q, pdv[4 * q], pdv[4 * q + 1], pdv[4 * q + 2], pdv[4 * q + 3]);
+                    st4(srow + 8 * q, ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             // inverse skew: dG^T[r_local = jl - i + 31][i] = dSs[i, jl]
@@ -459,6 +497,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                 dsb[g >> 3][g & 7] = (bf16_t)ds[g];
             }
             __builtin_amdgcn_wave_barrier();
+            AT_STAMP(3);   // skewed read, p, dS, inverse skew
             // dQ_ac^T += K^T . dSs^T   (A = K^T through the transposing read; k order of dsb = accumulator row order)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -492,17 +531,9 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
                     dqv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, dgb, dqv[db], 0, 0, 0);
                 }
             }
-            // shifted-back score gradient rows -> dbd[h][r][b][i]  (row = 32 consecutive queries = 64 contiguous bytes)
-            if (dbd && q_ok) {
-#pragma unroll 4
-                for (int qq = 0; qq < 32; ++qq) {
-                    const int rl = 2 * qq + hh, jl = rl + r - 31;
-                    const int rg = r_first + base + rl;
-                    if (rl < 63 && jl >= 0 && jl < 32 && jb + jl < Tn && rg >= 0 && rg < R)
-                        st1(dbd + (((long long)h * R + rg) * Bn + b) * Tn + iq, g_lds[rl * 32 + r]);
-                }
-            }
+            AT_STAMP(4);   // dQ MFMAs (transposing reads, dG fragments)
             __builtin_amdgcn_wave_barrier();
+            AT_STAMP(5);
         }
     }
     // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
@@ -514,234 +545,188 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
         for (int g = 0; g < 16; ++g) {
             const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
             if (q_ok && d < Dh) st1(dq + d, dqu[db][g] + dqv[db][g]);
-            float su = q_ok ? dqu[db][g] : 0.f, sv = q_ok ? dqv[db][g] : 0.f;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
+            const float su = half_sum(q_ok ? dqu[db][g] : 0.f, hh), sv = half_sum(q_ok ? dqv[db][g] : 0.f, hh);
             if (r == 0) { slab[d] = su; slab[64 + d] = sv; }
         }
+#ifdef AT_PROFILE
+    AT_STAMP(6);   // epilogue
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64)
+        for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(slab_uv)[i] = acc_t[i];
+#endif
+}
+
+// Key-major pass on the MATERIALISED probabilities: bwd_q leaves P_d (dropout applied) and scale*dS as [B,H,T,Tp] tensors (16 MB each
+// at B=32, T'=250, bf16 - they stay in the 256 MB Infinity Cache between the two kernels), so dK and dV are two plain
+// contractions over the queries,   dV^T[d][j] = sum_i dO[i][d] * P_d[i][j] ,   dK^T[d][j] = sum_i (q_i + u)[d] * dS[i][j] ,
+// instead of a second recomputation of scores, band products and exponentials (the first version of this pass: 55 us per layer
+// against 80 us for the query-major pass that had already computed every one of these numbers).
+// workgroup = (b, h, 64 keys); wave = (32 keys) x (32 head dims); query chunks of 64 stream through LDS, all four operand
+// fragments come out of it through the transposing read (k = query index is the row index of every tile).
+#define KV2_LD 72
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__restrict__ qkv, const float *__restrict__ bias_u,
+                                                                  const float *__restrict__ bias_v, const int32_t *__restrict__ key_lens,
+                                                                  const T *__restrict__ dout, const T *__restrict__ pd,
+                                                                  const T *__restrict__ ds, T *__restrict__ dqkv,
+                                                                  T *__restrict__ qv_out /*[H][B*T][Dh] or NULL*/, int Tn, int Tp, int H,
+                                                                  int Dh, int causal) {
+    __shared__ __attribute__((aligned(16))) bf16_t xp[64 * KV2_LD], xs[64 * KV2_LD], ydo[64 * KV2_LD], yqu[64 * KV2_LD];
+    const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int jhalf = wave & 1, dhalf = wave >> 1;
+    const int D = H * Dh;
+    const long long row_stride = 3LL * D;
+    const T *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const T *do_base = dout + ((long long)b * Tn) * D + (long long)h * Dh;
+    const T *pd_base = pd + (((long long)b * H + h) * Tn) * Tp + j0;
+    const T *ds_base = ds + (((long long)b * H + h) * Tn) * Tp + j0;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const int jk = j0 + 32 * jhalf + r;                    // this lane's key
+    const bool k_live = jk < len;
+    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int c = (tid & 7) * 8, rr0 = tid >> 3;           // staging: 8 column chunks x 32 rows per pass, 2 passes
+    const bool fast_d = (Dh % 8) == 0;
+    float bu8[8], bv8[8];
+    load8_clamped<float>(bias_u + h * Dh, c, Dh, fast_d, bu8);
+    load8_clamped<float>(bias_v + h * Dh, c, Dh, fast_d, bv8);
+    f32x16 dk = {0}, dv = {0};
+    // queries that can reach these keys: all of them, or (causal) those at or after the first key of the workgroup
+    const int i_begin = causal ? (j0 / 64) * 64 : 0;
+    float xpv[2][8], xsv[2][8], dov[2][8], qv8[2][8];
+    auto request = [&](int i0n) {   // always-issued clamped loads; masked at the LDS store
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int ic = min(i0n + rr0 + 32 * it, Tn - 1);
+            ld8(pd_base + (long long)ic * Tp + c, xpv[it]);
+            ld8(ds_base + (long long)ic * Tp + c, xsv[it]);
+            load8_clamped<T>(do_base + (long long)ic * D, c, Dh, fast_d, dov[it]);
+            load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, qv8[it]);
+        }
+    };
+    if (i_begin < Tn) request(i_begin);
+    for (int i0 = i_begin; i0 < Tn; i0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rr = rr0 + 32 * it, i = i0 + rr;
+            const bool live = i < Tn;
+            float a[8], cv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = live && c + e < Dh;
+                a[e] = ok ? qv8[it][e] + bu8[e] : 0.f;
+                cv[e] = ok ? qv8[it][e] + bv8[e] : 0.f;
+                if (!live) { xpv[it][e] = 0.f; xsv[it][e] = 0.f; dov[it][e] = 0.f; }
+            }
+            st8(xp + rr * KV2_LD + c, xpv[it]);
+            st8(xs + rr * KV2_LD + c, xsv[it]);
+            st8(ydo + rr * KV2_LD + c, dov[it]);
+            st8(yqu + rr * KV2_LD + c, a);
+            // (Q + v) rows in the [H, B*T, Dh] layout of the d(pk) product: written once, by the workgroup of the first key block
+            if (qv_out && blockIdx.x == 0 && live && c < Dh) {
+                T *qo = qv_out + (((long long)h * gridDim.z + b) * Tn + i) * Dh + c;
+                if (fast_d) st8(qo, cv);
+                else
+                    for (int e = 0; e < 8 && c + e < Dh; ++e) st1(qo + e, cv[e]);
+            }
+        }
+        if (i0 + 64 < Tn) request(i0 + 64);     // next chunk in flight during this chunk's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {           // 16 queries per MFMA step
+            if (i0 + 16 * s >= Tn) break;
+            const int ko = (16 * s + 4 * hh + q4) * KV2_LD + 16 * mhalf + 4 * p4;
+            auto frag = [&](const bf16_t *tile, int col0) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + ko + col0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(tile + ko + col0 + 8 * KV2_LD));
+                bf16x8 f;
+                f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                return f;
+            };
+            const bf16x8 a_do = frag(ydo, 32 * dhalf), a_qu = frag(yqu, 32 * dhalf);
+            const bf16x8 b_p = frag(xp, 32 * jhalf), b_s = frag(xs, 32 * jhalf);
+            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_do, b_p, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, b_s, dk, 0, 0, 0);
+        }
+    }
+    if (jk < Tn) {   // accumulators: rows = head dims 32*dhalf + (g&3) + 8(g>>2) + 4hh, column = this lane's key; masked keys get zeros
+        T *dkp = dqkv + ((long long)b * Tn + jk) * row_stride + (long long)h * 3 * Dh + Dh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = 32 * dhalf + 8 * q + 4 * hh;
+            float kk[4], vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kk[e] = k_live ? dk[4 * q + e] : 0.f; vv[e] = k_live ? dv[4 * q + e] : 0.f; }
+            if (d + 4 <= Dh && (Dh % 4) == 0) {
+                st4(dkp + d, kk[0], kk[1], kk[2], kk[3]);
+                st4(dkp + Dh + d, vv[0], vv[1], vv[2], vv[3]);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (d + e < Dh) { st1(dkp + d + e, kk[e]); st1(dkp + Dh + d + e, vv[e]); }
+            }
+        }
+    }
+}
+
+// Shifted-back score gradient for d(pk): dbd[h][r][b][i] = dS[b][h][i][j = r + i - (T-1)] (zero where that key does not exist or
+// is masked) - every entry written, no fill pass. workgroup = (64 band rows) x (64 queries) of one (b, h): the 64 x 128 rectangle of
+// dS it touches goes through LDS (coalesced row reads), the skew happens in the LDS read (row stride 137 elements: lane stride
+// 69 dwords, conflict-free), the writes are 128-byte runs along i.
+#define SH_LD 137
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_shift_back_kernel(const T *__restrict__ ds, const int32_t *__restrict__ key_lens,
+                                                                T *__restrict__ dbd, int Bn, int Tn, int Tp, int H, int causal) {
+    __shared__ T tile[64 * SH_LD];
+    const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64, bh = blockIdx.z, b = bh / H, h = bh % H;
+    const int R = 2 * Tn - 1;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const int jlo = r0 + i0 - (Tn - 1);                       // key of (rl = 0, il = 0); rectangle columns jlo .. jlo + 126
+    const T *src = ds + (((long long)b * H + h) * Tn) * Tp;
+    for (int e = threadIdx.x; e < 64 * 128; e += 256) {        // rows il, 128 consecutive keys (clamped address, masked value)
+        const int il = e >> 7, cj = e & 127, i = i0 + il, j = jlo + cj;
+        const T v = src[(long long)min(i, Tn - 1) * Tp + min(max(j, 0), Tp - 1)];
+        const bool ok = i < Tn && j >= 0 && j < len && !(causal && j > i);
+        tile[il * SH_LD + cj] = ok ? v : (T)0.f;
+    }
+    __syncthreads();
+    const int il = threadIdx.x & 63;
+    if (i0 + il < Tn) {
+        for (int rl = threadIdx.x >> 6; rl < 64; rl += 4) {
+            const int rg = r0 + rl;
+            if (rg < R) dbd[(((long long)h * R + rg) * Bn + b) * Tn + i0 + il] = tile[il * SH_LD + rl + il];
+        }
+    }
+}
+
+extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
+
+static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256); }
+static int attn_tp(int T) { return cdiv(T, 64) * 64; }
+
+__global__ void attn_zero_kernel(uint4 *p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
-                                                                 const float *__restrict__ bias_u, const float *__restrict__ bias_v,
-                                                                 const int32_t *__restrict__ key_lens, const T *__restrict__ out,
-                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
-                                                                 T *__restrict__ dqkv, T *__restrict__ qv_out /*[H][B*T][Dh] or NULL*/,
-                                                                 int Tn, int H, int Dh, float scale, int causal,
-                                                                 float pdrop, unsigned long long seed,
-                                                                 const unsigned long long *__restrict__ seed_dev) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (seed_dev) seed += *seed_dev;
-    bf16_t *qu_lds = reinterpret_cast<bf16_t *>(smem);      // [64][LD]  Q + u
-    bf16_t *qv_lds = qu_lds + AT_KT * AT_LD;                // [64][LD]  Q + v
-    bf16_t *do_lds = qv_lds + AT_KT * AT_LD;                // [64][LD]  dO
-    bf16_t *p_lds = do_lds + AT_KT * AT_LD;                 // [192][LD] band
-    float *st_lds = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);  // [2][64]: lse, delta of the query tile
-    float *g_all = st_lds + 128;                            // [4][32 i][64 r]
-    const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * AT_QB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    float *g_lds = g_all + wave * 32 * 64;
-    const int D = H * Dh, R = 2 * Tn - 1;
-    const long long row_stride = 3LL * D;
-    const T *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
-    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
-    const int jk = j0 + wave * AT_QW + r, jkc = min(jk, Tn - 1);   // this lane's key
-    const bool k_live = jk < len;                                   // masked / out-of-range keys get zero gradients
-
-    bf16x8 kb[4], vb[4];
-    {
-        const bool fast = (Dh % 8) == 0;
-        float k8[4][8], v8[4][8];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            load8_clamped<T>(q_base + (long long)jkc * row_stride + Dh, 16 * s + 8 * hh, Dh, fast, k8[s]);
-            load8_clamped<T>(q_base + (long long)jkc * row_stride + 2 * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { kb[s][j] = (bf16_t)k8[s][j]; vb[s][j] = (bf16_t)v8[s][j]; }
+static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *out,
+                            const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, int B, int Tn, int H, int Dh, float scale,
+                            int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, char *workspace, hipStream_t st) {
+    const int Tp = attn_tp(Tn);
+    float *slab = (float *)workspace;
+    const size_t mat = align_up((size_t)B * H * Tn * Tp * sizeof(float), 256);
+    T *pd = (T *)(workspace + attn_slab_bytes(B, Tn, H)), *ds = (T *)(workspace + attn_slab_bytes(B, Tn, H) + mat);
+    if (causal) {   // key blocks in the future of a whole query wave are skipped by bwd_q: their entries must read as zero
+        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)pd, mat / 16);
+        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, mat / 16);
     }
-    f32x16 dk[2], dv[2];
-    dk[0] = dk[1] = dv[0] = dv[1] = (f32x16){0};
-    const unsigned thr = drop_thr16(pdrop);
-    const float keep_scale = drop_scale16(thr);
-    const DropKey dkey = drop_key(seed);
-    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const bool fast_d = (Dh % 8) == 0;
-    float bu8[8], bv8[8];   // this thread's 8 bias columns in the staging passes (256 % 8 == 0: fixed per thread)
-    load8_clamped<float>(bias_u + h * Dh, (tid % (AT_DP / 8)) * 8, Dh, fast_d, bu8);
-    load8_clamped<float>(bias_v + h * Dh, (tid % (AT_DP / 8)) * 8, Dh, fast_d, bv8);
-
-    const int i_begin = causal ? (j0 / AT_KT) * AT_KT : 0;   // queries before the first key of the workgroup never see it
-    // query tiles are requested one iteration ahead (Dh % 8 == 0): Q, dO, O rows and the band in the storage type, lse in fp32
-    const bool pipe = fast_d;
-    StagePieces<T, AT_KT> sq, sdo, so;
-    StagePieces<T, AT_BAND> sp;
-    constexpr int NIT = AT_KT * (AT_DP / 8) / 256;
-    float lse_n[NIT];
-    auto request_tile = [&](int i0n) {
-        sq.request(q_base, row_stride, i0n, 0, Tn, Dh);
-        sdo.request(dout + ((long long)b * Tn) * D + (long long)h * Dh, D, i0n, 0, Tn, Dh);
-        so.request(out + ((long long)b * Tn) * D + (long long)h * Dh, D, i0n, 0, Tn, Dh);
-        sp.request(pk + (long long)h * Dh, D, j0 - i0n - (AT_KT - 1) + Tn - 1, 0, R, Dh);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) lse_n[it] = lse[((long long)b * H + h) * Tn + min(i0n + (tid + it * 256) / (AT_DP / 8), Tn - 1)];
-    };
-    if (pipe && i_begin < Tn) request_tile(i_begin);
-    for (int i0 = i_begin; i0 < Tn; i0 += AT_KT) {
-        __syncthreads();
-        // stage (Q+u), (Q+v), dO rows of the query tile, lse and delta
-        {
-            const int c = (tid % (AT_DP / 8)) * 8;
-            float q[NIT][8], d8[NIT][8], o8[NIT][8], lse_v[NIT];
-            if (pipe) {
-                // the three row sets go through LDS scratch-free: unpack the requested pieces in registers
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    if (sizeof(T) == 2) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            const unsigned a0 = (&sq.raw[it][0].x)[w], a1 = (&sdo.raw[it][0].x)[w], a2 = (&so.raw[it][0].x)[w];
-                            q[it][2 * w] = __uint_as_float(a0 << 16); q[it][2 * w + 1] = __uint_as_float(a0 & 0xffff0000u);
-                            d8[it][2 * w] = __uint_as_float(a1 << 16); d8[it][2 * w + 1] = __uint_as_float(a1 & 0xffff0000u);
-                            o8[it][2 * w] = __uint_as_float(a2 << 16); o8[it][2 * w + 1] = __uint_as_float(a2 & 0xffff0000u);
-                        }
-                    } else {
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            q[it][w] = __uint_as_float((&sq.raw[it][0].x)[w]);
-                            d8[it][w] = __uint_as_float((&sdo.raw[it][0].x)[w]);
-                            o8[it][w] = __uint_as_float((&so.raw[it][0].x)[w]);
-                        }
-                    }
-                    lse_v[it] = lse_n[it];
-                }
-                sp.commit(p_lds, Dh);
-                if (i0 + AT_KT < Tn) request_tile(i0 + AT_KT);   // next query tile: in flight during this tile's MFMAs
-            } else {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int rr = (tid + it * 256) / (AT_DP / 8), ic = min(i0 + rr, Tn - 1);
-                    load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, q[it]);
-                    load8_clamped<T>(dout + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, d8[it]);
-                    load8_clamped<T>(out + ((long long)b * Tn + ic) * D + (long long)h * Dh, c, Dh, fast_d, o8[it]);
-                    lse_v[it] = lse[((long long)b * H + h) * Tn + ic];
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int rr = (tid + it * 256) / (AT_DP / 8);
-                const bool live = i0 + rr < Tn;
-                float a[8], c8[8], dd[8];
-                float part = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool ok = live && (c + j) < Dh;
-                    a[j] = ok ? q[it][j] + bu8[j] : 0.f;
-                    c8[j] = ok ? q[it][j] + bv8[j] : 0.f;
-                    dd[j] = ok ? d8[it][j] : 0.f;
-                    part += dd[j] * (ok ? o8[it][j] : 0.f);
-                }
-                st8(qu_lds + rr * AT_LD + c, a);
-                st8(qv_lds + rr * AT_LD + c, c8);
-                st8(do_lds + rr * AT_LD + c, dd);
-                // (Q + v) rows in the [H, B*T, Dh] layout of the d(pk) product: written once, by the workgroup of the first key block
-                if (qv_out && blockIdx.x == 0 && live && c < Dh) {
-                    T *qo = qv_out + (((long long)h * gridDim.z + b) * Tn + i0 + rr) * Dh + c;
-                    if (fast_d) st8(qo, c8);
-                    else
-                        for (int j = 0; j < 8 && c + j < Dh; ++j) st1(qo + j, c8[j]);
-                }
-                // delta: 8 consecutive threads hold the 8 column chunks of one row
-#pragma unroll
-                for (int o = 4; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                if ((tid % (AT_DP / 8)) == 0) {
-                    st_lds[64 + rr] = part;
-                    st_lds[rr] = live ? lse_v[it] : 0.f;
-                }
-            }
-        }
-        if (!pipe) {
-            const int r_first = j0 - i0 - (AT_KT - 1) + Tn - 1;  // band row R <-> r = r_first + R ; keys [j0,j0+128) x queries [i0,i0+64)
-            stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, r_first, 0, R, Dh);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int ib = i0 + 32 * sub;
-            if (ib >= Tn) break;
-            if (causal && ib + 31 < j0 + wave * AT_QW) continue;   // every query of the sub-block precedes every key of the wave
-            // S[i (regs), j (lane)] = (Q+u) . K^T ; dPd = dO . V^T
-            f32x16 s_acc = {0}, dpd = {0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qu_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
-                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb[s], s_acc, 0, 0, 0);
-                const bf16x8 da = *reinterpret_cast<const bf16x8 *>(do_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
-                dpd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vb[s], dpd, 0, 0, 0);
-            }
-            // G[i (regs), r (lane)] = (Q+v) . Pband^T over the 64 band rows base + [0,64)
-            const int base = 32 * wave - 32 * sub + 32;
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                f32x16 g_acc = {0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(qv_lds + (32 * sub + r) * AT_LD + 16 * s + 8 * hh);
-                    // B operand: lane (col = band row base + 32rb + r, hh) holds P[row][16s + 8hh + e]
-                    const bf16x8 pb = *reinterpret_cast<const bf16x8 *>(p_lds + (base + 32 * rb + r) * AT_LD + 16 * s + 8 * hh);
-                    g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, pb, g_acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 16; ++g) g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh) * 64 + 32 * rb + r] = g_acc[g];
-            }
-            __builtin_amdgcn_wave_barrier();
-            bf16x8 pdb[2], dsb[2];
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int il = (g & 3) + 8 * (g >> 2) + 4 * hh;
-                const int i = ib + il;
-                const float bd = g_lds[il * 64 + (r - il + 31)];
-                const bool masked = (!k_live) || (i >= Tn) || (causal && jk > i);
-                const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - st_lds[32 * sub + il]);
-                float keep = 1.f;
-                if (pdrop > 0.f) {
-                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + i) * Tn) + jk;
-                    keep = drop_keep1(idx, dkey, thr) ? keep_scale : 0.f;
-                }
-                pdb[g >> 3][g & 7] = (bf16_t)(p * keep);
-                dsb[g >> 3][g & 7] = (bf16_t)(p * (dpd[g] * keep - st_lds[64 + 32 * sub + il]) * scale);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // dV^T += dO^T . Pd ; dK^T += (Q+u)^T . dSs   (A through the transposing read of the query-tile rows)
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int off = (32 * sub + 16 * s + 4 * hh + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(do_lds + off));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(do_lds + off + 8 * AT_LD));
-                    bf16x8 a;
-                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3]; a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pdb[s], dv[db], 0, 0, 0);
-                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(qu_lds + off));
-                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(qu_lds + off + 8 * AT_LD));
-                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3]; a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[s], dk[db], 0, 0, 0);
-                }
-        }
-    }
-    if (jk < Tn) {
-        T *dkp = dqkv + ((long long)b * Tn + jk) * row_stride + (long long)h * 3 * Dh + Dh;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                if (d < Dh) { st1(dkp + d, dk[db][g]); st1(dkp + Dh + d, dv[db][g]); }
-            }
-    }
+    const size_t lds_q = tsasr_relpos_attn_lds_bytes();
+    (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB), H, B), 256, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out,
+                                                                              (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
+                                                                              causal, pdrop, seed, seed_dev);
+    relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
+                                                                          (T *)qv_out, Tn, Tp, H, Dh, causal);
+    relpos_shift_back_kernel<T><<<dim3(cdiv(2 * Tn - 1, 64), cdiv(Tn, 64), B * H), 256, 0, st>>>(ds, key_lens, (T *)dbd, B, Tn, Tp, H, causal);
 }
 
 extern "C" {
@@ -775,14 +760,16 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
 }
 
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
-    return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256);
+    // pos_bias partial sums + the two materialised [B,H,T,Tp] tensors (P_d, scale*dS; sized for fp32 io)
+    return attn_slab_bytes(B, T, H) + 2 * align_up((size_t)B * H * T * attn_tp(T) * sizeof(float), 256);
 }
 
 /* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh]
- * reading of the parameter storage, dbd [H, 2T-1, B, T] in io_dtype = scale * dS shifted back to the (r, i) grid; it
- * must be ZERO-FILLED by the caller (entries without a key are not touched; an in-kernel fill of those entries by per-lane
- * 2-byte stores measured slower than the separate 32 MB fill); qv_out (may be NULL): (Q + pos_bias_v) as [H, B*T, Dh] io_dtype and d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] *
- * (q[b,i,h,:] + v[h,:]) is then one library GEMM per head. */
+ * reading of the parameter storage, dbd [H, 2T-1, B, T] in io_dtype = scale * dS shifted back to the (r, i) grid (fully written,
+ * zeros where a (r, i) pair has no key); qv_out (may be NULL): (Q + pos_bias_v) as [H, B*T, Dh] io_dtype; d(pk)[r, h, :] =
+ * sum_{b,i} dbd[h,r,b,i] * (q[b,i,h,:] + v[h,:]) is then one library GEMM per head. Three launches: the query-major pass
+ * (recomputes the probabilities; dQ, bias partial sums, and P_d / scale*dS materialised in the workspace), the key-major pass
+ * (dK, dV as plain contractions of those two tensors) and the shift-back of dS. */
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
@@ -792,25 +779,18 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
                     "tsasr_relpos_attn_bwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_bwd: head dim %d not supported", Dh);
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), "tsasr_relpos_attn_bwd: workspace too small");
-    const size_t lds_q = tsasr_relpos_attn_lds_bytes();
-    const size_t lds_kv = (size_t)(3 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)(128 + 4 * 32 * 64) * sizeof(float);
+    TSASR_CHECK_ARG((long long)B * H <= 65535, "tsasr_relpos_attn_bwd: B*H too large");
     const int nqt = cdiv(T, AT_QB);
-    dim3 grid(nqt, H, B);
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
-    if (io_dtype == TSASR_F32) {
-        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        relpos_attn_bwd_q_kernel<float><<<grid, 256, lds_q, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-        relpos_attn_bwd_kv_kernel<float><<<grid, 256, lds_kv, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (const float *)out, (const float *)dout, lse, (float *)dqkv, (float *)qv_out, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-    } else if (io_dtype == TSASR_BF16) {
-        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_kv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        relpos_attn_bwd_q_kernel<bf16_t><<<grid, 256, lds_q, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)dbd, slab, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-        relpos_attn_bwd_kv_kernel<bf16_t><<<grid, 256, lds_kv, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, (bf16_t *)qv_out, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
-    } else {
+    if (io_dtype == TSASR_F32)
+        launch_attn_bwd<float>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dbd, qv_out, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
+                               (char *)workspace, st);
+    else if (io_dtype == TSASR_BF16)
+        launch_attn_bwd<bf16_t>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dbd, qv_out, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
+                                (char *)workspace, st);
+    else
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);
-    }
     // slab parts [(b, qtile, wave)] x row [h][u 64 | v 64] -> sum over the parts per (h, which, d): batched with the other
     // parameter-gradient reductions while tsasr_reduce_defer is on (csrc/reduce.hip)
     for (int h = 0; h < H; ++h) {

@@ -815,7 +815,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         v = _f32(pv).reshape(-1).contiguous()
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkvc)
-        dbd = torch.zeros(H, R, B, T, dtype=qkvc.dtype, device=qkvc.device)     # entries without a key stay zero
+        dbd = torch.empty(H, R, B, T, dtype=qkvc.dtype, device=qkvc.device)     # fully written by the shift-back kernel
         qv = torch.empty(H, B * T, Dh, dtype=qkvc.dtype, device=qkvc.device)     # q + pos_bias_v, by-product of the key-major pass
         du, dv = torch.empty_like(u), torch.empty_like(v)
         _keep(du, dv)
