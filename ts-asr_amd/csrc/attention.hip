@@ -669,31 +669,46 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
 }
 
 // Shifted-back score gradient for d(pk): dbd[h][r][b][i] = dS[b][h][i][j = r + i - (T-1)] (zero where that key does not exist or
-// is masked) - every entry written, no fill pass. workgroup = (64 band rows) x (64 queries) of one (b, h): the 64 x 128 rectangle of
-// dS it touches goes through LDS (coalesced row reads), the skew happens in the LDS read (row stride 137 elements: lane stride
-// 69 dwords, conflict-free), the writes are 128-byte runs along i.
-#define SH_LD 137
+// is masked) - every entry written, no fill pass. workgroup = (64 band rows) x (64 queries) of one (b, h): the 64 x 136 rectangle of
+// dS it touches (start aligned down to 8 keys) goes through LDS as 16-byte pieces, the skew happens in the LDS read (row stride
+// 136 elements: lane stride 68.5 dwords, at most two-way conflicts), a thread writes two consecutive queries (128-byte runs along i).
+#define SH_LD 136
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_shift_back_kernel(const T *__restrict__ ds, const int32_t *__restrict__ key_lens,
                                                                 T *__restrict__ dbd, int Bn, int Tn, int Tp, int H, int causal) {
-    __shared__ T tile[64 * SH_LD];
+    __shared__ __attribute__((aligned(16))) T tile[64 * SH_LD];
     const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64, bh = blockIdx.z, b = bh / H, h = bh % H;
     const int R = 2 * Tn - 1;
     const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
-    const int jlo = r0 + i0 - (Tn - 1);                       // key of (rl = 0, il = 0); rectangle columns jlo .. jlo + 126
+    const int jlo = r0 + i0 - (Tn - 1);                       // key of (rl = 0, il = 0); keys jlo .. jlo + 126 are touched
+    const int jal = (jlo >= 0 ? jlo : jlo - 7) / 8 * 8;       // aligned down (also for negative jlo)
     const T *src = ds + (((long long)b * H + h) * Tn) * Tp;
-    for (int e = threadIdx.x; e < 64 * 128; e += 256) {        // rows il, 128 consecutive keys (clamped address, masked value)
-        const int il = e >> 7, cj = e & 127, i = i0 + il, j = jlo + cj;
-        const T v = src[(long long)min(i, Tn - 1) * Tp + min(max(j, 0), Tp - 1)];
-        const bool ok = i < Tn && j >= 0 && j < len && !(causal && j > i);
-        tile[il * SH_LD + cj] = ok ? v : (T)0.f;
+    constexpr int VE = 16 / (int)sizeof(T), NG = SH_LD / VE;   // elements per 16-byte piece, pieces per row
+    for (int e = threadIdx.x; e < 64 * NG; e += 256) {         // always-issued clamped loads; validity is decided at the read below
+        const int il = e / NG, gq = e % NG, j = jal + gq * VE;
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + (long long)min(i0 + il, Tn - 1) * Tp + min(max(j, 0), Tp - VE));
+        *reinterpret_cast<uint4 *>(tile + il * SH_LD + gq * VE) = v;
     }
     __syncthreads();
-    const int il = threadIdx.x & 63;
-    if (i0 + il < Tn) {
-        for (int rl = threadIdx.x >> 6; rl < 64; rl += 4) {
-            const int rg = r0 + rl;
-            if (rg < R) dbd[(((long long)h * R + rg) * Bn + b) * Tn + i0 + il] = tile[il * SH_LD + rl + il];
+    const int ip = (threadIdx.x & 31) * 2;                     // this thread's two queries
+    const int off = jlo - jal;
+    for (int rl = threadIdx.x >> 5; rl < 64; rl += 8) {
+        const int rg = r0 + rl;
+        if (rg >= R) break;
+        T v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int il = ip + q, i = i0 + il, j = jlo + rl + il;
+            const T x = tile[il * SH_LD + off + rl + il];
+            v[q] = (i < Tn && j >= 0 && j < len && !(causal && j > i)) ? x : (T)0.f;
+        }
+        T *dst = dbd + (((long long)h * R + rg) * Bn + b) * Tn + i0 + ip;
+        if (i0 + ip + 1 < Tn && (Tn % 2) == 0) {
+            struct alignas(2 * sizeof(T)) Pair { T a, b; };
+            *reinterpret_cast<Pair *>(dst) = Pair{v[0], v[1]};
+        } else {
+            if (i0 + ip < Tn) dst[0] = v[0];
+            if (i0 + ip + 1 < Tn) dst[1] = v[1];
         }
     }
 }
