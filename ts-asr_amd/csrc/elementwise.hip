@@ -10,6 +10,8 @@
 // (dgamma/dbeta/dbias) are two-stage and deterministic: per-workgroup partial rows, then a small column-sum kernel -
 // no float atomics. Dropout is counter-based (hash of element index and a per-call seed): the mask is never stored,
 // backward regenerates it.
+#include <algorithm>
+
 #include "common.h"
 
 template <typename T> struct Vec;  // 16-byte vector of T
@@ -205,6 +207,188 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
             float s = 0.f;
             for (int q = 0; q < rpb; ++q) s += colbuf[q * 2 * D + i];
             pw[i] = s;
+        }
+    }
+}
+
+// LayerNorm backward for WIDE rows (one workgroup per row at a time: the [F, C] = 5120 / 2560-element rows of the convolutional
+// front-end, 164 MB per tensor). The narrow-row kernel above, used here, ran at 1.8 TB/s: per row it re-read gamma and beta (40 KB
+// of fp32 parameters from L2 beside 20 KB of data), issued every load under a column guard (serialized, csrc/attention.hip note) and
+// exposed a full memory round trip plus four barriers per row. Here the parameters live in registers for the whole row loop, loads
+// are unconditional (clamped column), the next row (and its mean / rstd) is requested before this row's reductions, and the two row
+// sums share one exchange whose buffer alternates between rows (one barrier per row).
+template <typename T, int N> __device__ __forceinline__ void unpack16(const uint4 &w, float (&o)[N]);
+template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const uint4 &w, float (&o)[8]) {
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o[2 * q] = __uint_as_float(u[q] << 16); o[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack16<float, 4>(const uint4 &w, float (&o)[4]) {
+    o[0] = __uint_as_float(w.x); o[1] = __uint_as_float(w.y); o[2] = __uint_as_float(w.z); o[3] = __uint_as_float(w.w);
+}
+
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                 T *__restrict__ dx, float *__restrict__ part, long long M, int D,
+                                                                 float slope, int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float red[2][2][4];
+    const int l = threadIdx.x, w = l >> 6;
+    int cc[ITERS];
+    bool ok[ITERS];
+    float g[ITERS][N], b[ITERS][N], ag[ITERS][N], abt[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 256 + l) * N;
+        ok[it] = c < D;
+        cc[it] = ok[it] ? c : 0;
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            ldv<float, 4>(gamma + cc[it] + j, *reinterpret_cast<float(*)[4]>(&g[it][j]));
+            ldv<float, 4>(beta + cc[it] + j, *reinterpret_cast<float(*)[4]>(&b[it][j]));
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = 0.f;
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+    uint4 xn[ITERS], dn[ITERS];
+    float mu_n = 0.f, rs_n = 0.f;
+    auto request = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            xn[it] = *reinterpret_cast<const uint4 *>(x + row * D + cc[it]);
+            dn[it] = *reinterpret_cast<const uint4 *>(dy + row * D + cc[it]);
+        }
+        mu_n = mean[row];
+        rs_n = rstd[row];
+    };
+    if (r0 < r1) request(r0);
+    for (long long row = r0; row < r1; ++row) {
+        float xh[ITERS][N], gdy[ITERS][N];
+        const float mu = mu_n, rs = rs_n;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            float xv[N], dv[N];
+            unpack16<T, N>(xn[it], xv);
+            unpack16<T, N>(dn[it], dv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float h = (xv[j] - mu) * rs;
+                float d = ok[it] ? dv[j] : 0.f;
+                if (slope >= 0.f && (h * g[it][j] + b[it][j]) <= 0.f) d *= slope;  // LeakyReLU' on the pre-activation
+                xh[it][j] = h;
+                ag[it][j] += d * h;
+                abt[it][j] += d;
+                const float gd = d * g[it][j];
+                gdy[it][j] = gd;
+                s1 += gd;
+                s2 += gd * h;
+            }
+        }
+        if (row + 1 < r1) request(row + 1);       // in flight during the reductions and the stores of this row
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const int par = (int)(row & 1);
+        if ((l & 63) == 0) { red[par][0][w] = s1; red[par][1][w] = s2; }
+        __syncthreads();
+        const float m1 = ((red[par][0][0] + red[par][0][1]) + (red[par][0][2] + red[par][0][3])) / D;
+        const float m2 = ((red[par][1][0] + red[par][1][1]) + (red[par][1][2] + red[par][1][3])) / D;
+        T *dxr = dx + row * D;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (ok[it]) {
+                float o[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] = rs * (gdy[it][j] - m1 - xh[it][j] * m2);
+                stv<T, N>(dxr + cc[it], o);
+            }
+        }
+    }
+    float *pw = part + (size_t)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        if (ok[it]) {
+#pragma unroll
+            for (int j = 0; j < N; j += 4) {
+                *reinterpret_cast<float4 *>(pw + cc[it] + j) = make_float4(ag[it][j], ag[it][j + 1], ag[it][j + 2], ag[it][j + 3]);
+                *reinterpret_cast<float4 *>(pw + D + cc[it] + j) = make_float4(abt[it][j], abt[it][j + 1], abt[it][j + 2], abt[it][j + 3]);
+            }
+        }
+    }
+}
+
+// LayerNorm forward for wide rows: the same treatment (parameters in registers across a row loop, unconditional loads, next row in
+// flight during this row's two reductions; mean, then centred sum of squares - two passes over registers, not over memory).
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, T *__restrict__ y,
+                                                                 float *__restrict__ mean, float *__restrict__ rstd, long long M, int D,
+                                                                 float eps, float slope, int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float red[2][2][4];
+    const int l = threadIdx.x, w = l >> 6;
+    int cc[ITERS];
+    bool ok[ITERS];
+    float g[ITERS][N], b[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 256 + l) * N;
+        ok[it] = c < D;
+        cc[it] = ok[it] ? c : 0;
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            ldv<float, 4>(gamma + cc[it] + j, *reinterpret_cast<float(*)[4]>(&g[it][j]));
+            ldv<float, 4>(beta + cc[it] + j, *reinterpret_cast<float(*)[4]>(&b[it][j]));
+        }
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+    uint4 xn[ITERS];
+    auto request = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) xn[it] = *reinterpret_cast<const uint4 *>(x + row * D + cc[it]);
+    };
+    if (r0 < r1) request(r0);
+    for (long long row = r0; row < r1; ++row) {
+        float v[ITERS][N];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            unpack16<T, N>(xn[it], v[it]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s += ok[it] ? v[it][j] : 0.f;
+        }
+        if (row + 1 < r1) request(row + 1);
+        const int par = (int)(row & 1);
+        s = wave_sum(s);
+        if ((l & 63) == 0) red[par][0][w] = s;
+        __syncthreads();
+        const float mu = ((red[par][0][0] + red[par][0][1]) + (red[par][0][2] + red[par][0][3])) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const float d = ok[it] ? v[it][j] - mu : 0.f; q += d * d; }
+        q = wave_sum(q);
+        if ((l & 63) == 0) red[par][1][w] = q;
+        __syncthreads();
+        const float rs = rsqrtf(((red[par][1][0] + red[par][1][1]) + (red[par][1][2] + red[par][1][3])) / D + eps);
+        if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+        T *yr = y + row * D;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (ok[it]) {
+                float o[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float t = (v[it][j] - mu) * rs * g[it][j] + b[it][j];
+                    if (slope >= 0.f) t = lrelu(t, slope);
+                    o[j] = t;
+                }
+                stv<T, N>(yr + cc[it], o);
+            }
         }
     }
 }
@@ -637,13 +821,19 @@ static int launch_ln_fwd(const void *x, const float *g, const float *b, void *y,
 #define LN_FWD(TPR, IT)                                                                                                  \
     layernorm_fwd_kernel<T, TPR, IT><<<(unsigned)((M + (256 / TPR) - 1) / (256 / TPR)), 256, 0, st>>>(                    \
         (const T *)x, g, b, (T *)y, mean, rstd, M, D, eps, slope)
+    const int rpw = (int)std::max<long long>(4, (M + 1023) / 1024);      // wide rows: ~1024 workgroups walking rpw rows each
+#define LN_FWD_WIDE(IT)                                                                                                   \
+    layernorm_fwd_wide_kernel<T, IT><<<(unsigned)((M + rpw - 1) / rpw), 256, 0, st>>>((const T *)x, g, b, (T *)y, mean, rstd, M, D, eps, slope, rpw)
     if (D <= per_wave) LN_FWD(64, 1);
     else if (D <= 2 * per_wave) LN_FWD(64, 2);
     else if (D <= 4 * per_wave) LN_FWD(64, 4);
-    else if (D <= 2 * per_wg) LN_FWD(256, 2);
-    else if (D <= 4 * per_wg) LN_FWD(256, 4);
-    else if (D <= 8 * per_wg) LN_FWD(256, 8);
+    else if (D <= 2 * per_wg) LN_FWD_WIDE(2);
+    else if (D <= 3 * per_wg) LN_FWD_WIDE(3);
+    else if (D <= 4 * per_wg) LN_FWD_WIDE(4);
+    else if (D <= 6 * per_wg) LN_FWD_WIDE(6);
+    else if (D <= 8 * per_wg) LN_FWD_WIDE(8);
     else return -1;
+#undef LN_FWD_WIDE
 #undef LN_FWD
     return 0;
 }
@@ -656,13 +846,18 @@ static int launch_ln_bwd(const void *dy, const void *x, const float *g, const fl
 #define LN_BWD(TPR, IT)                                                                                                  \
     layernorm_bwd_kernel<T, TPR, IT><<<nwg, 256, (TPR == 64 ? (size_t)4 * 2 * D * sizeof(float) : 0), st>>>(             \
         (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
+#define LN_BWD_WIDE(IT)                                                                                                   \
+    layernorm_bwd_wide_kernel<T, IT><<<nwg, 256, 0, st>>>((const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
     if (D <= per_wave) LN_BWD(64, 1);
     else if (D <= 2 * per_wave) LN_BWD(64, 2);
     else if (D <= 4 * per_wave) LN_BWD(64, 4);
-    else if (D <= 2 * per_wg) LN_BWD(256, 2);
-    else if (D <= 4 * per_wg) LN_BWD(256, 4);
-    else if (D <= 8 * per_wg) LN_BWD(256, 8);
+    else if (D <= 2 * per_wg) LN_BWD_WIDE(2);
+    else if (D <= 3 * per_wg) LN_BWD_WIDE(3);
+    else if (D <= 4 * per_wg) LN_BWD_WIDE(4);
+    else if (D <= 6 * per_wg) LN_BWD_WIDE(6);
+    else if (D <= 8 * per_wg) LN_BWD_WIDE(8);
     else return -1;
+#undef LN_BWD_WIDE
 #undef LN_BWD
     return 0;
 }
@@ -704,7 +899,9 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
     TSASR_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && workspace, "tsasr_layernorm_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_layernorm_bwd: bad shape");
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_layernorm_bwd_workspace_bytes(M, D), "tsasr_layernorm_bwd: workspace too small");
-    const int rpw = pick_rows_per_wg(M, 8);
+    int rpw = pick_rows_per_wg(M, 8);
+    const bool wide = D > 4 * 64 * (io_dtype == TSASR_BF16 ? 8 : 4);
+    if (wide) rpw = (int)std::max<long long>(rpw, (M + 511) / 512);   // wide-row kernel: two workgroups per CU, each prefetching its next row
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
