@@ -11,7 +11,8 @@ batch = batch_mod.synthetic_batch(bench.B_LOCAL, bench.T_MEL, bench.T_ENROLL, be
 for _ in range(3):
     brain.fit_batch(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     brain.fit_batch(batch)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
@@ -21,7 +22,12 @@ for e in prof.events():
     t = getattr(e, "self_device_time_total", 0) or getattr(e, "self_cuda_time_total", 0)
     if t <= 0:
         continue
-    src = next((f for f in (e.stack or []) if "ts-asr_amd" in f or "bench.py" in f), "(autograd engine / other)")
+    src = next((f for f in (e.stack or []) if "ts-asr_amd" in f or "bench.py" in f), None)
+    if src is None:   # backward ops run on the autograd thread: attribute them to the autograd node that issued them
+        par = e.cpu_parent
+        while par is not None and not (par.name.endswith("Backward") or "Backward" in par.name or par.name.startswith("autograd::")):
+            par = par.cpu_parent
+        src = "(bwd) " + par.name if par is not None else "(other)"
     src = src.split("ts-asr_amd/")[-1][:70]
     agg[(e.name, src)][0] += 1
     agg[(e.name, src)][1] += t

@@ -632,6 +632,13 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     const float ks = drop_scale16(thr);
     const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
     float v[ITERS][N];
+    float gv[ITERS][N], bt[ITERS][N];      // requested with the row, used after the two reductions
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = min((it * 64 + l) * N, D - N);
+        ldv<float, N>(gamma + c, gv[it]);
+        ldv<float, N>(beta + c, bt[it]);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -672,11 +679,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * 64 + l) * N;
         if (c < D) {
-            float o[N], gv[N], bt[N];
-            ldv<float, N>(gamma + c, gv);
-            ldv<float, N>(beta + c, bt);
+            float o[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu) * rs * gv[j] + bt[j];
+            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu) * rs * gv[it][j] + bt[it][j];
             stv<T, N>(y + row * D + c, o);
         }
     }
@@ -703,49 +708,63 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     for (int it = 0; it < ITERS; ++it)
 #pragma unroll
         for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = abx[it][j] = 0.f;
-    const long long r0 = (long long)blockIdx.x * rows_per_wg;
-    for (int rr = wave; rr < rows_per_wg; rr += 4) {
-        const long long row = r0 + rr;
-        if (row >= M) break;
-        const float mu = mean[row], rs = rstd[row];
+    // this lane's columns (clamped: every load below is issued unconditionally and masked afterwards), gamma in registers
+    int cc[ITERS];
+    bool ok[ITERS];
+    float gm[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + l) * N;
+        ok[it] = c < D;
+        cc[it] = ok[it] ? c : 0;
+        ldv<float, N>(gamma + cc[it], gm[it]);
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+    // a wave walks rows r0 + wave, +4, ...: the next row (s, dy, dout, mean, rstd) is requested before this row's reductions
+    float sn[ITERS][N], dn[ITERS][N], on[ITERS][N], mu_n = 0.f, rs_n = 0.f;
+    auto request = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            ldv<T, N>(s_in + row * D + cc[it], sn[it]);
+            ldv<T, N>(dy + row * D + cc[it], dn[it]);
+            if (dout) ldv<T, N>(dout + row * D + cc[it], on[it]);
+        }
+        mu_n = mean[row];
+        rs_n = rstd[row];
+    };
+    if (r0 + wave < r1) request(r0 + wave);
+    for (long long row = r0 + wave; row < r1; row += 4) {
+        const float mu = mu_n, rs = rs_n;
         const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
-        float xh[ITERS][N], gd[ITERS][N];
+        float xh[ITERS][N], gd[ITERS][N], dov[ITERS][N];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = (it * 64 + l) * N;
-            if (c < D) {
-                float sv[N], dv[N];
-                ldv<T, N>(s_in + row * D + c, sv);
-                ldv<T, N>(dy + row * D + c, dv);
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const float h = (sv[j] - mu) * rs;
-                    xh[it][j] = h;
-                    ag[it][j] += dv[j] * h;
-                    abt[it][j] += dv[j];
-                    const float g = dv[j] * gamma[c + j];
-                    gd[it][j] = g;
-                    s1 += g;
-                    s2 += g * h;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < N; ++j) xh[it][j] = gd[it][j] = 0.f;
+            for (int j = 0; j < N; ++j) {
+                const float h = ok[it] ? (sn[it][j] - mu) * rs : 0.f, dv = ok[it] ? dn[it][j] : 0.f;
+                xh[it][j] = h;
+                ag[it][j] += dv * h;
+                abt[it][j] += dv;
+                const float g = dv * gm[it][j];
+                gd[it][j] = g;
+                s1 += g;
+                s2 += g * h;
+                dov[it][j] = dout ? on[it][j] : 0.f;
             }
         }
+        if (row + 4 < r1) request(row + 4);
         const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = (it * 64 + l) * N;
-            if (c < D) {
-                float ds[N], dxv[N], dov[N];
-                if (dout) ldv<T, N>(dout + row * D + c, dov);
+            if (ok[it]) {
+                const int c = cc[it];
+                float ds[N], dxv[N];
                 const unsigned long long idx = (unsigned long long)row * D + c;
                 const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float d = rs * (gd[it][j] - m1 - xh[it][j] * m2) + (dout ? dov[j] : 0.f);
+                    const float d = rs * (gd[it][j] - m1 - xh[it][j] * m2) + dov[it][j];
                     ds[j] = d;
                     float g = live ? d * alpha : 0.f;
                     if (p > 0.f) g = ((km >> j) & 1u) ? g * ks : 0.f;
