@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-hardware-queue timeline of ONE captured step from a rocprofv3 kernel trace (.db): which kernels ran where and when, and how
+much the queues overlapped (the step's branches run on separate HIP streams; hipGraph maps them to queues). Usage: stream_timeline.py db [step]"""
+import collections, re, sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
+starts = [i for i, r in enumerate(rows) if "seed_advance" in r[0]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 6
+step = rows[starts[k]:starts[k + 1]]
+t0 = step[0][1]
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:44]
+print("step %d: %.2f ms, %d kernels" % (k, (step[-1][2] - t0) / 1e6, len(step)))
+segs, prevq = [], None
+for n, s, e, q in step:
+    if q != prevq:
+        segs.append([s, e, q, 0, collections.Counter()])
+        prevq = q
+    segs[-1][1] = e; segs[-1][3] += 1; segs[-1][4][short(n)] += 1
+for s, e, q, c, names in segs:
+    if c >= 6 or e - s > 80e3:
+        print("  %6.2f-%6.2f ms q%d %4d kernels  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, q, c, ", ".join("%s x%d" % kv for kv in names.most_common(3))))
+byq = collections.defaultdict(list)
+for n, s, e, q in step:
+    byq[q].append((s, e))
+ev = sorted([(s, 1) for l in byq.values() for s, e in l] + [(e, -1) for l in byq.values() for s, e in l])
+both = act = 0; last = ev[0][0]; busy = collections.Counter()
+for t, d in ev:
+    busy[min(act, 2)] += t - last; last = t; act += d
+print("  time with 0 / 1 / >=2 kernels in flight: %.2f / %.2f / %.2f ms" % (busy[0] / 1e6, busy[1] / 1e6, busy[2] / 1e6))

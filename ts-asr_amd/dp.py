@@ -126,7 +126,7 @@ class GradArena:
             return
         self.flat_params16.copy_(self.flat_params)
         jobs, t_off, tiles = [], 0, 0
-        mats = [p for p in self.params_ordered if p.dim() == 2 and min(p.shape) >= 16 and p.numel() >= 4096]
+        mats = [p for p in self.params_ordered if (p.dim() == 2 or (p.dim() == 3 and p.shape[2] == 1)) and min(p.shape[:2]) >= 16 and p.numel() >= 4096]
         total_t = sum(p.numel() for p in mats)
         if getattr(self, "flat_params16_t", None) is None or self.flat_params16_t.numel() != total_t:
             self.flat_params16_t = torch.empty(max(total_t, 1), dtype=torch.bfloat16, device=self.device)
@@ -136,7 +136,7 @@ class GradArena:
             p._bf16_ver = p._version
             p._bf16_t = None
         for p in mats:
-            r, c = p.shape
+            r, c = p.shape[0], p.shape[1]
             jobs.append((self.offset[id(p)], t_off, r, c, tiles))
             p._bf16_t = self.flat_params16_t[t_off:t_off + r * c].view(c, r)
             t_off += r * c

@@ -381,6 +381,21 @@ class RelPosEncXL(nn.Module):
         return self._cache[key]
 
 
+_POS_CD = {}
+
+
+def _pos_cd(pos_embs):
+    """pos_embs[0] in the compute dtype. The table is a long-lived cached tensor (RelPosEncXL): cast it once, not once per layer
+    and step (18 small cast kernels per step otherwise)."""
+    if pos_embs.dtype == _COMPUTE_DTYPE:
+        return pos_embs[0]
+    key = (pos_embs.data_ptr(), tuple(pos_embs.shape), _COMPUTE_DTYPE)
+    hit = _POS_CD.get(key)
+    if hit is None or hit[0] is not pos_embs:
+        _POS_CD[key] = hit = (pos_embs, pos_embs[0].to(_COMPUTE_DTYPE))
+    return hit[1]
+
+
 class RelPosMHAXL(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.0, vbias=False, vdim=None, mask_pos_future=False):
         super().__init__()
@@ -419,7 +434,7 @@ class RelPosMHAXL(nn.Module):
 
     def _context(self, x, pos_embs, key_lens, causal, need_weights):
         qkv = ops.matmul_nt(x, self.in_proj_weight)                          # [B,T,H*3*Dh] per-head interleaved Q|K|V
-        pk = ops.matmul_nt(_cd(pos_embs[0]), self.linear_pos.weight)         # [2T-1, D]
+        pk = ops.matmul_nt(_pos_cd(pos_embs), self.linear_pos.weight)        # [2T-1, D]
         return ops.relpos_attention(qkv, pk, self.pos_bias_u, self.pos_bias_v, key_lens, self.num_heads, self.scale, causal,
                                     self.dropout if self.training else 0.0, need_weights)
 
@@ -469,7 +484,7 @@ class ConvolutionModule(nn.Module):
 
     def core(self, y):
         """Everything between the module's LayerNorm and its last bias/dropout: y = LN(x) -> [.., D] (bias of after_conv[2] not added)."""
-        y = ops.matmul_nt(y, self.bottleneck[0].weight.squeeze(-1))                                # 1x1 conv D->2D (bias below)
+        y = ops.matmul_nt(y, self.bottleneck[0].weight)     # 1x1 conv D->2D: the [2D, D, 1] Parameter itself (bias below)
         y = ops.convmod_core(y, self.bottleneck[0].bias, self.conv.weight, self.conv.bias, self.after_conv[0].weight,
                              self.after_conv[0].bias, self.causal, 1e-5, self.slope)                # bias+GLU+depthwise+LN+act
         return ops.matmul_nt(y, self.after_conv[2].weight)

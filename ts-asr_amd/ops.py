@@ -198,6 +198,9 @@ def _dgrad(dy2, weight, w16, M, N, K):
 
 
 def _gemm_ok(x, weight):
+    if weight.dim() == 3 and weight.shape[2] == 1 and weight.is_contiguous():   # kernel-size-1 Conv1d weight [N, K, 1]: the same matrix
+        return (x.dtype == torch.bfloat16 and x.is_cuda and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0
+                and x.shape[-1] == weight.shape[1])
     return (x.dtype == torch.bfloat16 and x.is_cuda and weight.dim() == 2 and weight.stride(1) == 1 and weight.shape[1] % 8 == 0
             and weight.shape[0] % 8 == 0 and weight.stride(0) % 8 == 0 and x.shape[-1] == weight.shape[1])
 
@@ -208,11 +211,11 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        N, K = weight.shape
-        x2 = x.reshape(-1, K)
+        N, K = weight.shape[0], weight.shape[1]          # [N, K] or a kernel-size-1 Conv1d weight [N, K, 1] (the Parameter itself:
+        x2 = x.reshape(-1, K)                            # its bf16 shadows and its slot in the gradient arena are found through it)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        w16 = _bf16_weight(weight)
+        w16 = _bf16_weight(weight).view(N, K) if weight.dim() == 3 else _bf16_weight(weight)
         if w16.stride(1) != 1 or w16.stride(0) % 8 != 0 or w16.data_ptr() % 16 != 0:
             w16 = w16.contiguous()
         M = x2.shape[0]
@@ -226,7 +229,7 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w16 = ctx.saved_tensors
         weight = ctx.weight
-        N, K = weight.shape
+        N, K = weight.shape[0], weight.shape[1]
         M = x2.shape[0]
         dy2 = dy.reshape(M, N)
         if not dy2.is_contiguous():
@@ -239,10 +242,10 @@ class _LinearFn(torch.autograd.Function):
             sink = _GRAD_SINK
             if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
                     and weight.grad.is_contiguous()):
-                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad, accumulate=True, defer_ok=True)     # grad += dy^T . x
+                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad.view(N, K), accumulate=True, defer_ok=True)     # grad += dy^T . x
                 sink.mark_ready(weight)
             else:
-                dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype)
+                dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
         return dx, dw
 
 
@@ -325,6 +328,8 @@ def matmul_nt(x, weight):
     library GEMM through PyTorch-ROCm."""
     if _gemm_ok(x, weight):
         return _LinearFn.apply(x, weight)
+    if weight.dim() == 3:
+        weight = weight.squeeze(-1)
     return F.linear(x, _w(weight, x))
 
 
