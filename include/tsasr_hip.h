@@ -163,13 +163,12 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream);
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H);
-/* Backward: dqkv [B,T,H,3*Dh] fully written; d_bias_u/d_bias_v fp32 [H*Dh] ([H,Dh] reading of the parameter storage);
- * dbd [H, 2T-1, B, T] (io_dtype) = scale * dS shifted back onto the (r, i) grid, fully written (zeros where an (r, i) pair has no
- * key); qv_out [H, B*T, Dh] (io_dtype, may be NULL) = q + pos_bias_v; the host gets d(pk)[r, h, :] = sum_{b,i} dbd[h,r,b,i] *
- * qv_out[h,(b,i),:] with one batched library GEMM. The workspace also holds P_d and scale*dS as [B,H,T,ceil64(T)] tensors between
- * the query-major pass (which computes them) and the key-major pass (dK, dV = two contractions over the queries). */
+/* Backward: dqkv [B,T,H,3*Dh] fully written; d_bias_u/d_bias_v fp32 [H*Dh] ([H,Dh] reading of the parameter storage); dpk [2T-1, H*Dh]
+ * (io_dtype, fully written) = gradient of pk = linear_pos(pos_embs). The workspace holds P_d and scale*dS as [B,H,T,ceil64(T)] tensors
+ * between the query-major pass (which computes them) and the key-major pass (dK, dV = two contractions over the queries), the
+ * q + pos_bias_v rows and the per-utterance-group partial sums of the d(pk) pass. */
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
-                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, float *d_bias_u,
+                          const void *out, const void *dout, const float *lse, void *dqkv, void *dpk, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
                           void *stream);

@@ -19,12 +19,12 @@ lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 out, lse = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev), torch.empty(B, H, T, device=dev)
 C.check(lib.tsasr_relpos_attn_fwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0,
                                   None, C.BF16, C.stream_ptr()), "fwd")
-dqkv = torch.empty_like(qkv); dbd = torch.empty(H, R, B, T, dtype=torch.bfloat16, device=dev); qv = torch.empty(H, B * T, Dh, dtype=torch.bfloat16, device=dev)
+dqkv = torch.empty_like(qkv); dpk = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
 du, dv = torch.empty_like(u), torch.empty_like(v)
 ws = torch.zeros(lib.tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), dtype=torch.uint8, device=dev)
 for _ in range(2):
-    C.check(lib.tsasr_relpos_attn_bwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(dbd),
-                                      C.ptr(qv), C.ptr(du), C.ptr(dv), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0, None, C.BF16, C.ptr(ws), ws.numel(), C.stream_ptr()), "bwd")
+    C.check(lib.tsasr_relpos_attn_bwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(dpk),
+                                      C.ptr(du), C.ptr(dv), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0, None, C.BF16, C.ptr(ws), ws.numel(), C.stream_ptr()), "bwd")
 torch.cuda.synchronize()
 st = ws[:56].view(torch.int64).cpu().tolist()
 names = ["prologue", "staging", "S/dP/G mfma + G store", "softmax/dS/skews + P,dS stores", "dQ mfma", "(sub-block end)", "epilogue"]

@@ -22,6 +22,8 @@
 //   * V is consumed through ds_read_b64_tr_b16 (hardware transpose read) so that it can be staged row-major/coalesced.
 // qkv layout: [B, T, H, 3*Dh] with Q|K|V interleaved per head (attention.py:549-553); pk: [2T-1, H*Dh];
 // pos_bias_u/v: the (Dh, H) parameter's storage reinterpreted as [H, Dh] (a view, not a transpose; attention.py:586-592).
+#include <algorithm>
+
 #include "common.h"
 
 #define AT_QW 32          // queries per wave
@@ -668,48 +670,102 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
     }
 }
 
-// Shifted-back score gradient for d(pk): dbd[h][r][b][i] = dS[b][h][i][j = r + i - (T-1)] (zero where that key does not exist or
-// is masked) - every entry written, no fill pass. workgroup = (64 band rows) x (64 queries) of one (b, h): the 64 x 136 rectangle of
-// dS it touches (start aligned down to 8 keys) goes through LDS as 16-byte pieces, the skew happens in the LDS read (row stride
-// 136 elements: lane stride 68.5 dwords, at most two-way conflicts), a thread writes two consecutive queries (128-byte runs along i).
+// d(pk)[r][h*Dh + d] = sum_b sum_i dS[b][h][i][j = r + i - (T-1)] * (q + v)[b][i][h][d]  - the gradient of the projected positional
+// table, straight from the materialised dS (the first version shifted dS back onto an (r, i) grid in HBM - 32 MB - and ran a library
+// batched GEMM over it whose K dimension was half zeros: 20 + 31 + 5 us per layer). workgroup = (64 band rows, head, group of
+// utterances); per utterance and block of 64 queries that can reach those rows: the 64 x 136 rectangle of dS goes to LDS as
+// 16-byte pieces, the skew happens on the way into the A tile (A[rl][i] = dS[i][r0 + rl + i - (T-1)], 2-byte LDS reads, 16-byte
+// writes), (q+v) rows are the B tile (k-major: transposing fragment reads), 4 MFMAs per wave; blocks of queries that cannot reach
+// the rows are skipped (half of them). Partial sums per utterance group, summed by dpk_reduce_kernel in a fixed order.
 #define SH_LD 136
+#define DPK_LD 72
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_shift_back_kernel(const T *__restrict__ ds, const int32_t *__restrict__ key_lens,
-                                                                T *__restrict__ dbd, int Bn, int Tn, int Tp, int H, int causal) {
-    __shared__ __attribute__((aligned(16))) T tile[64 * SH_LD];
-    const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64, bh = blockIdx.z, b = bh / H, h = bh % H;
+__global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ ds, const T *__restrict__ qv /*[H][B*T][Dh]*/,
+                                                         const int32_t *__restrict__ key_lens, float *__restrict__ part /*[G][R][H*64]*/,
+                                                         int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup) {
+    __shared__ __attribute__((aligned(16))) T raw[64 * SH_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t a_tile[64 * DPK_LD], b_tile[64 * DPK_LD];
+    const int r0 = blockIdx.x * 64, h = blockIdx.y, grp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int rblk = wave & 1, dblk = wave >> 1;
     const int R = 2 * Tn - 1;
-    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
-    const int jlo = r0 + i0 - (Tn - 1);                       // key of (rl = 0, il = 0); keys jlo .. jlo + 126 are touched
-    const int jal = (jlo >= 0 ? jlo : jlo - 7) / 8 * 8;       // aligned down (also for negative jlo)
-    const T *src = ds + (((long long)b * H + h) * Tn) * Tp;
-    constexpr int VE = 16 / (int)sizeof(T), NG = SH_LD / VE;   // elements per 16-byte piece, pieces per row
-    for (int e = threadIdx.x; e < 64 * NG; e += 256) {         // always-issued clamped loads; validity is decided at the read below
-        const int il = e / NG, gq = e % NG, j = jal + gq * VE;
-        const uint4 v = *reinterpret_cast<const uint4 *>(src + (long long)min(i0 + il, Tn - 1) * Tp + min(max(j, 0), Tp - VE));
-        *reinterpret_cast<uint4 *>(tile + il * SH_LD + gq * VE) = v;
-    }
-    __syncthreads();
-    const int ip = (threadIdx.x & 31) * 2;                     // this thread's two queries
-    const int off = jlo - jal;
-    for (int rl = threadIdx.x >> 5; rl < 64; rl += 8) {
-        const int rg = r0 + rl;
-        if (rg >= R) break;
-        T v[2];
+    const int grp4 = lane >> 4, mhalf = grp4 & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    constexpr int VE = 16 / (int)sizeof(T), NG = SH_LD / VE;
+    f32x16 acc = {0};
+    const int b_end = min(Bn, (grp + 1) * bgroup);
+    // (a version that requested the next pair's global loads before building this pair's tiles - LDS-only barriers in between -
+    // measured 5 % slower than this plain loop: two to four workgroups share a CU and cover each other's round trips)
+    for (int b = grp * bgroup; b < b_end; ++b) {
+        const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+        const T *src = ds + (((long long)b * H + h) * Tn) * Tp;
+        const T *qrow = qv + ((long long)h * Bn + b) * Tn * Dh;
+        for (int i0 = 0; i0 < Tn; i0 += 64) {
+            const int jlo = r0 + i0 - (Tn - 1);                  // key of (rl = 0, il = 0); keys jlo .. jlo + 126 are touched
+            if (jlo + 126 < 0 || jlo >= len) continue;           // no query of this block reaches these band rows (workgroup-uniform)
+            const int jal = (jlo >= 0 ? jlo : jlo - 7) / 8 * 8, off = jlo - jal;
+            __syncthreads();                                     // previous tiles consumed
+            for (int e = tid; e < 64 * NG; e += 256) {           // always-issued clamped loads; validity decided below
+                const int il = e / NG, gq = e % NG, j = jal + gq * VE;
+                *reinterpret_cast<uint4 *>(raw + il * SH_LD + gq * VE) =
+                    *reinterpret_cast<const uint4 *>(src + (long long)min(i0 + il, Tn - 1) * Tp + min(max(j, 0), Tp - VE));
+            }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int il = ip + q, i = i0 + il, j = jlo + rl + il;
-            const T x = tile[il * SH_LD + off + rl + il];
-            v[q] = (i < Tn && j >= 0 && j < len && !(causal && j > i)) ? x : (T)0.f;
+            for (int it = 0; it < 2; ++it) {                     // (q + v) rows i0 .. i0+63: 64 x 8 pieces of 8 dims
+                const int e = tid + 256 * it, il = e >> 3, c = (e & 7) * 8;
+                float v8[8];
+                load8_clamped<T>(qrow + (long long)min(i0 + il, Tn - 1) * Dh, c, Dh, (Dh % 8) == 0, v8);
+                if (i0 + il >= Tn) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v8[q] = 0.f;
+                }
+                st8(b_tile + il * DPK_LD + c, v8);
+            }
+            __syncthreads();
+            {   // A tile: thread = (band row rl, 16 consecutive queries)
+                const int rl = tid >> 2, il0 = (tid & 3) * 16;
+                float v16[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int il = il0 + q, i = i0 + il, j = jlo + rl + il;
+                    const float x = (float)raw[il * SH_LD + off + rl + il];
+                    v16[q] = (i < Tn && j >= 0 && j < len && !(causal && j > i)) ? x : 0.f;
+                }
+                st8(a_tile + rl * DPK_LD + il0, *reinterpret_cast<float(*)[8]>(&v16[0]));
+                st8(a_tile + rl * DPK_LD + il0 + 8, *reinterpret_cast<float(*)[8]>(&v16[8]));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(a_tile + (32 * rblk + r) * DPK_LD + 16 * s + 8 * hh);
+                const bf16_t *bp = b_tile + (16 * s + 8 * hh + q4) * DPK_LD + 32 * dblk + 16 * mhalf + 4 * p4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bp + 4 * DPK_LD));
+                bf16x8 bfr;
+                bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3]; bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc, 0, 0, 0);
+            }
         }
-        T *dst = dbd + (((long long)h * R + rg) * Bn + b) * Tn + i0 + ip;
-        if (i0 + ip + 1 < Tn && (Tn % 2) == 0) {
-            struct alignas(2 * sizeof(T)) Pair { T a, b; };
-            *reinterpret_cast<Pair *>(dst) = Pair{v[0], v[1]};
-        } else {
-            if (i0 + ip < Tn) dst[0] = v[0];
-            if (i0 + ip + 1 < Tn) dst[1] = v[1];
-        }
+    }
+    // accumulator: rows = band rows 32*rblk + (g&3) + 8(g>>2) + 4hh, column = head dim 32*dblk + r
+    float *pw = part + ((long long)grp * R) * (H * 64) + h * 64 + 32 * dblk + r;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int rg = r0 + 32 * rblk + (g & 3) + 8 * (g >> 2) + 4 * hh;
+        if (rg < R) pw[(long long)rg * (H * 64)] = acc[g];
+    }
+}
+
+// dpk[r][h*Dh + d] = sum over the utterance groups of part[g][r][h*64 + d], written in the io dtype
+template <typename T>
+__global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict__ part, T *__restrict__ dpk, int R, int H, int Dh, int G) {
+    const long long n = (long long)R * H * 64;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % (H * 64)), d = c & 63, hq = c >> 6;
+        const long long rr = e / (H * 64);
+        if (d >= Dh) continue;
+        float sum = 0.f;
+        for (int g = 0; g < G; ++g) sum += part[(long long)g * n + e];
+        st1(dpk + rr * (H * Dh) + hq * Dh + d, sum);
     }
 }
 
@@ -717,6 +773,12 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 
 static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256); }
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
+static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~512 workgroups
+    const int want = std::max(1, 512 / (4 * cdiv(2 * T - 1, 64)));
+    return std::max(1, cdiv(B, std::min(B, want)));
+}
+static size_t attn_qv_bytes(int B, int T, int H) { return align_up((size_t)B * T * H * AT_DP * sizeof(float), 256); }
+static size_t attn_part_bytes(int B, int T, int H) { return align_up((size_t)cdiv(B, attn_bgroup(B, T)) * (2 * T - 1) * H * 64 * sizeof(float), 256); }
 
 __global__ void attn_zero_kernel(uint4 *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -724,12 +786,15 @@ __global__ void attn_zero_kernel(uint4 *p, size_t n) {
 
 template <typename T>
 static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *out,
-                            const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, int B, int Tn, int H, int Dh, float scale,
+                            const void *dout, const float *lse, void *dqkv, void *dpk, int B, int Tn, int H, int Dh, float scale,
                             int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, char *workspace, hipStream_t st) {
     const int Tp = attn_tp(Tn);
     float *slab = (float *)workspace;
     const size_t mat = align_up((size_t)B * H * Tn * Tp * sizeof(float), 256);
     T *pd = (T *)(workspace + attn_slab_bytes(B, Tn, H)), *ds = (T *)(workspace + attn_slab_bytes(B, Tn, H) + mat);
+    T *qv = (T *)(workspace + attn_slab_bytes(B, Tn, H) + 2 * mat);
+    float *part = (float *)(workspace + attn_slab_bytes(B, Tn, H) + 2 * mat + attn_qv_bytes(B, Tn, H));
+    const int bg = attn_bgroup(B, Tn), G = cdiv(B, bg), R = 2 * Tn - 1;
     if (causal) {   // key blocks in the future of a whole query wave are skipped by bwd_q: their entries must read as zero
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)pd, mat / 16);
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, mat / 16);
@@ -740,8 +805,9 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
                                                                               (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
                                                                               causal, pdrop, seed, seed_dev);
     relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
-                                                                          (T *)qv_out, Tn, Tp, H, Dh, causal);
-    relpos_shift_back_kernel<T><<<dim3(cdiv(2 * Tn - 1, 64), cdiv(Tn, 64), B * H), 256, 0, st>>>(ds, key_lens, (T *)dbd, B, Tn, Tp, H, causal);
+                                                                          qv, Tn, Tp, H, Dh, causal);
+    relpos_dpk_kernel<T><<<dim3(cdiv(R, 64), H, G), 256, 0, st>>>(ds, qv, key_lens, part, B, Tn, Tp, H, Dh, causal, bg);
+    dpk_reduce_kernel<T><<<std::min(1024, cdiv(R * H * 64, 256)), 256, 0, st>>>(part, (T *)dpk, R, H, Dh, G);
 }
 
 extern "C" {
@@ -775,22 +841,22 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
 }
 
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
-    // pos_bias partial sums + the two materialised [B,H,T,Tp] tensors (P_d, scale*dS; sized for fp32 io)
-    return attn_slab_bytes(B, T, H) + 2 * align_up((size_t)B * H * T * attn_tp(T) * sizeof(float), 256);
+    // pos_bias partial sums + the two materialised [B,H,T,Tp] tensors (P_d, scale*dS; sized for fp32 io) + (q + v) rows + d(pk) partials
+    return attn_slab_bytes(B, T, H) + 2 * align_up((size_t)B * H * T * attn_tp(T) * sizeof(float), 256) + attn_qv_bytes(B, T, H) +
+           attn_part_bytes(B, T, H);
 }
 
-/* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh]
- * reading of the parameter storage, dbd [H, 2T-1, B, T] in io_dtype = scale * dS shifted back to the (r, i) grid (fully written,
- * zeros where a (r, i) pair has no key); qv_out (may be NULL): (Q + pos_bias_v) as [H, B*T, Dh] io_dtype; d(pk)[r, h, :] =
- * sum_{b,i} dbd[h,r,b,i] * (q[b,i,h,:] + v[h,:]) is then one library GEMM per head. Three launches: the query-major pass
- * (recomputes the probabilities; dQ, bias partial sums, and P_d / scale*dS materialised in the workspace), the key-major pass
- * (dK, dV as plain contractions of those two tensors) and the shift-back of dS. */
+/* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh] reading of the
+ * parameter storage, dpk [2T-1, H*Dh] (io_dtype, fully written) = gradient of the projected positional table pk. Five launches: the
+ * query-major pass (recomputes the probabilities; dQ, bias partial sums, and P_d / scale*dS materialised in the workspace), the
+ * key-major pass (dK, dV as plain contractions of those two tensors; also leaves the q + pos_bias_v rows), the d(pk) pass (skewed
+ * gather of dS against those rows on MFMA, zero blocks skipped) and the sum of its per-utterance-group partials. */
 int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
-                          const void *out, const void *dout, const float *lse, void *dqkv, void *dbd, void *qv_out, float *d_bias_u,
+                          const void *out, const void *dout, const float *lse, void *dqkv, void *dpk, float *d_bias_u,
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
                           void *stream) {
-    TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out && dout && lse && dqkv && dbd && d_bias_u && d_bias_v && workspace,
+    TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out && dout && lse && dqkv && dpk && d_bias_u && d_bias_v && workspace,
                     "tsasr_relpos_attn_bwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_bwd: head dim %d not supported", Dh);
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), "tsasr_relpos_attn_bwd: workspace too small");
@@ -799,10 +865,10 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     if (io_dtype == TSASR_F32)
-        launch_attn_bwd<float>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dbd, qv_out, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
+        launch_attn_bwd<float>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dpk, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
                                (char *)workspace, st);
     else if (io_dtype == TSASR_BF16)
-        launch_attn_bwd<bf16_t>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dbd, qv_out, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
+        launch_attn_bwd<bf16_t>(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, dpk, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev,
                                 (char *)workspace, st);
     else
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_bwd: bad io_dtype %d", io_dtype);

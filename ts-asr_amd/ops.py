@@ -820,18 +820,15 @@ class _RelPosAttnFn(torch.autograd.Function):
         v = _f32(pv).reshape(-1).contiguous()
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkvc)
-        dbd = torch.empty(H, R, B, T, dtype=qkvc.dtype, device=qkvc.device)     # fully written by the shift-back kernel
-        qv = torch.empty(H, B * T, Dh, dtype=qkvc.dtype, device=qkvc.device)     # q + pos_bias_v, by-product of the key-major pass
+        dpk = torch.empty(R, D, dtype=qkvc.dtype, device=qkvc.device)
         du, dv = torch.empty_like(u), torch.empty_like(v)
         _keep(du, dv)
         ws = _ws(C.lib().tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), qkvc.device)
         with prof.region("relpos_attn_bwd"):
             C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
-                                                  C.ptr(lse), C.ptr(dqkv), C.ptr(dbd), C.ptr(qv), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
+                                                  C.ptr(lse), C.ptr(dqkv), C.ptr(dpk), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
                                                   pdrop, seed, C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc), C.ptr(ws), ws.numel(), C.stream_ptr()),
                     "tsasr_relpos_attn_bwd")
-        # d(pk): parameter-like reduction over the batch = one library GEMM per head on the shifted-back score gradient
-        dpk = torch.bmm(dbd.view(H, R, B * T), qv).permute(1, 0, 2).reshape(R, D)
         return dqkv, dpk, _pgrad(pu, du), _pgrad(pv, dv), None, None, None, None, None, None
 
 
