@@ -19,7 +19,7 @@ STATUS = {
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
     "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank": "HIP", "sentence_norm": "HIP",
-    "relpos_attention": "HIP (d(pk) finished by one library bmm)",
+    "relpos_attention": "HIP (forward; backward = query-major, key-major, d(pk) and partial-sum kernels)",
 }
 
 _seed_counter = [0]
