@@ -113,6 +113,16 @@ int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, voi
 int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
                           unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, int io_dtype,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* out = dropout_p2( res + alpha * timemask(dropout_p(x + bias)) ): the residual tail of a front-end ConvBlock together with the block's
+ * outer Dropout (speechbrain/lobes/models/convolution.py:260-266) in one pass. Backward: dres = dropout_p2'(dout) (written; also the
+ * gradient of `res`), dx = alpha * timemask * dropout_p'(dres); dres is required when p2 > 0. Both masks are counter-based
+ * (seed / seed2 + *seed_dev) and regenerated in the backward. */
+int tsasr_dropout_add2_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha, float p,
+                           unsigned long long seed, float p2, unsigned long long seed2, const unsigned long long *seed_dev,
+                           const int32_t *valid_lens, int Trows, int io_dtype, void *stream);
+int tsasr_dropout_add2_bwd(const void *dout, void *dx, void *dres, float *dbias, long long M, int N, float alpha, float p,
+                           unsigned long long seed, float p2, unsigned long long seed2, const unsigned long long *seed_dev,
+                           const int32_t *valid_lens, int Trows, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 
 /* ------------------------------------------------------------------------------------------

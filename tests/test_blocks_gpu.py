@@ -668,3 +668,29 @@ def test_resample_kernel_vs_reference_golden(golden, nn_, speed):
     from oracle import tsasr_ref as R
     wav = torch.randn(2, L, generator=torch.Generator().manual_seed(1)) * 0.1
     close(rs(wav.to(DEV)), R.resample(wav, 16000, rs.new_freq), 1e-6, 1e-5)
+
+
+def test_dropout_add_with_outer_dropout(ops):
+    """Dropout(r + Dropout(y)) in one pass (the tail of a front-end ConvBlock, SB/lobes/models/convolution.py:260-266): both masks
+    are independent counter streams, the forward composes them, the backward regenerates both (fp32 io: exact arithmetic)."""
+    g = torch.Generator().manual_seed(11)
+    x, r = torch.randn(40, 300, 128, generator=g), torch.randn(40, 300, 128, generator=g)
+    xg, rg = x.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+    close(ops.dropout_add(xg, None, rg, 1.0, 0.1, False, outer_p=0.1), x + r, 1e-6)         # eval: identity
+    close(ops.dropout_add(xg, None, rg, 1.0, 0.0, True, outer_p=0.0), x + r, 1e-6)          # p = 0
+    out = ops.dropout_add(xg, None, rg, 1.0, 0.1, True, outer_p=0.1)
+    keep2 = out != 0
+    n = out.numel()
+    assert abs(keep2.float().mean().item() - 0.9) < 5 * (0.09 / n) ** 0.5 + 1e-5
+    inner = torch.where(keep2, out * (58982 / 65536) - rg.detach(), torch.zeros_like(out))   # undo the outer scale (p quantised to 1/65536)
+    big = xg.detach().abs() > 1e-2                             # |x| large enough to tell "kept" from "dropped" through fp32 rounding of r
+    keep1 = inner.abs() > 0.5 * xg.detach().abs()
+    sel = keep2 & keep1 & big
+    close(inner[sel], (xg.detach() / (58982 / 65536))[sel], 2e-5, 1e-4)
+    frac1 = (keep1 & keep2 & big).float().sum().item() / (keep2 & big).float().sum().item()
+    assert abs(frac1 - 0.9) < 2e-3                                                           # inner mask independent of the outer one
+    out.backward(torch.ones_like(out))
+    s2 = 65536 / 58982
+    close(rg.grad, keep2.float() * s2, 1e-6)
+    close(xg.grad[keep2 & big], (keep1.float() * s2 * s2)[keep2 & big], 1e-5)
+    assert torch.all(xg.grad[~keep2] == 0)

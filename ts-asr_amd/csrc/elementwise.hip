@@ -521,12 +521,13 @@ __global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restric
                                                               const T *__restrict__ res, T *__restrict__ out, long long total,
                                                               int Ncols, float alpha, float p, unsigned long long seed,
                                                               const unsigned long long *__restrict__ seed_dev,
-                                                              const int32_t *__restrict__ valid_lens, int Trows) {
+                                                              const int32_t *__restrict__ valid_lens, int Trows, float p2,
+                                                              unsigned long long seed2) {
     constexpr int N = Vec<T>::N;
-    if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_thr16(p);
-    const DropKey dk = drop_key(seed);
-    const float keep_scale = drop_scale16(thr);
+    if (seed_dev) { seed += *seed_dev; seed2 += *seed_dev; }
+    const unsigned thr = drop_thr16(p), thr2 = drop_thr16(p2);
+    const DropKey dk = drop_key(seed), dk2 = drop_key(seed2);
+    const float keep_scale = drop_scale16(thr), keep_scale2 = drop_scale16(thr2);
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < total; i += (long long)gridDim.x * 256 * N) {
         float v[N], r[N];
         ldv<T, N>(x + i, v);
@@ -535,12 +536,18 @@ __global__ __launch_bounds__(256) void dropout_add_fwd_kernel(const T *__restric
         const int c = (int)(i - row * Ncols);
         const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
         const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
+        const unsigned km2 = p2 > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk2, thr2) : ~0u;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float t = v[j] + (bias ? bias[c + j] : 0.f);
             if (p > 0.f) t = ((km >> j) & 1u) ? t * keep_scale : 0.f;
             t = live ? t * alpha : 0.f;
-            v[j] = (res ? r[j] : 0.f) + t;
+            t += res ? r[j] : 0.f;
+            if (p2 > 0.f) {                                  // outer dropout of the sum; the intermediate is rounded to the io type
+                if (sizeof(T) == 2) t = (float)(bf16_t)t;     // first, exactly as a separate second pass would have read it
+                t = ((km2 >> j) & 1u) ? t * keep_scale2 : 0.f;
+            }
+            v[j] = t;
         }
         stv<T, N>(out + i, v);
     }
@@ -551,13 +558,14 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
                                                               float *__restrict__ part, long long M, int Ncols, float alpha,
                                                               float p, unsigned long long seed,
                                                               const unsigned long long *__restrict__ seed_dev,
-                                                              const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
+                                                              const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg,
+                                                              float p2, unsigned long long seed2, T *__restrict__ dres) {
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float cred[];
-    if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_thr16(p);
-    const DropKey dk = drop_key(seed);
-    const float keep_scale = drop_scale16(thr);
+    if (seed_dev) { seed += *seed_dev; seed2 += *seed_dev; }
+    const unsigned thr = drop_thr16(p), thr2 = drop_thr16(p2);
+    const DropKey dk = drop_key(seed), dk2 = drop_key(seed2);
+    const float keep_scale = drop_scale16(thr), keep_scale2 = drop_scale16(thr2);
     const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
     const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
@@ -575,6 +583,16 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
                 float d[N];
                 ldv<T, N>(dout + i, d);
                 const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)i, dk, thr) : ~0u;
+                if (p2 > 0.f) {                               // gradient through the outer dropout = gradient of the residual input
+                    const unsigned km2 = drop_keep_mask<N>((unsigned long long)i, dk2, thr2);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        float g2 = ((km2 >> j) & 1u) ? d[j] * keep_scale2 : 0.f;
+                        if (sizeof(T) == 2) g2 = (float)(bf16_t)g2;
+                        d[j] = g2;
+                    }
+                    if (dres) stv<T, N>(dres + i, d);
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     float g = live ? d[j] * alpha : 0.f;
@@ -987,25 +1005,25 @@ int tsasr_bias_act_dropout_bwd(const void *dy, const void *y, void *dx, float *d
     return 0;
 }
 
-int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
-                          float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
-                          int io_dtype, void *stream) {
+static int dropout_add_fwd_impl(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
+                                float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                                float p2, unsigned long long seed2, int io_dtype, void *stream) {
     TSASR_CHECK_ARG(x && out, "tsasr_dropout_add_fwd: null pointer");
-    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_dropout_add_fwd: bad shape/p");
+    TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && p >= 0.f && p < 1.f && p2 >= 0.f && p2 < 1.f, "tsasr_dropout_add_fwd: bad shape/p");
     TSASR_CHECK_ARG(!valid_lens || (Trows > 0 && M % Trows == 0), "tsasr_dropout_add_fwd: rows %lld not a multiple of T=%d", M, Trows);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        dropout_add_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (const float *)res, (float *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows);
+        dropout_add_fwd_kernel<float><<<ew_grid(M * N, 4), 256, 0, st>>>((const float *)x, bias, (const float *)res, (float *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows, p2, seed2);
     else if (io_dtype == TSASR_BF16)
-        dropout_add_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows);
+        dropout_add_fwd_kernel<bf16_t><<<ew_grid(M * N, 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)out, M * N, N, alpha, p, seed, seed_dev, valid_lens, Trows, p2, seed2);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_fwd");
     return 0;
 }
 
-int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
-                          unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, int io_dtype,
-                          void *workspace, size_t workspace_bytes, void *stream) {
+static int dropout_add_bwd_impl(const void *dout, void *dx, void *dres, float *dbias, long long M, int N, float alpha, float p,
+                                unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, float p2,
+                                unsigned long long seed2, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(dout && dx, "tsasr_dropout_add_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "tsasr_dropout_add_bwd: bad shape");
     TSASR_CHECK_ARG(!dbias || (workspace && workspace_bytes >= tsasr_colpart_workspace_bytes(M, N)), "tsasr_dropout_add_bwd: workspace too small");
@@ -1014,13 +1032,43 @@ int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M,
     float *part = dbias ? (float *)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32)
-        dropout_add_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<float><<<nwg, 256, slot_lds(N, 4, part), st>>>((const float *)dout, (float *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw, p2, seed2, (float *)dres);
     else if (io_dtype == TSASR_BF16)
-        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
+        dropout_add_bwd_kernel<bf16_t><<<nwg, 256, slot_lds(N, 8, part), st>>>((const bf16_t *)dout, (bf16_t *)dx, part, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, rpw, p2, seed2, (bf16_t *)dres);
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     if (dbias) tsasr_reduce_submit(part, dbias, N, nwg, N, 0, st);
     TSASR_CHECK_LAUNCH("tsasr_dropout_add_bwd");
     return 0;
+}
+
+int tsasr_dropout_add_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha,
+                          float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
+                          int io_dtype, void *stream) {
+    return dropout_add_fwd_impl(x, bias, res, out, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, 0.f, 0ull, io_dtype, stream);
+}
+
+int tsasr_dropout_add_bwd(const void *dout, void *dx, float *dbias, long long M, int N, float alpha, float p,
+                          unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows, int io_dtype,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    return dropout_add_bwd_impl(dout, dx, nullptr, dbias, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, 0.f, 0ull, io_dtype, workspace,
+                                workspace_bytes, stream);
+}
+
+/* out = dropout_p2( res + alpha * timemask(dropout_p(x + bias)) ): the residual tail of a front-end ConvBlock with its outer Dropout
+ * (speechbrain/lobes/models/convolution.py:260-266: drop(drop(act(LN(conv(x)))) + LN(conv1x1(x)))) in one pass instead of two.
+ * Backward: dres = dropout_p2'(dout) (written; it is also the gradient of `res`), dx = alpha * timemask * dropout_p'(dres). */
+int tsasr_dropout_add2_fwd(const void *x, const float *bias, const void *res, void *out, long long M, int N, float alpha, float p,
+                           unsigned long long seed, float p2, unsigned long long seed2, const unsigned long long *seed_dev,
+                           const int32_t *valid_lens, int Trows, int io_dtype, void *stream) {
+    return dropout_add_fwd_impl(x, bias, res, out, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, p2, seed2, io_dtype, stream);
+}
+
+int tsasr_dropout_add2_bwd(const void *dout, void *dx, void *dres, float *dbias, long long M, int N, float alpha, float p,
+                           unsigned long long seed, float p2, unsigned long long seed2, const unsigned long long *seed_dev,
+                           const int32_t *valid_lens, int Trows, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(p2 <= 0.f || dres, "tsasr_dropout_add2_bwd: dres is required when the outer dropout is active");
+    return dropout_add_bwd_impl(dout, dx, dres, dbias, M, N, alpha, p, seed, seed_dev, valid_lens, Trows, p2, seed2, io_dtype, workspace,
+                                workspace_bytes, stream);
 }
 
 /* s = res + alpha * timemask(dropout_p(x + bias)) ; y = LayerNorm(s; gamma, beta, eps).  x, res, s, y: [M, D] io_dtype

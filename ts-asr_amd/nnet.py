@@ -322,8 +322,7 @@ class ConvBlock(nn.Module):
         y, r = ops.frontend_convs(x, c.weight, c.bias, rc.weight, rc.bias, self.padding)
         y = ops.layer_norm(y, n.weight, n.bias, 1e-5, act_slope=0.01)               # LN over [F,C] + LeakyReLU, one pass
         r = ops.layer_norm(r, rn.weight, rn.bias, 1e-5)
-        y = ops.dropout_add(y, None, r, 1.0, dropout, training)                      # r + Dropout(y)
-        return ops.bias_act_dropout(y, None, None, dropout, training) if (training and dropout > 0) else y
+        return ops.dropout_add(y, None, r, 1.0, dropout, training, outer_p=dropout)   # Dropout(r + Dropout(y)), one pass
 
 
 class ConvolutionFrontEnd(nn.Module):

@@ -495,7 +495,7 @@ def bias_act_dropout(x, bias, act_slope, p, training):
 
 class _DropoutAddFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, res, alpha, p, seed, valid_lens, trows):
+    def forward(ctx, x, bias, res, alpha, p, seed, valid_lens, trows, p2=0.0, seed2=0):
         C.require_gpu(x)
         xc = x.contiguous()
         N = xc.shape[-1]
@@ -506,40 +506,45 @@ class _DropoutAddFn(torch.autograd.Function):
             r = res.expand_as(xc).contiguous() if res.shape != xc.shape else res.contiguous()
         out = torch.empty_like(xc)
         with prof.region("dropout_add_fwd"):
-            C.check(C.lib().tsasr_dropout_add_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(out), M, N, float(alpha), float(p), seed,
-                                                  C.ptr(seed_state(xc.device)), C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()), "tsasr_dropout_add_fwd")
+            C.check(C.lib().tsasr_dropout_add2_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(out), M, N, float(alpha), float(p), seed, float(p2), seed2,
+                                                   C.ptr(seed_state(xc.device)), C.ptr(valid_lens), int(trows), C.io_dtype(xc), C.stream_ptr()),
+                    "tsasr_dropout_add2_fwd")
         ctx.save_for_backward(valid_lens)
         ctx.cfg = (float(alpha), float(p), seed, int(trows), bias is not None, bias,
-                   None if res is None else res.shape, xc.shape)
+                   None if res is None else res.shape, xc.shape, float(p2), seed2)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (valid_lens,) = ctx.saved_tensors
-        alpha, p, seed, trows, has_bias, bias_param, rshape, xshape = ctx.cfg
+        alpha, p, seed, trows, has_bias, bias_param, rshape, xshape, p2, seed2 = ctx.cfg
         dout = dout.contiguous()
         N = xshape[-1]
         M = dout.numel() // N
         dx = torch.empty_like(dout)
+        g2 = torch.empty_like(dout) if p2 > 0 else None      # gradient behind the outer dropout (= gradient of the residual input)
         db = torch.empty(N, dtype=torch.float32, device=dout.device) if has_bias else None
         _keep(db)
         ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), dout.device) if has_bias else None
         with prof.region("dropout_add_bwd"):
-            C.check(C.lib().tsasr_dropout_add_bwd(C.ptr(dout), C.ptr(dx), C.ptr(db), M, N, alpha, p, seed,
-                                                  C.ptr(seed_state(dout.device)), C.ptr(valid_lens), trows,
-                                                  C.io_dtype(dout), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
-                    "tsasr_dropout_add_bwd")
+            C.check(C.lib().tsasr_dropout_add2_bwd(C.ptr(dout), C.ptr(dx), C.ptr(g2), C.ptr(db), M, N, alpha, p, seed, p2, seed2,
+                                                   C.ptr(seed_state(dout.device)), C.ptr(valid_lens), trows,
+                                                   C.io_dtype(dout), C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                    "tsasr_dropout_add2_bwd")
         dres = None
         if rshape is not None:
-            dres = dout if tuple(rshape) == tuple(xshape) else dout.sum_to_size(rshape)
-        return dx, (_pgrad(bias_param, db) if has_bias else None), dres, None, None, None, None, None
+            gsrc = g2 if g2 is not None else dout
+            dres = gsrc if tuple(rshape) == tuple(xshape) else gsrc.sum_to_size(rshape)
+        return dx, (_pgrad(bias_param, db) if has_bias else None), dres, None, None, None, None, None, None, None
 
 
-def dropout_add(x, bias=None, res=None, alpha=1.0, p=0.0, training=False, valid_lens=None):
-    """res + alpha * timemask(dropout_p(x + bias)); x is [B, T, N] when valid_lens (int32 [B]) is given."""
+def dropout_add(x, bias=None, res=None, alpha=1.0, p=0.0, training=False, valid_lens=None, outer_p=0.0):
+    """dropout_outer_p( res + alpha * timemask(dropout_p(x + bias)) ); x is [B, T, N] when valid_lens (int32 [B]) is given. The outer
+    dropout (a front-end ConvBlock's last Dropout) rides in the same pass."""
     p = float(p) if training else 0.0
+    p2 = float(outer_p) if training else 0.0
     trows = x.shape[-2] if valid_lens is not None else 0
-    return _DropoutAddFn.apply(x, bias, res, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows)
+    return _DropoutAddFn.apply(x, bias, res, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, p2, next_seed() if p2 > 0 else 0)
 
 
 class _AddLayerNormFn(torch.autograd.Function):
