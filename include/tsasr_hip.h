@@ -306,6 +306,12 @@ long long tsasr_resample_out_len(long long n_in, int orig_freq, int new_freq);
 int tsasr_resample_fwd(const float *x, float *y, const float *weights, const int32_t *first, int B, int L, int n_out, int P, int stride,
                        int W, void *stream);
 
+/* out[c] (+)= sum_m x[m][c], x [M, N] io_dtype (N % 8 == 0, N <= 2048): bias gradient of a GEMM-shaped layer (front-end convolutions,
+ * speechbrain/nnet/CNN.py:629-676). The final sum over per-workgroup partials goes through the deferrable batched reduction. */
+size_t tsasr_colsum_workspace_bytes(long long M, int N);
+int tsasr_colsum(const void *x, float *out, long long M, int N, int accumulate, int io_dtype, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,8 @@ _PROTOS = {
     "tsasr_dropout_add_bwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_dropout_add2_fwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "tsasr_dropout_add2_bwd": (c_int, [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_ull, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_colsum_workspace_bytes": (c_size_t, [c_ll, c_int]),
+    "tsasr_colsum": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_convmod_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_int, c_void_p]),
     "tsasr_convmod_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_convmod_bwd": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_float, c_int, c_void_p, c_size_t, c_void_p]),

@@ -393,6 +393,49 @@ __global__ __launch_bounds__(256) void layernorm_fwd_wide_kernel(const T *__rest
     }
 }
 
+// Column sums of an [M, N] io-dtype matrix (bias gradient of a GEMM-shaped layer whose output gradient is already in HBM):
+// per-workgroup partial rows part[wg][N]; the caller finishes with tsasr_reduce_submit. 16-byte loads, 256/(N/8) rows per pass.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T *__restrict__ x, float *__restrict__ part, long long M, int Ncols,
+                                                          int rows_per_wg) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float cred[];   // [slots][Ncols]
+    const int chunks = Ncols / N, tpr = chunks < 256 ? chunks : 256, slots = 256 / tpr;
+    const int slot = threadIdx.x / tpr, lane = threadIdx.x % tpr;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+    for (int c = lane * N; c < Ncols; c += tpr * N) {
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = 0.f;
+        if (slot < slots) {
+            long long row = r0 + slot;
+            for (; row + 3 * slots < r1; row += 4 * slots) {       // four independent row loads in flight
+                float v[4][N];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ldv<T, N>(x + (row + (long long)q * slots) * Ncols + c, v[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc[j] += v[q][j];
+            }
+            for (; row < r1; row += slots) {
+                float v[N];
+                ldv<T, N>(x + row * Ncols + c, v);
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc[j] += v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) cred[slot * Ncols + c + j] = acc[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ncols; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < slots; ++q) s += cred[q * Ncols + i];
+        part[(size_t)blockIdx.x * Ncols + i] = s;
+    }
+}
+
 // out[c] = sum_n part[n][c]: 16 columns x 16 row-slices per workgroup, slices combined through LDS (fixed order ->
 // deterministic). part rows are `stride` wide; columns [0,D) go to out_a, [D,stride) to out_b.
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ part, float *__restrict__ out_a,
@@ -1129,6 +1172,34 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
         tsasr_reduce_submit(part + 2 * D, dbias, 3 * D, nwg, D, 0, st);
     } else colsum3_kernel<<<cdiv(3 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, dbias, nwg, D);
     TSASR_CHECK_LAUNCH("tsasr_add_layernorm_bwd");
+    return 0;
+}
+
+size_t tsasr_colsum_workspace_bytes(long long M, int N) {
+    const long long rpw = std::max<long long>(64, (M + 1023) / 1024);
+    return align_up((size_t)((M + rpw - 1) / rpw) * N * sizeof(float), 256);
+}
+
+/* out[c] (+)= sum_m x[m][c] for x [M, N] in io_dtype (N % 8 == 0, N <= 2048): the bias gradient of a layer whose output gradient
+ * sits in HBM anyway (front-end convolutions: speechbrain/nnet/CNN.py:629-676 through the GEMM path). Partial rows per workgroup,
+ * finished by the (deferrable) batched reduction. */
+int tsasr_colsum(const void *x, float *out, long long M, int N, int accumulate, int io_dtype, void *workspace, size_t workspace_bytes,
+                 void *stream) {
+    TSASR_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && N % 8 == 0 && N <= 2048, "tsasr_colsum: bad arguments");
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_colsum_workspace_bytes(M, N), "tsasr_colsum: workspace too small");
+    const int rpw = (int)std::max<long long>(64, (M + 1023) / 1024);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    float *part = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32) {
+        const int slots = 256 / std::min(256, N / 4);
+        colsum_rows_kernel<float><<<nwg, 256, (size_t)slots * N * sizeof(float), st>>>((const float *)x, part, M, N, rpw);
+    } else if (io_dtype == TSASR_BF16) {
+        const int slots = 256 / std::min(256, N / 8);
+        colsum_rows_kernel<bf16_t><<<nwg, 256, (size_t)slots * N * sizeof(float), st>>>((const bf16_t *)x, part, M, N, rpw);
+    } else TSASR_CHECK_ARG(false, "tsasr_colsum: bad io_dtype %d", io_dtype);
+    tsasr_reduce_submit(part, out, N, nwg, N, accumulate, st);
+    TSASR_CHECK_LAUNCH("tsasr_colsum");
     return 0;
 }
 

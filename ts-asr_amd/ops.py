@@ -688,6 +688,18 @@ def resample(wav, weights, first, orig_freq, new_freq):
     return y
 
 
+def colsum(x2):
+    """fp32 [N] column sums of an [M, N] matrix in the compute dtype (HIP; the final reduction joins the deferred batch)."""
+    C.require_gpu(x2)
+    M, N = x2.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2.device)
+    _keep(out)
+    ws = _ws(C.lib().tsasr_colsum_workspace_bytes(M, N), x2.device)
+    with prof.region("colsum"):
+        C.check(C.lib().tsasr_colsum(C.ptr(x2), C.ptr(out), M, N, 0, C.io_dtype(x2), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_colsum")
+    return out
+
+
 def _out_len(n):
     return (n - 1) // 2 + 1
 
@@ -755,6 +767,7 @@ class _FrontendConvFn(torch.autograd.Function):
             y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
         ctx.save_for_backward(A, wm, w2m)
         ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape, hip)
+        ctx.biases = (b1, b2)
         return y1, y2
 
     @staticmethod
@@ -774,7 +787,10 @@ class _FrontendConvFn(torch.autograd.Function):
             dA = g1 @ wm
             dR = g2 @ w2m
         dw1 = dwm.view(Co, 3, 3, Ci).permute(0, 3, 2, 1).to(dw1t)
-        db1, db2 = g1.sum(0, dtype=torch.float32).to(db1t), g2.sum(0, dtype=torch.float32).to(db2t)
+        if hip:   # column sums on a HIP kernel, added to the arena by the batched end-of-backward add
+            db1, db2 = _pgrad(ctx.biases[0], colsum(g1)), _pgrad(ctx.biases[1], colsum(g2))
+        else:
+            db1, db2 = g1.sum(0, dtype=torch.float32).to(db1t), g2.sum(0, dtype=torch.float32).to(db2t)
         dx = torch.empty(B, T, Fq, Ci, dtype=A.dtype, device=A.device)
         with prof.region("frontend_col2im"):
             C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(A), C.stream_ptr()),
