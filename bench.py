@@ -152,7 +152,10 @@ def main():
     use_graph = (not args.eager) and args.dtype == "bf16"
     if use_graph:
         brain.enable_hip_graph(warmup_steps=min(3, max(2, args.warmup - 1)))
-    for i in range(max(args.warmup, 4 if use_graph else 0)):   # graph mode: >= 3 eager steps + the capture step are warm-up
+    # graph mode: >= 3 eager steps + the capture step are warm-up; with gradient accumulation both flavours (accumulate-only and
+    # stepping micro-batch) must have been captured: one full accumulation cycle runs eagerly first, the second one captures
+    n_warm = max(args.warmup, (max(4, 2 * args.accum + 1)) if use_graph else 0)
+    for i in range(n_warm):
         brain.fit_batch(batch)
         torch.cuda.synchronize()
         log(f"warm-up step {i + 1} done" + (" (hipGraph captured)" if brain._graph is not None else ""))
