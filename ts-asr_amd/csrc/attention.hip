@@ -773,8 +773,8 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 
 static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256); }
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
-static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~512 workgroups
-    const int want = std::max(1, 512 / (4 * cdiv(2 * T - 1, 64)));
+static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
+    const int want = std::max(1, 1024 / (4 * cdiv(2 * T - 1, 64)));
     return std::max(1, cdiv(B, std::min(B, want)));
 }
 static size_t attn_qv_bytes(int B, int T, int H) { return align_up((size_t)B * T * H * AT_DP * sizeof(float), 256); }
