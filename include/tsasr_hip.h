@@ -88,6 +88,11 @@ size_t tsasr_layernorm_bwd_workspace_bytes(long long M, int D);
 int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
                         const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
                         int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* ... with dx = LayerNorm_bwd(dy) + dadd: the gradient that reached x along a residual path is summed in the same pass (rows of at
+ * most 2048 bf16 / 1024 fp32 elements). */
+int tsasr_layernorm_bwd_add(const void *dy, const void *dadd, const void *x, const float *gamma, const float *beta, const float *mean,
+                            const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                            int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Dropout masks are a pure function of (seed + *seed_dev, element index); seed_dev (device uint64, may be NULL) is advanced once per
  * training step by tsasr_seed_advance so that a captured hipGraph still draws fresh masks every replay. */

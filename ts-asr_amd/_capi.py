@@ -40,6 +40,7 @@ _PROTOS = {
     "tsasr_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_ll, c_int, c_float, c_float, c_int, c_void_p]),
     "tsasr_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
     "tsasr_layernorm_bwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_layernorm_bwd_add": (c_int, [c_void_p] * 10 + [c_ll, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_seed_advance": (c_int, [c_void_p, c_ull, c_void_p]),
     "tsasr_bias_act_dropout_fwd": (c_int, [c_void_p] * 3 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_int, c_void_p]),
     "tsasr_colpart_workspace_bytes": (c_size_t, [c_ll, c_int]),

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ mean, const float *__restrict__ rstd,
                                                             T *__restrict__ dx, float *__restrict__ part, long long M, int D,
-                                                            float slope, int rows_per_wg) {
+                                                            float slope, int rows_per_wg, const T *__restrict__ dadd) {
     constexpr int N = Vec<T>::N;
     __shared__ float red[4];
     __shared__ float colred[(TPR == 64) ? 1 : 1];
@@ -170,9 +170,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
             for (int it = 0; it < ITERS; ++it) {
                 const int c = (it * TPR + l) * N;
                 if (c < D) {
-                    float o[N];
+                    float o[N], ad[N];
+                    if (dadd) ldv<T, N>(dadd + row * D + c, ad);     // gradient that reached x along another path (residual): summed here
 #pragma unroll
-                    for (int j = 0; j < N; ++j) o[j] = rs * (gdy[it][j] - m1 - xh[it][j] * m2);
+                    for (int j = 0; j < N; ++j) o[j] = rs * (gdy[it][j] - m1 - xh[it][j] * m2) + (dadd ? ad[j] : 0.f);
                     stv<T, N>(dxr + c, o);
                 }
             }
@@ -920,12 +921,13 @@ static int launch_ln_fwd(const void *x, const float *g, const float *b, void *y,
 
 template <typename T>
 static int launch_ln_bwd(const void *dy, const void *x, const float *g, const float *b, const float *mean, const float *rstd,
-                         void *dx, float *part, long long M, int D, float slope, int rpw, int nwg, hipStream_t st) {
+                         void *dx, float *part, long long M, int D, float slope, int rpw, int nwg, hipStream_t st, const void *dadd = nullptr) {
+    if (dadd && D > 4 * 64 * Vec<T>::N) return -3;      // the pass-through sum is implemented for the one-wave-per-row kernels
     constexpr int N = Vec<T>::N;
     const int per_wave = 64 * N, per_wg = 256 * N;
 #define LN_BWD(TPR, IT)                                                                                                  \
     layernorm_bwd_kernel<T, TPR, IT><<<nwg, 256, (TPR == 64 ? (size_t)4 * 2 * D * sizeof(float) : 0), st>>>(             \
-        (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
+        (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw, (const T *)dadd)
 #define LN_BWD_WIDE(IT)                                                                                                   \
     layernorm_bwd_wide_kernel<T, IT><<<nwg, 256, 0, st>>>((const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
     if (D <= per_wave) LN_BWD(64, 1);
@@ -973,9 +975,11 @@ size_t tsasr_layernorm_bwd_workspace_bytes(long long M, int D) {
     return align_up((size_t)nwg * 2 * D * sizeof(float), 256);
 }
 
-int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
-                        const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
-                        int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+}  // extern "C"
+
+static int layernorm_bwd_impl(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
+                              const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                              int io_dtype, void *workspace, size_t workspace_bytes, void *stream, const void *dadd) {
     TSASR_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && workspace, "tsasr_layernorm_bwd: null pointer");
     TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_layernorm_bwd: bad shape");
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_layernorm_bwd_workspace_bytes(M, D), "tsasr_layernorm_bwd: workspace too small");
@@ -985,8 +989,8 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
-    int rc = io_dtype == TSASR_F32 ? launch_ln_bwd<float>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
-           : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st)
+    int rc = io_dtype == TSASR_F32 ? launch_ln_bwd<float>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st, dadd)
+           : io_dtype == TSASR_BF16 ? launch_ln_bwd<bf16_t>(dy, x, gamma, beta, mean, rstd, dx, part, M, D, act_slope, rpw, nwg, st, dadd)
                                     : -2;
     TSASR_CHECK_ARG(rc == 0, "tsasr_layernorm_bwd: D=%d too large or bad io_dtype %d", D, io_dtype);
     if (tsasr_reduce_deferring()) {
@@ -995,6 +999,26 @@ int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
     } else colsum_kernel<<<cdiv(2 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, nwg, D, 2 * D);
     TSASR_CHECK_LAUNCH("tsasr_layernorm_bwd");
     return 0;
+}
+
+extern "C" {
+
+int tsasr_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *beta, const float *mean,
+                        const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                        int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    return layernorm_bwd_impl(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, M, D, act_slope, io_dtype, workspace, workspace_bytes, stream,
+                              nullptr);
+}
+
+/* tsasr_layernorm_bwd with dx = LayerNorm_bwd(dy) + dadd: the gradient that reached x along a residual path is summed in the same
+ * pass (a Conformer layer reads its input twice: through ffn_module1's LayerNorm and as the residual). Rows of at most 4 x 64 x 8
+ * (bf16) / 4 x 64 x 4 (fp32) elements. */
+int tsasr_layernorm_bwd_add(const void *dy, const void *dadd, const void *x, const float *gamma, const float *beta, const float *mean,
+                            const float *rstd, void *dx, float *dgamma, float *dbeta, long long M, int D, float act_slope,
+                            int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dadd, "tsasr_layernorm_bwd_add: null pointer");
+    return layernorm_bwd_impl(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, M, D, act_slope, io_dtype, workspace, workspace_bytes, stream,
+                              dadd);
 }
 
 static size_t slot_lds(int Ncols, int vec, const float *part) {

@@ -16,6 +16,7 @@ Reference files mirrored (SB = vendor/speechbrain/speechbrain):
   ConvolutionModule / ConformerEncoderLayer              SB/lobes/models/transformer/Conformer.py:24-115 / 118-260
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -526,7 +527,7 @@ class ConformerEncoderLayer(nn.Module):
         ln1, pff1 = self.ffn_module1[0], self.ffn_module1[1].ffn
         ln2, pff2 = self.ffn_module2[0], self.ffn_module2[1].ffn
         x = _cd(x)
-        y = ops.layer_norm(x, ln1.weight, ln1.bias, 1e-5)
+        y, x = ops.layer_norm_res(x, ln1.weight, ln1.bias, 1e-5)     # x is read twice (here and as the residual): one backward kernel sums both gradients
         h = ops.ffn_core(y, pff1[0].weight, pff1[0].bias, pff1[3].weight, self.slope, p, tr)
         x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
         o, attn = mha._context(y, pos_embs, valid_lens, self.causal or src_mask is not None, need_attn)

@@ -442,6 +442,57 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, _pgrad(ctx.params[0], dg), _pgrad(ctx.params[1], db), None, None
 
 
+class _LayerNormResFn(torch.autograd.Function):
+    """(LayerNorm(x), x): the second output is x itself, handed on to whoever reads it as a residual. In backward the two gradients
+    arrive together and the LayerNorm backward kernel sums them (no separate add kernel, no extra 4 MB round trip per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C.require_gpu(x, weight, bias)
+        ctx.set_materialize_grads(False)
+        D = weight.numel()
+        xc = x.contiguous()
+        M = xc.numel() // D
+        g, b = _f32(weight).reshape(-1).contiguous(), _f32(bias).reshape(-1).contiguous()
+        y = torch.empty_like(xc)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        with prof.region("layernorm_fwd"):
+            C.check(C.lib().tsasr_layernorm_fwd(C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(y), C.ptr(mean), C.ptr(rstd), M, D, float(eps),
+                                                -1.0, C.io_dtype(xc), C.stream_ptr()), "tsasr_layernorm_fwd")
+        ctx.save_for_backward(xc, g, b, mean, rstd)
+        ctx.params = (weight, bias)
+        return y, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        xc, g, b, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        D = g.numel()
+        M = xc.numel() // D
+        dy = dy.contiguous()
+        dx = torch.empty_like(xc)
+        dg, db = torch.empty_like(g), torch.empty_like(b)
+        _keep(dg, db)
+        ws = _ws(C.lib().tsasr_layernorm_bwd_workspace_bytes(M, D), xc.device)
+        with prof.region("layernorm_bwd"):
+            if dres is None:
+                C.check(C.lib().tsasr_layernorm_bwd(C.ptr(dy), C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(mean), C.ptr(rstd), C.ptr(dx), C.ptr(dg),
+                                                    C.ptr(db), M, D, -1.0, C.io_dtype(xc), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                        "tsasr_layernorm_bwd")
+            else:
+                C.check(C.lib().tsasr_layernorm_bwd_add(C.ptr(dy), C.ptr(dres.contiguous()), C.ptr(xc), C.ptr(g), C.ptr(b), C.ptr(mean), C.ptr(rstd),
+                                                        C.ptr(dx), C.ptr(dg), C.ptr(db), M, D, -1.0, C.io_dtype(xc), C.ptr(ws), ws.numel(),
+                                                        C.stream_ptr()), "tsasr_layernorm_bwd_add")
+        return dx, _pgrad(ctx.params[0], dg), _pgrad(ctx.params[1], db), None
+
+
+def layer_norm_res(x, weight, bias, eps):
+    """(LayerNorm(x), x) for an x that is also used as a residual afterwards (use the returned alias for that)."""
+    return _LayerNormResFn.apply(x, weight, bias, eps)
+
+
 def layer_norm(x, weight, bias, eps, act_slope=None):
     """LayerNorm over the trailing dims covered by ``weight`` (1-D model width or the front-end's [F, C]),
     optionally fused with the LeakyReLU that follows it."""
