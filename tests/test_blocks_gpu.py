@@ -694,3 +694,45 @@ def test_dropout_add_with_outer_dropout(ops):
     close(rg.grad, keep2.float() * s2, 1e-6)
     close(xg.grad[keep2 & big], (keep1.float() * s2 * s2)[keep2 & big], 1e-5)
     assert torch.all(xg.grad[~keep2] == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(160000, 128), (777, 256), (5, 2048)])
+def test_colsum_kernel(ops, dtype, M, N):
+    """tsasr_colsum (bias gradients of the GEMM-shaped front-end convolutions) against a float64 column sum."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g).to(dtype)
+    ref = x.double().sum(0)
+    out = ops.colsum(x.to(DEV))
+    tol = 2e-3 * (M ** 0.5)
+    close(out, ref.float(), tol, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_norm_res_sums_both_gradients(ops, dtype):
+    """(LayerNorm(x), x) with the residual pass-through: forward values and the summed gradient equal LayerNorm + an explicit add."""
+    g = torch.Generator().manual_seed(3)
+    M, D = 300, 256
+    x = torch.randn(M, D, generator=g).to(dtype)
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    dy, dr = torch.randn(M, D, generator=g).to(dtype), torch.randn(M, D, generator=g).to(dtype)
+    res = {}
+    for which in ("res", "plain"):
+        xg = x.to(DEV).requires_grad_()
+        wg, bg = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        if which == "res":
+            y, xa = ops.layer_norm_res(xg, wg, bg, 1e-5)
+        else:
+            y, xa = ops.layer_norm(xg, wg, bg, 1e-5), xg
+        torch.autograd.backward([y, xa], [dy.to(DEV), dr.to(DEV)])
+        res[which] = (y.detach(), xg.grad, wg.grad, bg.grad)
+    lo = dtype == torch.bfloat16
+    assert torch.equal(res["res"][0], res["plain"][0])
+    close(res["res"][1], res["plain"][1], 3e-2 if lo else 1e-6, 1e-2 if lo else 1e-6)      # one rounding less on the fused path
+    close(res["res"][2], res["plain"][2], 1e-4, 1e-5)
+    close(res["res"][3], res["plain"][3], 1e-4, 1e-5)
+    # only the residual path has a gradient
+    xg = x.to(DEV).requires_grad_()
+    y, xa = ops.layer_norm_res(xg, w.to(DEV), b.to(DEV), 1e-5)
+    xa.backward(dr.to(DEV))
+    assert torch.equal(xg.grad, dr.to(DEV))
