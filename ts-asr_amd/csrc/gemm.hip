@@ -16,6 +16,8 @@
 // Kernel: 256 threads = 2x2 waves, macro-tile BMxBN in {128x128, 64x64} (picked so that the grid covers the 256 CUs), BK = 64,
 // v_mfma_f32_32x32x16_bf16, fp32 accumulators, two LDS buffers with the next tile's global loads in flight during the MFMAs
 // (register staging, one barrier per k-tile), LDS rows padded by 16 B (conflict-free 16-byte fragment reads).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define GB_K 64
@@ -607,7 +609,10 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
         // are k-major, i.e. every fragment comes through ds_read_b64_tr_b16, and that path - not the DMA, not VALU, not MFMA - is
         // what bounds these kernels (the same tiles read with ds_read_b128, wrong results, run in 21.5 us instead of 30.1 us).
         // Macro-tile / split sweeps (tools/wgrad_sweep.py) stay within 10% of this choice in isolation and within noise in the step.
-        int s = (int)((512 + tiles - 1) / tiles);
+        // target: 3 workgroups per CU. Measured on the whole step (A/B in one process group, same box): 256 -> 19.0 ms, 384 -> 18.0,
+        // 512 -> 17.65, 640 / 768 -> 17.4, 896 -> 17.85, 1024 -> 17.8 (more slabs = more bytes for the batched reduction).
+        static const int target = getenv("TSASR_WGRAD_WGS") ? atoi(getenv("TSASR_WGRAD_WGS")) : 768;
+        int s = (int)((target + tiles - 1) / tiles);
         const int max_s = K / 256;             // at least 4 k-tiles per split
         if (s > max_s) s = max_s;
         if (s > 32) s = 32;
