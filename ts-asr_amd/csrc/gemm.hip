@@ -601,7 +601,8 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
                     t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
     // the largest macro-tile that still gives every CU work: 128x128 needs >= 2 tiles per CU (below that the 128x64 ring kernel
     // wins by 5-20% at N <= 768: tools/fwd_sweep.py), 128x64 needs ~one per CU
-    p.tile = t0 >= 512 ? 0 : (t1 >= 192 ? 1 : 2);
+    static const int thr0 = getenv("TSASR_GEMM_T0") ? atoi(getenv("TSASR_GEMM_T0")) : 512, thr1 = getenv("TSASR_GEMM_T1") ? atoi(getenv("TSASR_GEMM_T1")) : 192;
+    p.tile = t0 >= thr0 ? 0 : (t1 >= thr1 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
     if (out_f32 && tiles < 256 && K >= 1024) {
