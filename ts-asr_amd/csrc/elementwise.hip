@@ -10,6 +10,8 @@
 // (dgamma/dbeta/dbias) are two-stage and deterministic: per-workgroup partial rows, then a small column-sum kernel -
 // no float atomics. Dropout is counter-based (hash of element index and a per-call seed): the mask is never stored,
 // backward regenerates it.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -889,7 +891,8 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ 
 static int pick_rows_per_wg(long long M, int min_rows) {
     // ~1024 workgroups (4 per CU: a wave walks its rows one after the other, so other waves must cover its memory round
     // trips) unless rows are few; at least `min_rows` rows each so partial slabs stay small
-    long long r = (M + 1023) / 1024;
+    static const long long target = getenv("TSASR_ROW_WGS") ? atoll(getenv("TSASR_ROW_WGS")) : 1024;
+    long long r = (M + target - 1) / target;
     if (r < min_rows) r = min_rows;
     return (int)r;
 }

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__re
     else { c[0] = s.x; c[1] = s.y; c[2] = s.z; c[3] = s.w; }
 }
 
-static int g_use_ring = 1;
+static int g_use_ring = getenv("TSASR_GEMM_RING") ? atoi(getenv("TSASR_GEMM_RING")) : 1;   // 0: never, 1: long K or small tiles, 2: always
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
