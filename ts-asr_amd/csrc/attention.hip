@@ -26,8 +26,12 @@
 
 #include "common.h"
 
+#ifndef AT_NW
+#define AT_NW 4           // waves per workgroup (forward and query-major backward kernels)
+#endif
+#define AT_TH (64 * AT_NW) // threads per workgroup
 #define AT_QW 32          // queries per wave
-#define AT_QB 128         // queries per workgroup
+#define AT_QB (32 * AT_NW) // queries per workgroup
 #define AT_KT 64          // keys per LDS tile
 #define AT_DP 64          // padded head dim (Dh <= 64)
 #define AT_LD 72          // LDS row stride in bf16 (144 B: 16-byte slots rotate by 9 per row -> conflict-free b128 reads)
@@ -79,19 +83,19 @@ __device__ __forceinline__ void load8_clamped(const T *__restrict__ row, int d0,
 template <typename T, int ROWS>
 __device__ __forceinline__ void stage_rows(bf16_t *lds, const T *__restrict__ src, long long src_stride, int first_row, int lo, int hi,
                                            int Dh) {
-    constexpr int NIT = ROWS * (AT_DP / 8) / 256;
-    static_assert(ROWS * (AT_DP / 8) % 256 == 0, "whole passes of the workgroup");
+    constexpr int NIT = ROWS * (AT_DP / 8) / AT_TH;
+    static_assert(ROWS * (AT_DP / 8) % AT_TH == 0, "whole passes of the workgroup");
     const bool fast = (Dh % 8) == 0;
     const int c = (threadIdx.x % (AT_DP / 8)) * 8;      // 256 % (AT_DP / 8) == 0: one column group per thread
     float v[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int rr = (threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+        const int rr = (threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
         load8_clamped<T>(src + (long long)min(max(r, lo), hi - 1) * src_stride, c, Dh, fast, v[it]);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int rr = (threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+        const int rr = (threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
         if (r < lo || r >= hi) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[it][j] = 0.f;
@@ -106,7 +110,7 @@ __device__ __forceinline__ void stage_rows(bf16_t *lds, const T *__restrict__ sr
 // round trip per tile (4 tiles at T' = 250).
 template <typename T, int ROWS>
 struct StagePieces {
-    static constexpr int NIT = ROWS * (AT_DP / 8) / 256, W = 8 * (int)sizeof(T) / 16;   // uint4 words per 8-element piece
+    static constexpr int NIT = ROWS * (AT_DP / 8) / AT_TH, W = 8 * (int)sizeof(T) / 16;   // uint4 words per 8-element piece
     uint4 raw[NIT][W];
     int first_row, lo, hi;
     __device__ __forceinline__ void request(const T *__restrict__ src, long long src_stride, int first, int lo_, int hi_, int Dh) {
@@ -114,7 +118,7 @@ struct StagePieces {
         const int c = (threadIdx.x % (AT_DP / 8)) * 8, cc = min(c, ((Dh + 7) & ~7) - 8);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int r = first + (int)(threadIdx.x + it * 256) / (AT_DP / 8);
+            const int r = first + (int)(threadIdx.x + it * AT_TH) / (AT_DP / 8);
             const uint4 *p = reinterpret_cast<const uint4 *>(src + (long long)min(max(r, lo_), hi_ - 1) * src_stride + cc);
 #pragma unroll
             for (int w = 0; w < W; ++w) raw[it][w] = p[w];
@@ -124,7 +128,7 @@ struct StagePieces {
         const int c = (threadIdx.x % (AT_DP / 8)) * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int rr = (int)(threadIdx.x + it * 256) / (AT_DP / 8), r = first_row + rr;
+            const int rr = (int)(threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
             if (sizeof(T) == 2 && (Dh % 8) == 0) {   // bf16 source, whole 16-byte pieces: straight to LDS, no fp32 round trip
                 const bool ok = r >= lo && r < hi && c < Dh;
                 uint4 w = raw[it][0];
@@ -153,7 +157,7 @@ struct StagePieces {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+__global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
                                                               const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                               const int32_t *__restrict__ key_lens, T *__restrict__ out,
                                                               float *__restrict__ lse, int Tn, int H, int Dh, float scale,
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(const T *__restric
 // dS = P * (dP - delta), delta_i = dO_i . O_i ; with dropout P_d = P*m/(1-p): dP = (dO.V^T)*m/(1-p), same counter-based mask.
 // =====================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+__global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
                                                                 const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                 const int32_t *__restrict__ key_lens, const T *__restrict__ out,
                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(const T *__restr
     }
     // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
     T *dq = dqkv + ((long long)b * Tn + iqc) * row_stride + (long long)h * 3 * Dh;
-    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * 4 + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
+    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * AT_NW + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict
 
 extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 
-static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * 4 * 128 * sizeof(float), 256); }
+static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * AT_NW * 128 * sizeof(float), 256); }
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
 static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
     const int want = std::max(1, 1024 / (4 * cdiv(2 * T - 1, 64)));
@@ -801,7 +805,7 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     }
     const size_t lds_q = tsasr_relpos_attn_lds_bytes();
     (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB), H, B), 256, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out,
+    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB), H, B), AT_TH, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out,
                                                                               (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
                                                                               causal, pdrop, seed, seed_dev);
     relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
@@ -813,7 +817,7 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
 extern "C" {
 
 size_t tsasr_relpos_attn_lds_bytes(void) {
-    return (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)4 * 64 * 32 * sizeof(float);
+    return (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)AT_NW * 64 * 32 * sizeof(float);
 }
 
 /* out [B,T,H*Dh] = fused rel-pos attention; lse [B,H,T] fp32 (may be NULL) is kept for the backward.
@@ -829,10 +833,10 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_fwd_kernel<float><<<grid, AT_TH, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else if (io_dtype == TSASR_BF16) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_fwd_kernel<bf16_t><<<grid, AT_TH, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_fwd: bad io_dtype %d", io_dtype);
     }
@@ -875,8 +879,8 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
     // slab parts [(b, qtile, wave)] x row [h][u 64 | v 64] -> sum over the parts per (h, which, d): batched with the other
     // parameter-gradient reductions while tsasr_reduce_defer is on (csrc/reduce.hip)
     for (int h = 0; h < H; ++h) {
-        tsasr_reduce_submit(slab + h * 128, d_bias_u + h * Dh, (long long)H * 128, 4 * B * nqt, Dh, 0, st);
-        tsasr_reduce_submit(slab + h * 128 + 64, d_bias_v + h * Dh, (long long)H * 128, 4 * B * nqt, Dh, 0, st);
+        tsasr_reduce_submit(slab + h * 128, d_bias_u + h * Dh, (long long)H * 128, AT_NW * B * nqt, Dh, 0, st);
+        tsasr_reduce_submit(slab + h * 128 + 64, d_bias_v + h * Dh, (long long)H * 128, AT_NW * B * nqt, Dh, 0, st);
     }
     TSASR_CHECK_LAUNCH("tsasr_relpos_attn_bwd");
     return 0;
