@@ -893,6 +893,8 @@ static int pick_rows_per_wg(long long M, int min_rows) {
     // trips) unless rows are few; at least `min_rows` rows each so partial slabs stay small
     static const long long target = getenv("TSASR_ROW_WGS") ? atoll(getenv("TSASR_ROW_WGS")) : 1024;
     long long r = (M + target - 1) / target;
+    static const int min_env = getenv("TSASR_ROW_MIN") ? atoi(getenv("TSASR_ROW_MIN")) : 0;
+    if (min_env > 0) min_rows = min_env;
     if (r < min_rows) r = min_rows;
     return (int)r;
 }
@@ -1031,7 +1033,8 @@ static size_t slot_lds(int Ncols, int vec, const float *part) {
 
 static unsigned ew_grid(long long total, int N) {
     long long blocks = (total / N + 255) / 256;
-    if (blocks > 4096) blocks = 4096;  // grid-stride beyond 16 workgroups per CU
+    static const long long cap = getenv("TSASR_EW_CAP") ? atoll(getenv("TSASR_EW_CAP")) : 4096;
+    if (blocks > cap) blocks = cap;  // grid-stride beyond 16 workgroups per CU
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
