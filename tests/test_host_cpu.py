@@ -222,3 +222,65 @@ def test_resampler_host_side_matches_reference(golden):
     x = torch.sin(torch.arange(1600.0)).unsqueeze(0)
     assert torch.equal(no(x), x) and no(x) is not x
     assert nn_.SpeedPerturb(16000, speeds=[100])(x) is x
+
+
+SAMPLER_CASES = {
+    "train": dict(max_batch_length=50.0, num_buckets=80, shuffle=False, batch_ordering="ascending", max_batch_ex=None),
+    "valid": dict(max_batch_length=50.0, num_buckets=80, shuffle=False, batch_ordering="descending", max_batch_ex=6),
+    "shuffled_e0": dict(max_batch_length=30.0, num_buckets=12, shuffle=True, batch_ordering="random", seed=7, epoch=0),
+    "shuffled_e3": dict(max_batch_length=30.0, num_buckets=12, shuffle=True, batch_ordering="random", seed=7, epoch=3),
+    "boundaries": dict(max_batch_length=40.0, bucket_boundaries=[5.0, 10.0, 20.0, 40.0], shuffle=False, batch_ordering="descending",
+                       drop_last=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_CASES))
+def test_dynamic_batch_sampler_equals_reference(golden, name):
+    """Batch compositions of dataio.DynamicBatchSampler against the reference's own sampler run on the same 500 durations
+    (tests/golden/c1_sampler.npz, oracle/gen_golden_sampler.py): the recipe's train / valid settings and the shuffled, random-order,
+    max_batch_ex and explicit-boundary variants - index for index."""
+    dataio = importlib.import_module("ts-asr_amd.dataio")
+    g = golden["c1_sampler"]
+    lens = g["durations"].tolist()
+    s = dataio.DynamicBatchSampler(list(range(len(lens))), lengths_list=lens, **SAMPLER_CASES[name])
+    assert np.allclose(s._bucket_boundaries, g[name + "_boundaries"], rtol=1e-12)
+    batches = [list(b) for b in s]
+    assert [len(b) for b in batches] == g[name + "_sizes"].tolist() and len(s) == len(batches)
+    assert [i for b in batches for i in b] == g[name + "_flat"].tolist()
+    kw = SAMPLER_CASES[name]
+    if not kw.get("drop_last"):
+        assert sorted(i for b in batches for i in b) == list(range(len(lens)))        # every utterance exactly once
+    for b in batches:                                                                      # a bucket's batch never exceeds its budget
+        edge = g[name + "_boundaries"][min(int(np.searchsorted(g[name + "_boundaries"], max(lens[i] for i in b))), len(g[name + "_boundaries"]) - 1)]
+        assert len(b) <= max(1, int(kw["max_batch_length"] / edge)) or max(lens[i] for i in b) > g[name + "_boundaries"][-1]
+
+
+def test_mixing_arithmetic_and_collate():
+    """dataio.mix_sources on hand-computable cases (train_librispeechmix_scratch.py:356-386): delays in samples, zero padding, crop
+    window, interference rescaled to the requested power ratio; collate -> PaddedBatch with relative lengths and blank-prefixed tokens."""
+    dataio = importlib.import_module("ts-asr_amd.dataio")
+    sr = 10
+    a, b = torch.arange(1.0, 9.0), torch.ones(4) * 2
+    m = dataio.mix_sources([a, b], delays=[0.0, 0.25], start=0.1, duration=0.6, target_speaker_idx=0, sample_rate=sr)
+    full = torch.tensor([1, 2, 3, 4 + 2, 5 + 2, 6 + 2, 7 + 2, 8.0])          # b delayed by ceil(2.5) = 3 samples
+    assert torch.equal(m, full[1:7])
+    m2 = dataio.mix_sources([a, b], [0.0, 0.0], 0.0, 0.8, 0, sr, gain_nontarget=-10)
+    interferer = m2 - a
+    assert float((interferer[:4] ** 2).mean() / (a ** 2).mean()) == pytest.approx(0.1, rel=1e-5) and torch.all(interferer[4:] == 0)
+    assert torch.equal(dataio.trim_enroll(torch.arange(100.0), 2.55, sr), torch.arange(26.0))
+    batch = dataio.collate([dict(id="u1", mixed_sig=torch.randn(50), enroll_sig=torch.randn(30), tokens=[3, 4, 5]),
+                            dict(id="u2", mixed_sig=torch.randn(40), enroll_sig=torch.randn(15), tokens=[7])])
+    assert batch.mixed_sig.data.shape == (2, 50) and batch.mixed_sig.lengths.tolist() == pytest.approx([1.0, 0.8])
+    assert batch.tokens_bos.data.tolist() == [[0, 3, 4, 5], [0, 7, 0, 0]] and batch.tokens_bos.lengths.tolist() == pytest.approx([1.0, 0.5])
+    assert batch.tokens.data.tolist() == [[3, 4, 5], [7, 0, 0]] and batch.id == ["u1", "u2"]
+
+
+def test_manifest_loader(tmp_path):
+    dataio = importlib.import_module("ts-asr_amd.dataio")
+    entry = {"utt1": {"wavs": ["{data_folder}/a.flac", "{data_folder}/b.flac"], "enroll_wav": "{data_folder}/e.flac", "delays": [0.0, 1.5],
+                      "start": 0.0, "duration": 10.0, "durations": [8.0, 8.5], "target_speaker_idx": 0, "wrd": "HELLO", "speakers": ["1", "2"],
+                      "genders": ["m", "f"]}}
+    p = tmp_path / "m.json"
+    p.write_text(__import__("json").dumps(entry))
+    d = dataio.load_manifest(str(p), {"data_folder": "/data"})
+    assert d["utt1"]["wavs"] == ["/data/a.flac", "/data/b.flac"] and d["utt1"]["enroll_wav"] == "/data/e.flac" and d["utt1"]["delays"] == [0.0, 1.5]

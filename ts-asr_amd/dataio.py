@@ -1,0 +1,169 @@
+"""Data side of the recipe: what turns a LibriSpeechMix manifest into the batches ``TSASR.fit_batch`` eats.
+
+Host logic only - nothing here is on the device hot path; a maintainer may equally keep the reference's own ``speechbrain.dataio``
+(pure CPU code) in front of the MI355X step. Mirrors:
+
+  * ``DynamicBatchSampler``  - speechbrain/dataio/sampler.py:306-702 (length-bucketed batches: log-normal bucket boundaries,
+    ``max_batch_length`` / boundary examples per bucket, batches emitted as buckets fill, then ordered). Batch compositions are
+    identical to the reference's for the same arguments (tests/golden/c1_sampler.npz).
+  * ``mix_sources`` / ``trim_enroll`` - the arithmetic of ``audio_pipeline`` (train_librispeechmix_scratch.py:338-386): per-speaker
+    gain against the target's power, delay padding, sum, crop. Works on CPU or GPU tensors. The reference's version is a closure
+    around torchaudio file reads, so it cannot be run here: this restatement is unpinned (plain tensor arithmetic, unit-tested
+    against hand-computed cases only).
+  * ``load_manifest`` - the JSON written by librispeechmix_prepare.py:206-218 ({id: {wavs, enroll_wav, delays, start, duration,
+    durations, target_speaker_idx, wrd, speakers, genders}}) with the ``{data_folder}`` replacement of DynamicItemDataset.from_json.
+  * ``collate`` - PaddedBatch of (mixed_sig, enroll_sig, tokens_bos, tokens) with relative lengths (speechbrain/dataio/batch.py:20-190).
+Audio decoding (FLAC) and the SentencePiece tokenizer stay with the caller.
+"""
+import json
+import math
+
+import numpy as np
+import torch
+from torch.utils.data import Sampler
+
+from .batch import PaddedBatch, PaddedData
+
+
+class DynamicBatchSampler(Sampler):
+    def __init__(self, dataset, max_batch_length, num_buckets=None, length_func=lambda x: x["duration"], shuffle=True,
+                 batch_ordering="random", max_batch_ex=None, bucket_boundaries=(), lengths_list=None, seed=42, epoch=0,
+                 drop_last=False, verbose=False):
+        self._dataset = dataset
+        if num_buckets is None and len(bucket_boundaries) == 0:
+            raise RuntimeError("Please specify either num_buckets or bucket boundaries.Check the docs, and/or the tutorial !")
+        if lengths_list is not None:
+            self._ex_lengths = [lengths_list[i] for i in range(len(lengths_list))]
+        else:
+            if not (hasattr(dataset, "data") and hasattr(dataset, "data_ids")):
+                raise NotImplementedError("Dataset should expose .data / .data_ids (DynamicItemDataset protocol) when using length function")
+            self._ex_lengths = [length_func(dataset.data[dataset.data_ids[i]]) for i in range(len(dataset))]
+        if len(bucket_boundaries) > 0:
+            if not all(x >= 0 for x in bucket_boundaries):
+                raise ValueError("All elements in bucket boundaries should be non-negative (>= 0).")
+            if len(set(bucket_boundaries)) != len(bucket_boundaries):
+                raise ValueError("Bucket_boundaries should not contain duplicates.")
+            if list(bucket_boundaries) != sorted(bucket_boundaries):
+                raise AssertionError("The arg bucket_boundaries should be an ascending sorted list of non negative values values!")
+            self._bucket_boundaries = np.array(sorted(bucket_boundaries))
+        else:
+            self._bucket_boundaries = np.array(self._warped_boundaries(max_batch_length, num_buckets))
+        self._max_batch_length, self._shuffle_ex, self._batch_ordering = max_batch_length, shuffle, batch_ordering
+        self._seed, self._drop_last, self._epoch, self.verbose = seed, drop_last, epoch, verbose
+        self._max_batch_ex = np.inf if max_batch_ex is None else max_batch_ex
+        self._bucket_lens = [max(1, int(max_batch_length / b)) for b in self._bucket_boundaries] + [1]
+        self._generate_batches()
+
+    @staticmethod
+    def _warped_boundaries(max_batch_length, num_quantiles):
+        """Right bucket edges = quantiles of a unit log-normal at k/(n+1), rescaled so that the last one is max_batch_length."""
+        from scipy.stats import lognorm
+        nb = num_quantiles + 1
+        q = lognorm.ppf(np.linspace(1 / nb, num_quantiles / nb, num_quantiles), 1)
+        return sorted(q * max_batch_length / q[-1])
+
+    def get_durations(self, batch):
+        return [self._ex_lengths[i] for i in batch]
+
+    def _generate_batches(self):
+        n = len(self._ex_lengths) if self._dataset is None else len(self._dataset)
+        if self._shuffle_ex:
+            g = torch.Generator()
+            g.manual_seed(self._seed + self._epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = range(n)
+        batches, open_ = [], [[] for _ in self._bucket_lens]
+        for idx in order:
+            b = int(np.searchsorted(self._bucket_boundaries, self._ex_lengths[idx]))
+            open_[b].append(idx)
+            if len(open_[b]) >= self._bucket_lens[b] or len(open_[b]) >= self._max_batch_ex:
+                batches.append(open_[b])
+                open_[b] = []
+        if not self._drop_last:
+            batches.extend(b for b in open_ if b)
+        longest = lambda batch: max(self._ex_lengths[i] for i in batch)  # noqa: E731
+        if self._batch_ordering == "random":
+            g = torch.Generator()
+            g.manual_seed(self._seed + self._epoch)
+            batches = [batches[i] for i in torch.randperm(len(batches), generator=g).tolist()]
+        elif self._batch_ordering == "ascending":
+            batches = sorted(batches, key=longest)
+        elif self._batch_ordering == "descending":
+            batches = sorted(batches, key=longest, reverse=True)
+        else:
+            raise NotImplementedError
+        self._batches = batches
+
+    def __iter__(self):
+        for batch in self._batches:
+            yield batch
+        if self._shuffle_ex:            # re-bucket with the next epoch's permutation
+            self._generate_batches()
+
+    def set_epoch(self, epoch):
+        self._epoch = epoch
+        self._generate_batches()
+
+    def __len__(self):
+        return len(self._batches)
+
+
+def load_manifest(json_path, replacements=None):
+    """{utterance id: entry} with ``{key}`` placeholders in string fields substituted (e.g. {"data_folder": "/data/LibriSpeechMix"})."""
+    with open(json_path) as f:
+        data = json.load(f)
+    if replacements:
+        def sub(v):
+            if isinstance(v, str):
+                for k, r in replacements.items():
+                    v = v.replace("{" + k + "}", r)
+                return v
+            if isinstance(v, list):
+                return [sub(x) for x in v]
+            if isinstance(v, dict):
+                return {k: sub(x) for k, x in v.items()}
+            return v
+        data = sub(data)
+    return data
+
+
+def mix_sources(sigs, delays, start, duration, target_speaker_idx, sample_rate=16000, gain_nontarget=0):
+    """The mixture of train_librispeechmix_scratch.py:356-386: every non-target source is rescaled so that its mean power is
+    10^(gain_nontarget/10) times the target's (gain_nontarget == 0: sources are summed as they are), each source is shifted right by
+    ceil(delay * sample_rate) samples, all are zero-padded to the longest and summed, and the window
+    [ceil(start * sr), ceil(start * sr) + ceil(duration * sr)) is returned."""
+    sigs = [s.clone() for s in sigs]
+    out = []
+    for i, (sig, delay) in enumerate(zip(sigs, delays)):
+        if i != target_speaker_idx and gain_nontarget != 0:
+            target_power = (sigs[target_speaker_idx] ** 2).mean()
+            gain = (10 ** (gain_nontarget / 10) * target_power / (sig ** 2).mean()).sqrt()
+            sig = sig * gain
+        out.append(torch.nn.functional.pad(sig, [math.ceil(delay * sample_rate), 0]))
+    n = max(len(x) for x in out)
+    mixed = torch.stack([torch.nn.functional.pad(x, [0, n - len(x)]) for x in out]).sum(0)
+    a = math.ceil(start * sample_rate)
+    return mixed[a:a + math.ceil(duration * sample_rate)]
+
+
+def trim_enroll(enroll_sig, trim_enroll_seconds, sample_rate=16000):
+    return enroll_sig[: math.ceil(trim_enroll_seconds * sample_rate)]
+
+
+def collate(examples, blank_index=0):
+    """examples: dicts with id, mixed_sig [L], enroll_sig [Le], tokens (list / 1-D int tensor) -> the PaddedBatch TSASR.fit_batch takes
+    (tokens_bos = [blank] + tokens, relative lengths = len / max len, as speechbrain.dataio.batch.PaddedBatch)."""
+    def pad(seqs, dtype=None):
+        seqs = [torch.as_tensor(s) if dtype is None else torch.as_tensor(s, dtype=dtype) for s in seqs]
+        n = max(int(s.shape[0]) for s in seqs)
+        data = torch.stack([torch.nn.functional.pad(s, [0, n - s.shape[0]]) for s in seqs])
+        return PaddedData(data, torch.tensor([s.shape[0] / n for s in seqs], dtype=torch.float32))
+    toks = [torch.as_tensor(e["tokens"], dtype=torch.long) for e in examples]
+    return PaddedBatch({
+        "id": [e["id"] for e in examples],
+        "mixed_sig": pad([e["mixed_sig"] for e in examples]),
+        "enroll_sig": pad([e["enroll_sig"] for e in examples]),
+        "tokens_bos": pad([torch.cat([torch.tensor([blank_index]), t]) for t in toks]),
+        "tokens": pad(toks),
+    })
