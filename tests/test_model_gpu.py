@@ -245,3 +245,28 @@ def test_training_step_with_augmentation_on():
         a, _ = brain.compute_forward(batch, Stage.VALID)
         b, _ = brain.compute_forward(batch, Stage.VALID)
     assert torch.equal(a, b)                                    # evaluation is never augmented
+
+
+def test_hip_graph_cache_per_batch_shape():
+    """Length-bucketed training: two batch shapes alternate; each gets its own captured graph (shared memory pool) after one eager
+    step, and the losses equal the all-eager run bit for bit."""
+    inp = golden_inputs()
+    short = {k: (v[:, : v.shape[1] * 3 // 4] if k in ("mixed_sig", "enroll_sig") else v) for k, v in inp.items()}
+    losses = {}
+    for mode in ("eager", "graph"):
+        brain, h = entry._config1_brain(DEV, "bf16")
+        brain.modules.train()
+        if mode == "graph":
+            brain.enable_hip_graph(warmup_steps=2)
+        batches = [make_batch(inp).to(DEV), make_batch(short).to(DEV)]
+        ls = [float(brain.fit_batch(batches[i % 2])) for i in range(12)]
+        losses[mode] = ls
+        if mode == "graph":
+            assert len(brain._graphs) == 2 and len(brain._static_batches) == 2
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)
+    # beyond the cap a new shape simply runs eagerly
+    brain._graph_max_shapes = 2
+    tiny = {k: (v[:, : v.shape[1] // 2] if k in ("mixed_sig", "enroll_sig") else v) for k, v in inp.items()}
+    for _ in range(3):
+        assert np.isfinite(float(brain.fit_batch(make_batch(tiny).to(DEV))))
+    assert len(brain._graphs) == 2

@@ -151,7 +151,8 @@ class Brain:
         self.optimizer = None
         self.arena = None
         self._graph_mode, self._graph, self._graph_warmup, self._eager_steps = False, None, 3, 0
-        self._static_batch, self._static_loss, self._graphs, self._graph_pool, self._eager_stepped = None, {}, {}, None, False
+        self._static_batches, self._static_loss, self._graphs, self._graph_pool, self._eager_stepped = {}, {}, {}, None, False
+        self._graph_max_shapes, self._seen_shapes = 24, set()
         self._aux_streams = []
         self.rank = int(os.environ.get("RANK", 0))
         self.distributed = bool(self.distributed_launch) and _dp.is_initialized()
@@ -252,16 +253,32 @@ class Brain:
         return loss.detach(), outputs
 
     # ---- hipGraph replay of the whole step (HIP streams and graphs instead of a tracing compiler) -----------------
-    def enable_hip_graph(self, warmup_steps=3):
-        """After ``warmup_steps`` eager steps (allocator warm, arena laid out in backward order) the step is captured once and
-        replayed: ~3000 launches collapse into one graph launch. Needs fixed batch shapes; with more than one rank the
-        gradient all-reduce runs between two graphs (forward+backward | optimizer)."""
-        self._graph_mode, self._graph_warmup = True, int(warmup_steps)
+    def enable_hip_graph(self, warmup_steps=3, max_shapes=24):
+        """After ``warmup_steps`` eager steps (allocator warm, arena laid out in backward order) the step is captured and replayed:
+        ~1000 launches collapse into one graph launch. One graph per distinct set of batch tensor shapes (and per flavour, see
+        _fit_batch_graph), up to ``max_shapes`` shapes: with length-bucketed batches padded to the bucket edge
+        (dataio.DynamicBatchSampler) a real epoch replays a handful of graphs; all graphs share one memory pool (they never run
+        concurrently). A shape beyond the cap runs eagerly. With more than one rank the gradient all-reduce runs between two
+        graphs (forward+backward | optimizer)."""
+        self._graph_mode, self._graph_warmup, self._graph_max_shapes = True, int(warmup_steps), int(max_shapes)
+
+    @staticmethod
+    def _shape_key(batch):
+        key = []
+        for k in batch._keys:
+            v = getattr(batch, k)
+            if isinstance(v, tuple):
+                key.append((k,) + tuple(tuple(t.shape) for t in v))
+        return tuple(key)
 
     def _fit_batch_graph(self, batch, should_step=True):
-        """Two graphs at most: the micro-step that only accumulates gradients and the one that also clips / steps / clears
+        """Two flavours per batch shape: the micro-step that only accumulates gradients and the one that also clips / steps / clears
         (gradient accumulation: grad_accumulation_factor - 1 replays of the first, one of the second)."""
-        if self._eager_steps < self._graph_warmup or not self._eager_stepped:
+        key = self._shape_key(batch)
+        full = key not in self._static_batches and len(self._static_batches) >= self._graph_max_shapes
+        first = key not in self._seen_shapes      # a new shape runs eagerly once: per-shape caches (positional tables, ...) must be
+        self._seen_shapes.add(key)                # filled outside a capture, where their memory would belong to the graph pool
+        if self._eager_steps < self._graph_warmup or not self._eager_stepped or full or first:
             # eager until the allocator is warm AND one optimizer step has run: the arena re-lays itself out in backward order when
             # the gradients are first cleared, which must not happen inside a capture
             self._eager_steps += 1
@@ -271,13 +288,13 @@ class Brain:
                 self.optimizer_step += 1
                 self._eager_stepped = True
             return loss
-        flavour = "step" if should_step else "accumulate"
+        flavour = ("step" if should_step else "accumulate", key)
         if should_step:
             self.optimizer.prepare()            # host half (step count, lr -> device); also allocates its buffers before a capture
         if flavour not in self._graphs:
-            self._capture(batch, should_step)
+            self._capture(batch, should_step, key)
         else:
-            self._copy_batch(batch)
+            self._copy_batch(batch, key)
         self._graphs[flavour].replay()
         if should_step:
             if self.distributed:                # one big averaged all-reduce between the two halves of the step
@@ -287,30 +304,29 @@ class Brain:
             self.optimizer_step += 1
         return self._static_loss[flavour]
 
-    def _capture(self, batch, should_step=True):
-        if self._static_batch is None:
-            self._static_batch = batch.to(self.device)
+    def _capture(self, batch, should_step, key):
+        if key not in self._static_batches:
+            self._static_batches[key] = batch.to(self.device)
         else:
-            self._copy_batch(batch)
+            self._copy_batch(batch, key)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool):
-            loss, _ = self._device_step(self._static_batch, should_step, comm=False)
+            loss, _ = self._device_step(self._static_batches[key], should_step, comm=False)
         if self._graph_pool is None:
             self._graph_pool = g.pool()
-        flavour = "step" if should_step else "accumulate"
+        flavour = ("step" if should_step else "accumulate", key)
         self._graphs[flavour], self._static_loss[flavour] = g, loss
         self._graph = g
 
-    def _copy_batch(self, batch):
-        if batch is self._static_batch:
+    def _copy_batch(self, batch, key):
+        static = self._static_batches[key]
+        if batch is static:
             return
-        for k in self._static_batch._keys:
-            dst, src = getattr(self._static_batch, k), getattr(batch, k)
+        for k in static._keys:
+            dst, src = getattr(static, k), getattr(batch, k)
             if isinstance(dst, tuple):
                 for d, s_ in zip(dst, src):
-                    if d.shape != s_.shape:
-                        raise ValueError("hip-graph mode needs fixed batch shapes; call with enable_hip_graph off for ragged batches")
                     d.copy_(s_, non_blocking=True)
 
     def check_gradients(self, loss):

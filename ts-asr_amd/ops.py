@@ -67,7 +67,7 @@ def _keep(*tensors):
         _DEFER["keep"].extend(t for t in tensors if t is not None)
 
 
-_TABLE_PAIRS = 16   # slot 0: eager flushes; slots 1.. : one per captured graph of this process (a replayed memcpy node re-reads ITS host table)
+_TABLE_PAIRS = 64   # slot 0: eager flushes; slots 1.. : one per captured graph of this process (a replayed memcpy node re-reads ITS host table)
 
 
 def reduce_defer_prepare(device):
