@@ -311,7 +311,10 @@ class Brain:
             self._copy_batch(batch, key)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool):
+        # multi-rank: the RCCL watchdog thread polls events while this thread captures; "thread_local" keeps its (legal) calls from
+        # invalidating the capture (single rank keeps the strict default)
+        mode = "thread_local" if self.distributed else "global"
+        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
             loss, _ = self._device_step(self._static_batches[key], should_step, comm=False)
         if self._graph_pool is None:
             self._graph_pool = g.pool()
