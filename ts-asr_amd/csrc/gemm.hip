@@ -18,6 +18,8 @@
 // (register staging, one barrier per k-tile), LDS rows padded by 16 B (conflict-free 16-byte fragment reads).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 #define GB_K 64
@@ -605,7 +607,8 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
     p.tile = t0 >= thr0 ? 0 : (t1 >= thr1 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
-    if (out_f32 && tiles < 256 && K >= 1024) {
+    static const int min_k = getenv("TSASR_SPLIT_MINK") ? atoi(getenv("TSASR_SPLIT_MINK")) : 384;   // (1024 -> 384: the K = 2T'-1 weight gradients of linear_pos ran on 16 workgroups; -0.12 ms per step)
+    if (out_f32 && tiles < 256 && K >= min_k) {
         // weight gradients: few output tiles, long inner dimension -> split it (fp32 slabs, reduced in fixed order). Both operands
         // are k-major, i.e. every fragment comes through ds_read_b64_tr_b16, and that path - not the DMA, not VALU, not MFMA - is
         // what bounds these kernels (the same tiles read with ds_read_b128, wrong results, run in 21.5 us instead of 30.1 us).
@@ -614,7 +617,7 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
         // 512 -> 17.65, 640 / 768 -> 17.4, 896 -> 17.85, 1024 -> 17.8 (more slabs = more bytes for the batched reduction).
         static const int target = getenv("TSASR_WGRAD_WGS") ? atoi(getenv("TSASR_WGRAD_WGS")) : 768;
         int s = (int)((target + tiles - 1) / tiles);
-        const int max_s = K / 256;             // at least 4 k-tiles per split
+        const int max_s = std::max(1, K / (min_k >= 1024 ? 256 : 128));             // at least 4 (2 for short K) k-tiles per split
         if (s > max_s) s = max_s;
         if (s > 32) s = 32;
         if (s < 1) s = 1;
