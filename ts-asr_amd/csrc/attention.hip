@@ -22,6 +22,8 @@
 //   * V is consumed through ds_read_b64_tr_b16 (hardware transpose read) so that it can be staged row-major/coalesced.
 // qkv layout: [B, T, H, 3*Dh] with Q|K|V interleaved per head (attention.py:549-553); pk: [2T-1, H*Dh];
 // pos_bias_u/v: the (Dh, H) parameter's storage reinterpreted as [H, Dh] (a view, not a transpose; attention.py:586-592).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -778,7 +780,8 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * AT_NW * 128 * sizeof(float), 256); }
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
 static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
-    const int want = std::max(1, 1024 / (4 * cdiv(2 * T - 1, 64)));
+    static const int dpk_wgs = getenv("TSASR_DPK_WGS") ? atoi(getenv("TSASR_DPK_WGS")) : 1024;
+    const int want = std::max(1, dpk_wgs / (4 * cdiv(2 * T - 1, 64)));
     return std::max(1, cdiv(B, std::min(B, want)));
 }
 static size_t attn_qv_bytes(int B, int T, int H) { return align_up((size_t)B * T * H * AT_DP * sizeof(float), 256); }

@@ -990,7 +990,8 @@ static int layernorm_bwd_impl(const void *dy, const void *x, const float *gamma,
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_layernorm_bwd_workspace_bytes(M, D), "tsasr_layernorm_bwd: workspace too small");
     int rpw = pick_rows_per_wg(M, 8);
     const bool wide = D > 4 * 64 * (io_dtype == TSASR_BF16 ? 8 : 4);
-    if (wide) rpw = (int)std::max<long long>(rpw, (M + 511) / 512);   // wide-row kernel: two workgroups per CU, each prefetching its next row
+    static const long long wide_wgs = getenv("TSASR_LNW_WGS") ? atoll(getenv("TSASR_LNW_WGS")) : 512;
+    if (wide) rpw = (int)std::max<long long>(rpw, (M + wide_wgs - 1) / wide_wgs);   // wide-row kernel: two workgroups per CU, each prefetching its next row
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
