@@ -274,15 +274,16 @@ class GradArena:
             self._order_final, self._reorder_pending, self._order_seen = True, False, []
 
     def allreduce_all(self):
-        """Average the whole arena over the ranks in bucket-sized collectives (graph mode: between the two captured halves)."""
+        """Average the whole arena over the ranks (graph mode: between the captured step and the optimizer)."""
         if self.world_size <= 1:
             return
+        # nothing can overlap here (the captured step has finished, the optimizer needs every gradient): ONE collective over the whole
+        # contiguous arena (204 MB fp32) instead of one per bucket - a ring all-reduce is bandwidth-bound per link, the per-call
+        # latency is paid once
         nccl = dist.get_backend(self.group) == "nccl"
-        for b in self.buckets:
-            chunk = self.grads[b["lo"]:b["hi"]]
-            dist.all_reduce(chunk, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
-            if not nccl:
-                chunk.div_(self.world_size)
+        dist.all_reduce(self.grads, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
+        if not nccl:
+            self.grads.div_(self.world_size)
 
     def grad_norm(self):
         return torch.linalg.vector_norm(self.grads)
