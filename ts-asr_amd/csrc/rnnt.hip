@@ -21,6 +21,10 @@
 //       Y: workgroup (b, 8 frames) walks u-tiles -> denc.  No float atomics anywhere => bitwise reproducible.
 #include <type_traits>
 
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 
 #define NEG_INF (-INFINITY)
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
     const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
     const float *__restrict__ W, T *__restrict__ ddec, float *__restrict__ slab_w /*[B*nut][32][J]*/,
     float *__restrict__ slab_b /*[B*nut][32]*/, const int32_t *__restrict__ tlen, const int32_t *__restrict__ ulen,
-    int Tn, int U1, int J, int V, int ldl, float slope) {
+    int Tn, int U1, int J, int V, int ldl, float slope, float *__restrict__ denc_part /*[nut][B][T][J] or NULL*/) {
     __shared__ __attribute__((aligned(16))) bf16_t a_lds[4][32 * 32];  // per-wave dlogits tile [u][v]
     const int b = blockIdx.z, ut = blockIdx.x, u0 = ut * 32, nut = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -297,15 +301,28 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f.wf[i][0], D, 0, 0, 0);
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
             bf16x8 hb[2];
+            float esum = 0.f;   // sum of dh over this tile's 16 u rows of the lane: the tile's share of denc[b, t, k]
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float x = e + dv[i][g];
-                dacc[i][g] += (x > 0.f) ? D[g] : slope * D[g];
+                const float dh = (x > 0.f) ? D[g] : slope * D[g];
+                dacc[i][g] += dh;
+                esum += dh;
                 hb[g >> 3][g & 7] = (bf16_t)lrelu(x, slope);
+            }
+            if (denc_part) {    // dh is in registers here anyway: the separate denc pass recomputed every one of these tiles
+                esum += __shfl_xor(esum, 32, 64);
+                if (h == 0) denc_part[(((size_t)ut * gridDim.z + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
             }
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], hb[0], wacc[i], 0, 0, 0);
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], hb[1], wacc[i], 0, 0, 0);
         }
+    }
+    if (denc_part && h == 0) {   // frames this tile never visited (beyond the utterance, or the tile lies outside the lattice)
+        for (int t = t_end; t < Tn; ++t)
+#pragma unroll
+            for (int i = 0; i < KB; ++i)
+                if (f.kb[i] >= 0) denc_part[(((size_t)ut * gridDim.z + b) * Tn + t) * J + f.kb[i] * 32 + r] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
@@ -753,10 +770,27 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
     return 0;
 }
 
+}  // extern "C"
+
+// denc[e] = sum over the u tiles of part[tile][e] (fixed order), four elements per thread, written in the io dtype
+template <typename T>
+__global__ __launch_bounds__(256) void denc_sum_kernel(const float *__restrict__ part, T *__restrict__ denc, long long n, int nparts) {
+    for (long long e = (blockIdx.x * 256LL + threadIdx.x) * 4; e < n; e += (long long)gridDim.x * 256 * 4) {
+        float4 s = *reinterpret_cast<const float4 *>(part + e);
+        for (int p = 1; p < nparts; ++p) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (long long)p * n + e);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        st1(denc + e, s.x); st1(denc + e + 1, s.y); st1(denc + e + 2, s.z); st1(denc + e + 3, s.w);
+    }
+}
+
+extern "C" {
+
 size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J) {
-    (void)T;
     const size_t nslab = (size_t)B * cdiv(U1, 32);
-    return align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256);
+    return align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256) +
+           align_up(nslab * T * J * sizeof(float), 256);      // denc partial sums per u tile
 }
 
 int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, const float *W, void *denc, void *ddec,
@@ -774,12 +808,19 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     float *slab_b = (float *)((char *)workspace + align_up(nslab * 32 * J * sizeof(float), 256));
     hipStream_t st = (hipStream_t)stream;
     dim3 gx(nut, ksplit, B), gy(cdiv(T, TG), ksplit, B);
+    // one pass: the kernel that forms dh tile by tile for ddec / dW also leaves each tile's column sums (its share of denc); a small
+    // kernel adds the cdiv(U1, 32) shares. TSASR_JOINT_TWO_PASS=1 brings the separate denc kernel back (A/B: it recomputes every tile).
+    static const bool two_pass = getenv("TSASR_JOINT_TWO_PASS") && atoi(getenv("TSASR_JOINT_TWO_PASS")) != 0;
+    float *part = two_pass ? nullptr : (float *)((char *)workspace + align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256));
+    const long long n_enc = (long long)B * T * J;
     if (io_dtype == TSASR_F32) {
-        joint_bwd_x_kernel<float><<<gx, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope);
-        joint_bwd_y_kernel<float><<<gy, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+        joint_bwd_x_kernel<float><<<gx, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part);
+        if (two_pass) joint_bwd_y_kernel<float><<<gy, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+        else denc_sum_kernel<float><<<(unsigned)std::min<long long>(4096, (n_enc / 4 + 255) / 256), 256, 0, st>>>(part, (float *)denc, n_enc, nut);
     } else if (io_dtype == TSASR_BF16) {
-        joint_bwd_x_kernel<bf16_t><<<gx, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope);
-        joint_bwd_y_kernel<bf16_t><<<gy, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+        joint_bwd_x_kernel<bf16_t><<<gx, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part);
+        if (two_pass) joint_bwd_y_kernel<bf16_t><<<gy, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
+        else denc_sum_kernel<bf16_t><<<(unsigned)std::min<long long>(4096, (n_enc / 4 + 255) / 256), 256, 0, st>>>(part, (bf16_t *)denc, n_enc, nut);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_joint_bwd: bad io_dtype %d", io_dtype);
     }
