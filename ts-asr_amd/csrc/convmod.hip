@@ -70,14 +70,18 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T *__restrict
 #pragma unroll
     for (int k = 0; k < K; ++k) w[k] = cw[d * K + k];
     const float bias = cb[d];
-#pragma unroll 4
+    // this thread's 16 output frames read 16 + K - 1 consecutive GLU rows of ONE channel: fetched from LDS once into registers
+    // (46 reads) instead of once per tap (496 reads: the tap loops were LDS-issue bound)
+    float win[CV_FPT + K - 1];
+#pragma unroll
+    for (int j = 0; j < CV_FPT + K - 1; ++j) win[j] = g_lds[(fg * CV_FPT + j) * CV_CH + ch];
+#pragma unroll
     for (int s = 0; s < CV_FPT; ++s) {
-        const int tl = fg * CV_FPT + s, t = t0 + tl;
-        if (t >= Tn) break;
+        const int t = t0 + fg * CV_FPT + s;
         float acc = bias;
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc += w[k] * g_lds[(tl + k) * CV_CH + ch];
-        st1(c_out + ((size_t)b * Tn + t) * D + d, acc);
+        for (int k = 0; k < K; ++k) acc += w[k] * win[s + k];
+        if (t < Tn) st1(c_out + ((size_t)b * Tn + t) * D + d, acc);
     }
 }
 
@@ -132,19 +136,26 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict
             a_in[s] = ld1(p + d);
             g_in[s] = ld1(p + D + d);
         }
+        // register windows (see the forward kernel): GLU rows and dc rows [fg*16, fg*16 + 16 + K - 1) of this channel
+        float gw[CV_FPT + K - 1], dcw[CV_FPT + K - 1];
+#pragma unroll
+        for (int j = 0; j < CV_FPT + K - 1; ++j) {
+            gw[j] = g_lds[(fg * CV_FPT + j) * CV_CH + ch];
+            dcw[j] = dc_lds[(fg * CV_FPT + j) * CV_CH + ch];
+        }
 #pragma unroll
         for (int s = 0; s < CV_FPT; ++s) {
             const int tl = fg * CV_FPT + s, t = t0 + tl;
-            if (t < Tn) {
-                // dW[k] += dc[t] * g[t + k - pad_l] ; dconv_b += dc[t] ; dg[t] = sum_k w[k] * dc[t - k + pad_l]
-                const float dct = dc_lds[(own_off + tl) * CV_CH + ch];
-                dcb += dct;
-                float dg = 0.f;
+            // dW[k] += dc[t] * g[t + k - pad_l] ; dconv_b += dc[t] ; dg[t] = sum_k w[k] * dc[t - k + pad_l]
+            const float dct = t < Tn ? dc_lds[(own_off + tl) * CV_CH + ch] : 0.f;   // (own_off is a run-time row: one LDS read)
+            dcb += dct;
+            float dg = 0.f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    dw[k] += dct * g_lds[(tl + k) * CV_CH + ch];
-                    dg += w[k] * dc_lds[(tl + (K - 1) - k) * CV_CH + ch];
-                }
+            for (int k = 0; k < K; ++k) {
+                dw[k] += dct * gw[s + k];
+                dg += w[k] * dcw[s + (K - 1) - k];
+            }
+            if (t < Tn) {
                 const float a = a_in[s] + ba, sg = sigmoidf_fast(g_in[s] + bb);
                 const float da = dg * sg, db = dg * a * sg * (1.f - sg);
                 T *q = dy2 + ((size_t)b * Tn + t) * 2 * D;
