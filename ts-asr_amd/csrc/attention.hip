@@ -278,7 +278,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
                 mx = fmaxf(mx, x);
             }
             __builtin_amdgcn_wave_barrier();
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, other_half(mx));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
             float psum = 0.f;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
                 }
                 pb[g >> 3][g & 7] = (bf16_t)p;
             }
-            psum += __shfl_xor(psum, 32, 64);
+            psum += other_half(psum);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
                 delta += dd * oo;
             }
     }
-    delta += __shfl_xor(delta, 32, 64);
+    delta += other_half(delta);
     const float lse_i = lse[((long long)b * H + h) * Tn + iqc];
     f32x16 dqu[2], dqv[2];
     dqu[0] = dqu[1] = dqv[0] = dqv[1] = (f32x16){0};

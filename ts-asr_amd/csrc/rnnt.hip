@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
                 hb[g >> 3][g & 7] = (bf16_t)lrelu(x, slope);
             }
             if (denc_part) {    // dh is in registers here anyway: the separate denc pass recomputed every one of these tiles
-                esum += __shfl_xor(esum, 32, 64);
+                esum += other_half(esum);
                 if (h == 0) denc_part[(((size_t)ut * gridDim.z + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
             }
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], hb[0], wacc[i], 0, 0, 0);
