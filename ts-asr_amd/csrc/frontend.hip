@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
     // workgroup needs 4 x C*12 floats of LDS (12 KB at C = 64) instead of ppb x C*12 (96 KB = one workgroup per CU, every
     // loop iteration's memory round trip exposed) and many workgroups share a CU
     const int W = C * 12, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cgs = C / 8;
-    for (int off = cgs; off < 64; off <<= 1) {
+    for (int off = cgs; off < 32; off <<= 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -128,6 +128,15 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
             dw2[j] += __shfl_xor(dw2[j], off, 64);
             db2[j] += __shfl_xor(db2[j], off, 64);
         }
+    }
+    if (cgs <= 32)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // the last fold (lane ^ 32) is a v_permlane32_swap, not a trip through the LDS crossbar
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dw[j][k] += other_half(dw[j][k]);
+        db1[j] += other_half(db1[j]);
+        dw2[j] += other_half(dw2[j]);
+        db2[j] += other_half(db2[j]);
     }
     if (lane < cgs) {
         float *mine = red + wave * W;

@@ -539,8 +539,10 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
         if (c + 2 < V) m = fmaxf(m, x.z);
         if (c + 3 < V) m = fmaxf(m, x.w);
     }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // 8 lanes per lattice cell: reductions stay inside the 16-lane DPP rows (quad swaps, then the half-row mirror) - no LDS crossbar
+    m = fmaxf(m, dpp_mov<0xB1>(m));
+    m = fmaxf(m, dpp_mov<0x4E>(m));
+    m = fmaxf(m, dpp_mov<0x141>(m));
     float s = 0.f;
     for (int c = sub * 4; c < V; c += 32) {
         const float4 x = *reinterpret_cast<const float4 *>(rowp + c);
@@ -549,8 +551,9 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
         if (c + 2 < V) s += __expf(x.z - m);
         if (c + 3 < V) s += __expf(x.w - m);
     }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s += dpp_mov<0xB1>(s);
+    s += dpp_mov<0x4E>(s);
+    s += dpp_mov<0x141>(s);
     if (sub == 0) {
         const float lse = m + __logf(s);
         const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
