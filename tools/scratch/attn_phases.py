@@ -5,8 +5,10 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, root)
 import torch
 C = importlib.import_module("ts-asr_amd._capi")
-subprocess.check_call(f"cd {root}/ts-asr_amd/csrc && mkdir -p /tmp/atprof && for f in *.hip capi.cpp; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -DAT_PROFILE -x hip -c $f -o /tmp/atprof/$f.o || exit 1; done && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/atprof/libtsasr_hip.so /tmp/atprof/*.o", shell=True)
-C.LIB_PATH = "/tmp/atprof/libtsasr_hip.so"; C._lib = None
+PROF = os.path.join(root, "ts-asr_amd", "lib", "libtsasr_hip_prof.so")   # prebuilt with -DAT_PROFILE (see the Makefile-free recipe below)
+if not os.path.exists(PROF):
+    subprocess.check_call(f"cd {root}/ts-asr_amd/csrc && mkdir -p /tmp/atprof && for f in *.hip capi.cpp; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -DAT_PROFILE -x hip -c $f -o /tmp/atprof/$f.o || exit 1; done && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o {PROF} /tmp/atprof/*.o", shell=True)
+C.LIB_PATH = PROF; C._lib = None
 lib = C.lib()
 B, T, H, Dh = 32, 250, 4, 64
 D, R = H * Dh, 2 * T - 1
@@ -17,6 +19,17 @@ qkv, pk, dout = bf(B, T, 3 * D), bf(R, D), bf(B, T, D)
 u, v = (torch.randn(H * Dh, generator=g) * 0.1).to(dev), (torch.randn(H * Dh, generator=g) * 0.1).to(dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
 out, lse = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev), torch.empty(B, H, T, device=dev)
+for _ in range(2):
+    C.check(lib.tsasr_relpos_attn_fwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0,
+                                      None, C.BF16, C.stream_ptr()), "fwd")
+torch.cuda.synchronize()
+fst = lse.view(-1)[:12].view(torch.int64).cpu().tolist()
+fnames = ["prologue", "staging", "AC + G mfma, G store", "skew read / softmax / P", "P.V (last sub-block)", "epilogue"]
+ftot = sum(fst)
+print("fwd wave 1 of workgroup 0, cycles:")
+for n, c in zip(fnames, fst):
+    print(f"  {n:28s} {c:8d}  {100 * c / max(ftot, 1):5.1f}%")
+print(f"  total {ftot} = {ftot / 2.4e3:.1f} us at 2.4 GHz")
 C.check(lib.tsasr_relpos_attn_fwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0,
                                   None, C.BF16, C.stream_ptr()), "fwd")
 dqkv = torch.empty_like(qkv); dpk = torch.empty(R, D, dtype=torch.bfloat16, device=dev)

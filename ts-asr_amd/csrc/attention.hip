@@ -214,11 +214,18 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
     const bool pipe = (Dh % 8) == 0;   // 16-byte aligned row pieces: tiles are requested one iteration ahead (StagePieces)
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
+#ifdef AT_PROFILE
+    long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_prev = clock64();
+#define ATF_STAMP(i) do { const long long n_ = clock64(); facc[i] += n_ - ft_prev; ft_prev = n_; } while (0)
+#else
+#define ATF_STAMP(i)
+#endif
     if (pipe && j_end > 0) {
         sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
         sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
         sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
     }
+    ATF_STAMP(0);   // prologue
     for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
         __syncthreads();  // previous tile fully consumed
         if (pipe) {
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             stage_rows<T, AT_BAND>(p_lds, pk + (long long)h * Dh, D, j0 - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
         }
         __syncthreads();
+        ATF_STAMP(1);   // staging
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int jb = j0 + 32 * sub;
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
                 for (int g = 0; g < 16; ++g) g_lds[(32 * rb + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = g_acc[g];
             }
             __builtin_amdgcn_wave_barrier();
+            ATF_STAMP(2);   // AC + G MFMAs, G tile to LDS
             // ---- scores for this lane's query: 16 keys j = jb + (g&3) + 8(g>>2) + 4hh ; BD via the skewed read
             float sc[16];
             float mx = -INFINITY;
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) o_acc[db][g] *= alpha;
+            ATF_STAMP(3);   // skewed read, softmax update, P fragments, O rescale
             // ---- O^T += V^T . P^T ; A = V^T through the transposing LDS read
             const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 #pragma unroll
@@ -319,19 +329,31 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             }
         }
     }
+    ATF_STAMP(4);       // (P.V of the last sub-block; earlier ones are folded into phase 2 of the next)
     // ---- epilogue: out[b, iq, h*Dh + d] = O / l ; lse = m + log l
     if (iq < Tn) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         T *orow = out + ((long long)b * Tn + iq) * D + (long long)h * Dh;
+        // four consecutive head dims per store (the accumulator registers 4q .. 4q+3 of a lane are consecutive dims): 8 stores of
+        // 8 bytes instead of 32 of 2 - the 2-byte version was 17 % of the kernel, store-issue bound
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                if (d < Dh) st1(orow + d, o_acc[db][g] * inv);
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * db + 8 * q + 4 * hh;
+                if (d + 4 <= Dh && (Dh % 4) == 0)
+                    st4(orow + d, o_acc[db][4 * q] * inv, o_acc[db][4 * q + 1] * inv, o_acc[db][4 * q + 2] * inv, o_acc[db][4 * q + 3] * inv);
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (d + e < Dh) st1(orow + d + e, o_acc[db][4 * q + e] * inv);
             }
         if (hh == 0 && lse) lse[((long long)b * H + h) * Tn + iq] = m_run + __logf(l_run);
     }
+#ifdef AT_PROFILE
+    ATF_STAMP(5);       // epilogue
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64 && lse)
+        for (int i = 0; i < 6; ++i) reinterpret_cast<long long *>(lse)[i] = facc[i];   // (profile build: clobbers the first lse values)
+#endif
 }
 
 
@@ -552,7 +574,13 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
-            if (q_ok && d < Dh) st1(dq + d, dqu[db][g] + dqv[db][g]);
+            if ((g & 3) == 0 && q_ok) {   // four consecutive head dims per store
+                if (d + 4 <= Dh && (Dh % 4) == 0)
+                    st4(dq + d, dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (d + e < Dh) st1(dq + d + e, dqu[db][g + e] + dqv[db][g + e]);
+            }
             const float su = half_sum(q_ok ? dqu[db][g] : 0.f, hh), sv = half_sum(q_ok ? dqv[db][g] : 0.f, hh);
             if (r == 0) { slab[d] = su; slab[64 + d] = sv; }
         }
