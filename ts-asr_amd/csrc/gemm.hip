@@ -474,6 +474,123 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
     gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep, ty, tz);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient tile (both operands k-major, 64x64 output, fp32 out): the four waves split the K dimension INSIDE the k-tile
+// (wave w owns k16 step w) and each accumulates the whole 64x64 tile, instead of each owning one 32x32 block over all four steps.
+// Same MFMA count per wave, but a wave now reads 2 + 2 fragments for 4 MFMAs instead of 4 x (1 + 1): half the
+// ds_read_b64_tr_b16 traffic, which is what bounds these kernels. The four partial tiles are combined through LDS in a fixed
+// order ((w0 + w2) + (w1 + w3)) before the slab / accumulate store.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int OUT_MODE>
+__global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C,
+                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
+                                                                 long long slab_stride, int nsplit) {
+    using TA = RingTile<64, true>;
+    using TB = RingTile<64, true>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;
+    static_assert(GB_K / 16 == 4, "one k16 step per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty, tz;
+    tile_coords((N + 63) / 64, (M + 63) / 64, nsplit, tx, ty, tz);
+    const int m0 = ty * 64, n0 = tx * 64;
+    const int kbeg = tz * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / GB_K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
+    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
+    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    int a_off[2][TA::NFO], b_off[2][TB::NFO];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        TA::frag_offsets(32 * i, wave, lane, a_off[i]);
+        TB::frag_offsets(32 * i, wave, lane, b_off[i]);
+    }
+#pragma unroll
+    for (int t = 0; t < RING_STAGES - 1; ++t)
+        if (t < nk) {
+            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
+            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + RING_STAGES - 1 < nk) {
+            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
+            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
+            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
+        }
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = TA::frag_at(as, a_off[i]);
+            bfr[i] = TB::frag_at(bs, b_off[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // all fragment reads done before the partial tiles overwrite the ring
+    constexpr int LDT = 64 + 4;
+    static_assert(2 * 64 * LDT * 4 <= RING_STAGES * SLOT, "two fp32 tiles fit the ring");
+    float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 64 * LDT;
+    const int r = lane & 31, hh = lane >> 5;
+    float *mine = (wave & 1) ? t1 : t0;
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) mine[(32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r] = acc[i][j][g];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *q = mine + (32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r;
+                    *q = acc[i][j][g] + *q;
+                }
+    }
+    __syncthreads();
+    float *Cf = C + (OUT_MODE == 1 ? (long long)tz * slab_stride : 0);
+    const bool vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cf) & 15) == 0);
+    for (int c = threadIdx.x; c < 64 * 16; c += 256) {
+        const int rr = c >> 4, cc = (c & 15) * 4;
+        const int m = m0 + rr, n = n0 + cc;
+        if (m >= M || n >= N) continue;
+        float *dst = Cf + (long long)m * ldc + n;
+        const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc), vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc);
+        const float vv[4] = {va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
+        if (vec && n + 4 <= N) {
+            float4 o = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            if (OUT_MODE == 2) {
+                const float4 old = *reinterpret_cast<float4 *>(dst);
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *reinterpret_cast<float4 *>(dst) = o;
+        } else {
+            for (int e = 0; e < 4 && n + e < N; ++e) {
+                if (OUT_MODE == 2) dst[e] += vv[e];
+                else dst[e] = vv[e];
+            }
+        }
+    }
+}
+
 template <int BM, int BN, bool AT, bool BT>
 struct RingSmem {
     static constexpr size_t PIPE = (size_t)RING_STAGES * (RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES);
@@ -566,6 +683,15 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
     // for the smaller macro-tiles at any K (3 workgroups per CU); the register-staged loop wins for 128x128 at short K (K = 256)
     const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024 || BM * BN < 128 * 128) &&
                       (AT ? M >= 8 : true) && (BT ? N >= 8 : true);
+    if constexpr (BM == 64 && BN == 64 && AT && BT && OUT_MODE != 0) {
+        static const int wavek = getenv("TSASR_WGRAD_WAVEK") ? atoi(getenv("TSASR_WGRAD_WAVEK")) : 1;
+        if (ring && wavek) {
+            using R = RingSmem<64, 64, true, true>;
+            gemm_tt64_wavek_kernel<OUT_MODE><<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (float *)C, M, N, K, lda, ldb, ldc, kchunk,
+                                                                          slab_stride, splits);
+            return;
+        }
+    }
     if (ring) {
         using R = RingSmem<BM, BN, AT, BT>;
         auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE>;

@@ -17,17 +17,22 @@ struct ReduceJob {
     const float *src;     // partial rows: src[p * pstride + c]
     float *dst;           // dst[c] (+)= sum_p
     long long pstride;
-    int nparts, width, accumulate, tile0, wide, pad_;
+    int nparts, width, accumulate, tile0, wide, pad_;   // wide: 0 = tall job, n = wide job with n 1024-column pieces per tile
 };
 
 // tall jobs (many partial rows, few columns): tile = 64 columns (256-byte row pieces), 4 row slices per workgroup, combined through LDS
 // wide jobs (few slabs, many columns):        tile = 1024 columns, one thread = 4 consecutive columns, 16-byte slab loads
 #define RD_WIDE_TILE 1024
 #define RD_TALL_COLS 64
+static int wide_iters() {   // 1024-column pieces per wide tile (A/B knob; fewer, larger workgroups amortise the job lookup)
+    static const int it = getenv("TSASR_RD_WIDE_ITERS") ? atoi(getenv("TSASR_RD_WIDE_ITERS")) : 1;
+    return it < 1 ? 1 : it;
+}
 
 __device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*red)[RD_TALL_COLS + 1]) {
     if (j.wide) {
-        const int c = lt * RD_WIDE_TILE + threadIdx.x * 4;
+      for (int it = 0; it < j.wide; ++it) {
+        const int c = (lt * j.wide + it) * RD_WIDE_TILE + threadIdx.x * 4;
         if (c >= j.width) return;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         if (c + 4 <= j.width && ((reinterpret_cast<uintptr_t>(j.src) | (uintptr_t)(j.pstride * 4)) & 15) == 0) {
@@ -48,11 +53,22 @@ __device__ __forceinline__ void reduce_tile(const ReduceJob &j, int lt, float (*
             for (int p = 0; p < j.nparts; ++p)
                 for (int e = 0; e < 4 && c + e < j.width; ++e) s[e] += j.src[(long long)p * j.pstride + c + e];
         }
-        for (int e = 0; e < 4 && c + e < j.width; ++e) {
-            if (j.accumulate) j.dst[c + e] += s[e];
-            else j.dst[c + e] = s[e];
+        if (c + 4 <= j.width && (reinterpret_cast<uintptr_t>(j.dst) & 15) == 0) {
+            float4 *d = reinterpret_cast<float4 *>(j.dst + c);
+            float4 o = make_float4(s[0], s[1], s[2], s[3]);
+            if (j.accumulate) {
+                const float4 a = *d;
+                o.x = a.x + s[0]; o.y = a.y + s[1]; o.z = a.z + s[2]; o.w = a.w + s[3];
+            }
+            *d = o;
+        } else {
+            for (int e = 0; e < 4 && c + e < j.width; ++e) {
+                if (j.accumulate) j.dst[c + e] += s[e];
+                else j.dst[c + e] = s[e];
+            }
         }
-        return;
+      }
+      return;
     }
     const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6, col = lt * RD_TALL_COLS + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -80,14 +96,28 @@ __global__ __launch_bounds__(256) void reduce_one_kernel(ReduceJob job) {
     reduce_tile(job, blockIdx.x, red);
 }
 
-__global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__restrict__ jobs, int njobs, int bisect) {
     __shared__ float red[4][RD_TALL_COLS + 1];
-    int lo = 0, hi = njobs - 1;
-    const int bid = blockIdx.x;
-    while (lo < hi) {   // last job whose first tile <= bid (uniform per workgroup)
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+    // last job whose first tile <= bid (uniform per workgroup): 64-ary search, one lane per probe - two dependent loads for up
+    // to 4096 jobs instead of the ~9 of a bisection (the lookup latency, not the slab traffic, bounded this kernel)
+    const int bid = blockIdx.x, lane = threadIdx.x & 63;
+    int lo = 0, n = njobs;
+    if (bisect) {   // A/B only
+        int hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+        }
+        n = 1;
     }
+    while (n > 1) {
+        const int step = (n + 63) >> 6, idx = lo + lane * step;
+        const bool le = lane * step < n && jobs[idx].tile0 <= bid;   // monotone: a prefix of lanes (lane 0 always) says yes
+        const int seg = __popcll(__ballot(le)) - 1;
+        lo += seg * step;
+        n = min(step, n - seg * step);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
     const ReduceJob j = jobs[lo];
     reduce_tile(j, bid - j.tile0, red);
 }
@@ -95,14 +125,14 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__res
 static std::vector<ReduceJob> g_jobs;
 static int g_defer = 0, g_tiles = 0;
 
-static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE) : cdiv(j.width, RD_TALL_COLS); }
+static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE * j.wide) : cdiv(j.width, RD_TALL_COLS); }
 
 bool tsasr_reduce_deferring() { return g_defer != 0; }
 
 // dst[c] (+)= sum_{p < nparts} src[p * pstride + c], c < width: queued while deferral is on, else launched on `st`
 void tsasr_reduce_submit(const float *src, float *dst, long long pstride, int nparts, int width, int accumulate, hipStream_t st) {
     if (!dst || width <= 0 || nparts <= 0) return;
-    ReduceJob j{src, dst, pstride, nparts, width, accumulate, g_tiles, nparts < 32 && width >= 4096 ? 1 : 0, 0};
+    ReduceJob j{src, dst, pstride, nparts, width, accumulate, g_tiles, nparts < 32 && width >= 4096 ? wide_iters() : 0, 0};
     if (g_defer) {
         g_jobs.push_back(j);
         g_tiles += job_tiles(j);
@@ -142,7 +172,8 @@ int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, vo
         tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
         return TSASR_E_LAUNCH;
     }
-    reduce_many_kernel<<<g_tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)g_jobs.size());
+    static const int bisect = getenv("TSASR_RD_BISECT") ? atoi(getenv("TSASR_RD_BISECT")) : 0;
+    reduce_many_kernel<<<g_tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)g_jobs.size(), bisect);
     g_jobs.clear();
     g_tiles = 0;
     TSASR_CHECK_LAUNCH("tsasr_reduce_flush");
