@@ -160,9 +160,15 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
     if prof.ENABLED:  # label = the kernel template instantiation rocprofv3 will show (mirror of plan() in csrc/gemm.hip)
         t0, t1, t2 = ((M + 127) // 128) * ((N + 127) // 128), ((M + 127) // 128) * ((N + 63) // 64), ((M + 63) // 64) * ((N + 63) // 64)
         tiles, tile = (t0, "128, 128") if t0 >= 512 else ((t1, "128, 64") if t1 >= 192 else (t2, "64, 64"))
-        split = od == C.F32 and tiles < 256 and K >= 384 and min(32, max(1, K // 128), (768 + tiles - 1) // tiles) > 1
-        mode = 1 if (split or (od == C.F32 and not accumulate)) else (2 if accumulate else 0)
-        label = f"gemm_bf16_kernel<{tile}, {'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}, {mode}>"
+        nsplit = min(32, max(1, K // 128), (768 + tiles - 1) // tiles) if (od == C.F32 and tiles < 256 and K >= 384) else 1
+        kchunk = -(-(-(-K // nsplit)) // 64) * 64
+        mode = 1 if (nsplit > 1 or (od == C.F32 and not accumulate)) else (2 if accumulate else 0)
+        ring = K % 64 == 0 and (tile != "128, 128" or min(K, kchunk) >= 1024) and (M >= 8 or not trans_a) and (N >= 8 or not trans_b)
+        if ring and tile == "64, 64" and trans_a and trans_b and mode != 0:
+            label = f"gemm_tt64_wavek_kernel<{mode}>"
+        else:
+            label = (f"gemm_bf16_{'ring_' if ring else ''}kernel<{tile}, {'true' if trans_a else 'false'}, "
+                     f"{'true' if trans_b else 'false'}, {mode}>")
     else:
         label = "gemm"
     with prof.region(label, 2.0 * M * N * K):
