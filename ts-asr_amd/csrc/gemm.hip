@@ -591,6 +591,111 @@ __global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *_
     }
 }
 
+// The same wave-K split for the plain forward / data-gradient 64x64 tile (both operands k-contiguous, bf16 output): the main loops
+// of these kernels are bound by LDS bandwidth, not by MFMA or by the DMA latency (bytes through LDS per 32x32x16 MFMA: 2 KB of
+// fragment reads + 1 KB of DMA writes with one 32x32 block per wave; 1 + 1 KB with a 64x64 block per wave).
+__global__ __launch_bounds__(256, 2) void gemm_nn64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
+                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
+                                                                 long long slab_stride, int nsplit) {
+    using TA = RingTile<64, false>;
+    using TB = RingTile<64, false>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;
+    static_assert(GB_K / 16 == 4, "one k16 step per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty, tz;
+    tile_coords((N + 63) / 64, (M + 63) / 64, nsplit, tx, ty, tz);
+    const int m0 = ty * 64, n0 = tx * 64;
+    const int kbeg = tz * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / GB_K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
+    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
+    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    int a_off[2][TA::NFO], b_off[2][TB::NFO];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        TA::frag_offsets(32 * i, wave, lane, a_off[i]);
+        TB::frag_offsets(32 * i, wave, lane, b_off[i]);
+    }
+#pragma unroll
+    for (int t = 0; t < RING_STAGES - 1; ++t)
+        if (t < nk) {
+            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
+            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + RING_STAGES - 1 < nk) {
+            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
+            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
+            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
+        }
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = TA::frag_at(as, a_off[i]);
+            bfr[i] = TB::frag_at(bs, b_off[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // all fragment reads done before the partial tiles overwrite the ring
+    constexpr int LDT = 64 + 4;
+    static_assert(2 * 64 * LDT * 4 <= RING_STAGES * SLOT, "two fp32 tiles fit the ring");
+    float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 64 * LDT;
+    const int r = lane & 31, hh = lane >> 5;
+    float *mine = (wave & 1) ? t1 : t0;
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) mine[(32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r] = acc[i][j][g];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float *q = mine + (32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r;
+                    *q = acc[i][j][g] + *q;
+                }
+    }
+    __syncthreads();
+    const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    for (int c = threadIdx.x; c < 64 * 8; c += 256) {
+        const int rr = c >> 3, cc = (c & 7) * 8;
+        const int m = m0 + rr, n = n0 + cc;
+        if (m >= M || n >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e), vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc + e);
+            v[e] = va.x + vb.x; v[e + 1] = va.y + vb.y; v[e + 2] = va.z + vb.z; v[e + 3] = va.w + vb.w;
+        }
+        bf16_t *dst = C + (long long)m * ldc + n;
+        if (vec && n + 8 <= N) st8(dst, v);
+        else
+            for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
+    }
+}
+
 template <int BM, int BN, bool AT, bool BT>
 struct RingSmem {
     static constexpr size_t PIPE = (size_t)RING_STAGES * (RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES);
@@ -689,6 +794,15 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
             using R = RingSmem<64, 64, true, true>;
             gemm_tt64_wavek_kernel<OUT_MODE><<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (float *)C, M, N, K, lda, ldb, ldc, kchunk,
                                                                           slab_stride, splits);
+            return;
+        }
+    }
+    if constexpr (BM == 64 && BN == 64 && !AT && !BT && OUT_MODE == 0) {
+        static const int wavek = getenv("TSASR_NN_WAVEK") ? atoi(getenv("TSASR_NN_WAVEK")) : 1;
+        if (ring && wavek && ep.mode == 0 && min(K, kchunk) >= 16 * GB_K) {   // short K: the heavier epilogue costs more than the loop gains (5.4 -> 6.1 us at K = 256; 13.1 -> 11.2 us at M = 4000, K = 2048)
+            using R = RingSmem<64, 64, false, false>;
+            gemm_nn64_wavek_kernel<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, kchunk,
+                                                                slab_stride, splits);
             return;
         }
     }

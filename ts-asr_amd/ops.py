@@ -166,6 +166,8 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
         ring = K % 64 == 0 and (tile != "128, 128" or min(K, kchunk) >= 1024) and (M >= 8 or not trans_a) and (N >= 8 or not trans_b)
         if ring and tile == "64, 64" and trans_a and trans_b and mode != 0:
             label = f"gemm_tt64_wavek_kernel<{mode}>"
+        elif ring and tile == "64, 64" and not trans_a and not trans_b and mode == 0 and min(K, kchunk) >= 1024:
+            label = "gemm_nn64_wavek_kernel"
         else:
             label = (f"gemm_bf16_{'ring_' if ring else ''}kernel<{tile}, {'true' if trans_a else 'false'}, "
                      f"{'true' if trans_b else 'false'}, {mode}>")
@@ -350,9 +352,9 @@ def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
 
 
 class _LstmFn(torch.autograd.Function):
-    """Single-layer LSTM over [B,U,I] in bf16: input projection = library GEMM (K = 28 one-hot rows), recurrence = per-step
-    HIP GEMM (accumulate into the gate buffer) + HIP cell kernel; backward mirrors it; the two weight gradients are single
-    GEMMs over all (b,t). Every launch is graph-capturable."""
+    """Single-layer LSTM over [B,U,I] in bf16: input projection = HIP GEMM (the 28 embedding columns padded to 32, bias folded into the
+    padding), recurrence = one persistent HIP kernel per direction (H in {256, 512}; else per-step HIP GEMM + cell kernel); the
+    weight gradients are single HIP GEMMs over all (b,t). Every launch is graph-capturable."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
@@ -361,7 +363,20 @@ class _LstmFn(torch.autograd.Function):
         dev = x.device
         # x-part of the gate pre-activations, laid out [B,U,H,4] (gate-minor: the kernels move a unit's four gates as one float4)
         perm = lambda t: t.view(4, H, *t.shape[1:]).transpose(0, 1).reshape(t.shape)  # noqa: E731
-        gates = F.linear(x.float(), perm(w_ih.float()), perm((b_ih + b_hh).float())).contiguous()
+        # input projection on the HIP GEMM too: the inner dimension (28 embedding columns) is padded to a multiple of 8 and the bias
+        # rides in two of the padding columns (x = 1 there; the weight columns hold the bias split into a bf16 high and low part,
+        # i.e. ~16 mantissa bits, accumulated in fp32 by the MFMA) - no library GEMM, no fp32 copies of x and W_ih
+        Ip = (I + 2 + 7) // 8 * 8
+        xp = torch.zeros(B * U, Ip, dtype=torch.bfloat16, device=dev)
+        xp[:, :I] = x.reshape(B * U, I)
+        xp[:, I:I + 2] = 1.0
+        bias = perm((b_ih + b_hh).float())
+        b_hi = bias.to(torch.bfloat16)
+        wp = torch.zeros(4 * H, Ip, dtype=torch.bfloat16, device=dev)
+        wp[:, :I] = perm(w_ih)
+        wp[:, I] = b_hi
+        wp[:, I + 1] = bias - b_hi.float()
+        gates = gemm_bf16(xp, wp, B * U, 4 * H, Ip, Ip, Ip, 0, 0, out_dtype=torch.float32)
         c = torch.empty(B, U, H, dtype=torch.float32, device=dev)
         h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
         whh16 = _bf16_weight(w_hh).contiguous()
@@ -370,17 +385,19 @@ class _LstmFn(torch.autograd.Function):
         with prof.region("lstm_fwd"):   # the whole recurrence: one persistent launch (H in {256, 512}), else one fused launch per step
             C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh16), B, U, H, C.BF16, C.ptr(ws), ws.numel(), st),
                     "tsasr_lstm_seq_fwd")
-        ctx.save_for_backward(x, gates, c, h, whh16)
+        ctx.save_for_backward(xp, gates, c, h, whh16)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.in_shape = (B, U, I)
         return h
 
     @staticmethod
     def backward(ctx, dout):
-        x, gates, c, h, whh16 = ctx.saved_tensors
+        xp, gates, c, h, whh16 = ctx.saved_tensors
         w_ih, w_hh, b_ih, b_hh = ctx.params
-        B, U, I = x.shape
+        B, U, I = ctx.in_shape
+        Ip = xp.shape[1]
         H = w_hh.shape[1]
-        dev = x.device
+        dev = xp.device
         dout = dout.contiguous()
         dgates = torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=dev)
         whhT = _bf16_weight_t(w_hh)
@@ -395,10 +412,14 @@ class _LstmFn(torch.autograd.Function):
         h_prev = torch.zeros_like(h)
         h_prev[:, 1:] = h[:, :-1]
         dw_hh = gemm_bf16(dg2, h_prev.view(B * U, H), 4 * H, H, B * U, 4 * H, H, 1, 1, out_dtype=torch.float32)
-        dg32 = dg2.float()
-        dw_ih = dg32.t() @ x.reshape(B * U, I).float()
-        db = dg32.sum(0)
-        dx = (dg32 @ w_ih.float()).view(B, U, I).to(x.dtype) if ctx.needs_input_grad[0] else None
+        # dW_ih and the bias gradient in one GEMM against the padded input (its ones-column sums the gate gradients over b, t)
+        dwp = gemm_bf16(dg2, xp, 4 * H, Ip, B * U, 4 * H, Ip, 1, 1, out_dtype=torch.float32)
+        dw_ih, db = dwp[:, :I], dwp[:, I]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wq = torch.zeros(4 * H, Ip, dtype=torch.bfloat16, device=dev)
+            wq[:, :I] = w_ih
+            dx = gemm_bf16(dg2, wq, B * U, Ip, 4 * H, 4 * H, Ip, 0, 1)[:, :I].reshape(B, U, I)
         return dx, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db.to(b_ih.dtype), db.to(b_hh.dtype)
 
 
