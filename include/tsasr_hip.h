@@ -281,7 +281,9 @@ int tsasr_transpose_many_bf16(const void *src_base, void *dst_base, const void *
  * force the parameter-gradient outputs of the *_bwd entry points (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias)
  * and of tsasr_gemm_bf16(accumulate = 2) are only QUEUED: their workspaces and outputs must stay alive and untouched until
  * tsasr_reduce_flush runs all queued jobs in one launch (table_host: pinned host memory, table_dev: device memory, both at least
- * tsasr_reduce_table_bytes(tsasr_reduce_pending()) bytes; must outlive a captured graph). Replaces ~310 small launches per step. */
+ * tsasr_reduce_table_bytes(tsasr_reduce_pending()) bytes; must outlive a captured graph). While `stream` is being captured the flush
+ * fills table_host only: the caller copies it to table_dev once, after the capture has ended, so a replayed graph carries no memcpy
+ * node. Replaces ~310 small launches per step. */
 int tsasr_reduce_defer(int on);
 int tsasr_reduce_pending(void);
 size_t tsasr_reduce_table_bytes(int max_jobs);

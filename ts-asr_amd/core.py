@@ -316,6 +316,9 @@ class Brain:
         mode = "thread_local" if self.distributed else "global"
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
             loss, _ = self._device_step(self._static_batches[key], should_step, comm=False)
+        from . import ops as _ops
+        _ops.upload_captured_tables()             # job tables of the captured flushes: uploaded once, now (replays carry no memcpy node)
+        self.arena.upload_captured_tables()
         if self._graph_pool is None:
             self._graph_pool = g.pool()
         flavour = ("step" if should_step else "accumulate", key)

@@ -159,18 +159,25 @@ int tsasr_reduce_pending(void) { return (int)g_jobs.size(); }
 size_t tsasr_reduce_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof(ReduceJob); }
 
 /* Runs every queued reduction in ONE launch. table_host: PINNED host memory, table_dev: device memory, both `table_bytes` >=
- * tsasr_reduce_table_bytes(tsasr_reduce_pending()); the job table is copied host -> device on `stream` (a memcpy node under
- * graph capture - the buffers must outlive the graph). */
+ * tsasr_reduce_table_bytes(tsasr_reduce_pending()); the job table is copied host -> device on `stream` - except while `stream` is
+ * being captured: then only table_host is filled and the caller uploads it to table_dev after the capture (both must outlive the graph). */
 int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream) {
     if (g_jobs.empty()) return 0;
     const size_t need = g_jobs.size() * sizeof(ReduceJob);
     TSASR_CHECK_ARG(table_host && table_dev && table_bytes >= need, "tsasr_reduce_flush: job table too small (%zu < %zu bytes)", table_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     memcpy(table_host, g_jobs.data(), need);
-    hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) {
-        tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
-        return TSASR_E_LAUNCH;
+    // Under stream capture the table is NOT uploaded here: the caller copies table_host -> table_dev itself once the capture has
+    // ended (the pointers in it stay valid for the graph's lifetime, each captured graph owns its table pair), so a replay carries
+    // no memcpy node (ROCm 7.2 replays of captured memset / memcpy nodes have shown stale payloads).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone) {
+        hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
+            return TSASR_E_LAUNCH;
+        }
     }
     static const int bisect = getenv("TSASR_RD_BISECT") ? atoi(getenv("TSASR_RD_BISECT")) : 0;
     reduce_many_kernel<<<g_tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)g_jobs.size(), bisect);

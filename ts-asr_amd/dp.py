@@ -69,6 +69,7 @@ class GradArena:
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_host, self._defer_dev, self._defer_key = [], None, None, None, None
+        self._defer_upload = []
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -190,13 +191,21 @@ class GradArena:
         tab[n * 8:n * 16].view(np.uint64)[:] = [p.grad.data_ptr() for _, p in self._deferred]
         tab[n * 16:].view(np.int32)[:] = [g.numel() for g, _ in self._deferred]
         key = (k, tab.tobytes())
-        if key != self._defer_key or k > 0:     # same pointers as the last eager step: skip the upload
+        if k > 0:                               # captured: filled now, uploaded after the capture (upload_captured_tables) - no memcpy node
+            host[:n * 20].copy_(torch.from_numpy(tab))
+            self._defer_upload.append((k, n * 20))
+        elif key != self._defer_key:            # same pointers as the last eager step: skip the upload
             host[:n * 20].copy_(torch.from_numpy(tab))
             dev[:n * 20].copy_(host[:n * 20], non_blocking=True)
             self._defer_key = key
         C.check(C.lib().tsasr_accumulate_many(C.ptr(dev), n, C.stream_ptr()), "tsasr_accumulate_many")
         self._keepalive = self._deferred    # the temporaries must outlive the launch
         self._deferred = []
+
+    def upload_captured_tables(self):
+        for k, nb in self._defer_upload:
+            self._defer_dev[k][:nb].copy_(self._defer_host[k][:nb], non_blocking=True)
+        self._defer_upload = []
 
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):

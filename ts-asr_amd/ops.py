@@ -107,7 +107,17 @@ def reduce_flush():
         k = table_slot(_DEFER)
         C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
                 "tsasr_reduce_flush")
+        if k > 0:
+            _DEFER.setdefault("upload", []).append(k)   # captured: the table goes to the device after the capture (upload_captured_tables)
     _DEFER["keep"] = []
+
+
+def upload_captured_tables():
+    """After a stream capture: copy the job tables the captured flushes filled on the host to their device twins (a graph replay
+    carries no memcpy node; each captured graph owns its pair for life)."""
+    for k in _DEFER.get("upload", []):
+        _DEFER["dev"][k].copy_(_DEFER["host"][k], non_blocking=True)
+    _DEFER["upload"] = []
 
 
 def reduce_defer_end():
