@@ -399,7 +399,8 @@ def test_fused_clip_adamw_vs_torch():
     np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(8000, 2048, 256), (8000, 256, 2048), (250, 144, 144), (1000, 640, 256), (129, 72, 200), (2048, 256, 8000)])
+@pytest.mark.parametrize("M,N,K", [(8000, 2048, 256), (8000, 256, 2048), (250, 144, 144), (1000, 640, 256), (129, 72, 200), (2048, 256, 8000),
+                                   (4000, 256, 2048), (1000, 200, 1024)])   # the last two: 64x64 tiles at long K (wave-K main loops), ragged M / N
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_bf16_layouts(ops, M, N, K, ta, tb):
     """csrc/gemm.hip vs fp32 matmul of the same bf16 operands: every operand layout, ragged edges, split-K accumulate."""
