@@ -288,6 +288,9 @@ int tsasr_reduce_defer(int on);
 int tsasr_reduce_pending(void);
 size_t tsasr_reduce_table_bytes(int max_jobs);
 int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
+/* Only the jobs whose partial rows were produced on `stream` (complete in its order): the main stream reduces its share while a
+ * forked stream still runs its part of backward; the rest goes with the final tsasr_reduce_flush. Needs its own table pair. */
+int tsasr_reduce_flush_stream(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 
 /* SpecAugment on the normalised features (speechbrain/lobes/augment.py:32-201, applied at train_librispeechmix_scratch.py:91-94;
  * recipe settings conformer-t_scratch.yaml:132-142). tsasr_specaug_draw produces every random number of one call on the device

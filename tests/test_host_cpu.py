@@ -284,3 +284,30 @@ def test_manifest_loader(tmp_path):
     p.write_text(__import__("json").dumps(entry))
     d = dataio.load_manifest(str(p), {"data_folder": "/data"})
     assert d["utt1"]["wavs"] == ["/data/a.flac", "/data/b.flac"] and d["utt1"]["enroll_wav"] == "/data/e.flac" and d["utt1"]["delays"] == [0.0, 1.5]
+
+
+def test_no_swapped_opsel_packed_fp32_in_device_code(tmp_path):
+    """Device-code lint. `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (a packed fp32 op with swapped source halves) gave
+    run-to-run different low bits on gfx950 whenever a second hardware queue had kernels in flight (round 1: the conv-1 bias
+    gradient of the front-end under hipGraph replay with the forked speaker branch; csrc/frontend.hip). No kernel of the library may
+    contain that instruction form: the check disassembles every gfx950 code object of the built library."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "ts-asr_amd", "lib", "libtsasr_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        pytest.skip("needs the built library and llvm-objdump")
+    work = shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(work)], cwd=tmp_path, check=True, capture_output=True)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950*"))
+    assert objs, "no gfx950 code objects found in the library"
+    bad = re.compile(r"v_pk_\w+_f32.*op_sel:\[0,1\] op_sel_hi:\[1,0\]")
+    n_pk = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        n_pk += len(re.findall(r"v_pk_\w+_f32", asm))
+        hits = [l.strip() for l in asm.splitlines() if bad.search(l)]
+        assert not hits, f"{os.path.basename(o)}: {hits[:3]}"
+    assert n_pk > 0   # the disassembly really saw packed fp32 code

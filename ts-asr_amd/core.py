@@ -28,6 +28,8 @@ from . import optim as _optim
 logger = logging.getLogger(__name__)
 
 
+_EARLY_FLUSH = os.environ.get("TSASR_EARLY_FLUSH", "1") != "0"   # A/B knob
+
 class Stage(enum.Enum):
     TRAIN = enum.auto()
     VALID = enum.auto()
@@ -242,7 +244,9 @@ class Brain:
         # Streams the recipe forked in forward also ran their share of backward. autograd joins only the streams its LEAF
         # (AccumulateGrad) nodes ran on - and most parameter gradients here bypass those nodes (GEMMs accumulate straight into
         # the arena, small gradients are queued for one batched add) - so join explicitly before anything reads the gradients.
-        for s in self._aux_streams:
+        if self._aux_streams and _EARLY_FLUSH and torch.device(self.device).type == "cuda":
+            _ops.reduce_flush_own_stream()    # this stream's split-K slabs / partial rows (2/3 of them) are reduced while the forked
+        for s in self._aux_streams:           # stream is still in the speaker branch's backward (half-filled grids)
             torch.cuda.current_stream().wait_stream(s)
         self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
         if should_step and (comm or not self.distributed):

@@ -89,6 +89,13 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
         db1[j] = dw2[j] = db2[j] = 0.f;
     }
     const long long P = (long long)B * To * Fo;
+    // The bias sums go through the same packed FMA form as the filter taps (x 1.0, opaque to the compiler). Written as plain adds
+    // they compiled to v_pk_add_f32 with swapped op_sel halves (op_sel:[0,1] op_sel_hi:[1,0]) - the only such instruction in the
+    // library - and exactly those sums (even channels of db1) came out different in the low bits from run to run whenever a second
+    // hardware queue had kernels in flight (hipGraph replay with the forked speaker branch): an instruction-timing hazard, not a
+    // data race (found by hashing every parameter gradient of identical replays, tools/scratch/grad_det.py).
+    float one = 1.f;
+    asm volatile("" : "+v"(one));
     for (long long p = (long long)blockIdx.x * ppb + pl; p < P; p += (long long)gridDim.x * ppb) {
         const int fo = p % Fo, to = (p / Fo) % To, b = p / ((long long)Fo * To);
         float a[9];
@@ -110,9 +117,9 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) dw[j][k] += g1[j] * a[k];
-            db1[j] += g1[j];
+            db1[j] = __builtin_fmaf(g1[j], one, db1[j]);   // (see `one` above)
             dw2[j] += g2[j] * centre;
-            db2[j] += g2[j];
+            db2[j] = __builtin_fmaf(g2[j], one, db2[j]);
         }
     }
     // lanes of a wave that share a channel group differ in the position bits: fold them with xor-shuffles first, so that the

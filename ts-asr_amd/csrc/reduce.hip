@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(const ReduceJob *__res
 }
 
 static std::vector<ReduceJob> g_jobs;
+static std::vector<hipStream_t> g_job_streams;   // the stream each queued job's partial rows are produced on
 static int g_defer = 0, g_tiles = 0;
 
 static int job_tiles(const ReduceJob &j) { return j.wide ? cdiv(j.width, RD_WIDE_TILE * j.wide) : cdiv(j.width, RD_TALL_COLS); }
@@ -135,12 +136,48 @@ void tsasr_reduce_submit(const float *src, float *dst, long long pstride, int np
     ReduceJob j{src, dst, pstride, nparts, width, accumulate, g_tiles, nparts < 32 && width >= 4096 ? wide_iters() : 0, 0};
     if (g_defer) {
         g_jobs.push_back(j);
+        g_job_streams.push_back(st);
         g_tiles += job_tiles(j);
         return;
     }
     j.tile0 = 0;
     reduce_one_kernel<<<job_tiles(j), 256, 0, st>>>(j);
 }
+
+static int reduce_flush_impl(void *table_host, void *table_dev, size_t table_bytes, hipStream_t st, bool only_own) {
+    std::vector<ReduceJob> sel, rest;
+    std::vector<hipStream_t> rest_streams;
+    int tiles = 0, rest_tiles = 0;
+    for (size_t i = 0; i < g_jobs.size(); ++i) {
+        ReduceJob j = g_jobs[i];
+        if (!only_own || g_job_streams[i] == st) { j.tile0 = tiles; tiles += job_tiles(j); sel.push_back(j); }
+        else { j.tile0 = rest_tiles; rest_tiles += job_tiles(j); rest.push_back(j); rest_streams.push_back(g_job_streams[i]); }
+    }
+    if (sel.empty()) return 0;
+    const size_t need = sel.size() * sizeof(ReduceJob);
+    TSASR_CHECK_ARG(table_host && table_dev && table_bytes >= need, "tsasr_reduce_flush: job table too small (%zu < %zu bytes)", table_bytes, need);
+    memcpy(table_host, sel.data(), need);
+    // Under stream capture the table is NOT uploaded here: the caller copies table_host -> table_dev itself once the capture has
+    // ended (the pointers in it stay valid for the graph's lifetime, each captured graph owns its table pair), so a replay carries
+    // no memcpy node (ROCm 7.2 replays of captured memset / memcpy nodes have shown stale payloads).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone) {
+        hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
+            return TSASR_E_LAUNCH;
+        }
+    }
+    static const int bisect = getenv("TSASR_RD_BISECT") ? atoi(getenv("TSASR_RD_BISECT")) : 0;
+    reduce_many_kernel<<<tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)sel.size(), bisect);
+    g_jobs.swap(rest);
+    g_job_streams.swap(rest_streams);
+    g_tiles = rest_tiles;
+    TSASR_CHECK_LAUNCH("tsasr_reduce_flush");
+    return 0;
+}
+
 
 extern "C" {
 
@@ -162,29 +199,13 @@ size_t tsasr_reduce_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof
  * tsasr_reduce_table_bytes(tsasr_reduce_pending()); the job table is copied host -> device on `stream` - except while `stream` is
  * being captured: then only table_host is filled and the caller uploads it to table_dev after the capture (both must outlive the graph). */
 int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream) {
-    if (g_jobs.empty()) return 0;
-    const size_t need = g_jobs.size() * sizeof(ReduceJob);
-    TSASR_CHECK_ARG(table_host && table_dev && table_bytes >= need, "tsasr_reduce_flush: job table too small (%zu < %zu bytes)", table_bytes, need);
-    hipStream_t st = (hipStream_t)stream;
-    memcpy(table_host, g_jobs.data(), need);
-    // Under stream capture the table is NOT uploaded here: the caller copies table_host -> table_dev itself once the capture has
-    // ended (the pointers in it stay valid for the graph's lifetime, each captured graph owns its table pair), so a replay carries
-    // no memcpy node (ROCm 7.2 replays of captured memset / memcpy nodes have shown stale payloads).
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    if (cap == hipStreamCaptureStatusNone) {
-        hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
-            tsasr_set_error("tsasr_reduce_flush: job table upload failed: %s", hipGetErrorString(e));
-            return TSASR_E_LAUNCH;
-        }
-    }
-    static const int bisect = getenv("TSASR_RD_BISECT") ? atoi(getenv("TSASR_RD_BISECT")) : 0;
-    reduce_many_kernel<<<g_tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)g_jobs.size(), bisect);
-    g_jobs.clear();
-    g_tiles = 0;
-    TSASR_CHECK_LAUNCH("tsasr_reduce_flush");
-    return 0;
+    return reduce_flush_impl(table_host, table_dev, table_bytes, (hipStream_t)stream, false);
+}
+
+/* Same, but only the jobs whose partial rows were produced ON `stream` (they are complete in its order): lets the main stream
+ * reduce its share while a forked stream is still running its part of backward; the rest goes with the final tsasr_reduce_flush. */
+int tsasr_reduce_flush_stream(void *table_host, void *table_dev, size_t table_bytes, void *stream) {
+    return reduce_flush_impl(table_host, table_dev, table_bytes, (hipStream_t)stream, true);
 }
 
 }  // extern "C"

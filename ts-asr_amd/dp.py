@@ -191,7 +191,7 @@ class GradArena:
         tab[n * 8:n * 16].view(np.uint64)[:] = [p.grad.data_ptr() for _, p in self._deferred]
         tab[n * 16:].view(np.int32)[:] = [g.numel() for g, _ in self._deferred]
         key = (k, tab.tobytes())
-        if k > 0:                               # captured: filled now, uploaded after the capture (upload_captured_tables) - no memcpy node
+        if k > 1:                               # captured: filled now, uploaded after the capture (upload_captured_tables) - no memcpy node
             host[:n * 20].copy_(torch.from_numpy(tab))
             self._defer_upload.append((k, n * 20))
         elif key != self._defer_key:            # same pointers as the last eager step: skip the upload

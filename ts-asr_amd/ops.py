@@ -51,7 +51,7 @@ def begin_step(device):
 # Deferred reductions (csrc/reduce.hip): between GradArena.begin_backward and finish_backward the partial-sum reductions of
 # parameter gradients are queued and run as one launch; their workspaces must outlive the queue, so they are parked here.
 _DEFER = {"on": False, "keep": [], "host": None, "dev": None}
-_DEFER_MAX_JOBS = 8192
+_DEFER_MAX_JOBS = 4096
 
 
 def _ws(nbytes, device):
@@ -67,7 +67,7 @@ def _keep(*tensors):
         _DEFER["keep"].extend(t for t in tensors if t is not None)
 
 
-_TABLE_PAIRS = 64   # slot 0: eager flushes; slots 1.. : one per captured graph of this process (a replayed memcpy node re-reads ITS host table)
+_TABLE_PAIRS = 128  # slots 0 / 1: eager flushes (final / early); slots 2.. : one per flush of every captured graph of this process (a graph's kernels keep reading ITS tables)
 
 
 def reduce_defer_prepare(device):
@@ -79,14 +79,15 @@ def reduce_defer_prepare(device):
         _DEFER["captures"] = 0
 
 
-def table_slot(state):
-    """Index of the (pinned host, device) table pair to use now: 0 when executing eagerly, a fresh one per stream capture."""
+def table_slot(state, eager=0):
+    """Index of the (pinned host, device) table pair to use now: `eager` (0 or 1) when executing eagerly, a fresh one per flush
+    inside a stream capture."""
     if not torch.cuda.is_current_stream_capturing():
-        return 0
+        return eager
     state["captures"] += 1
-    if state["captures"] >= _TABLE_PAIRS:
-        raise RuntimeError("more captured graphs than job-table slots (ops._TABLE_PAIRS)")
-    return state["captures"]
+    if state["captures"] + 1 >= _TABLE_PAIRS:
+        raise RuntimeError("more captured flushes than job-table slots (ops._TABLE_PAIRS)")
+    return state["captures"] + 1
 
 
 def reduce_defer_begin(device):
@@ -107,9 +108,24 @@ def reduce_flush():
         k = table_slot(_DEFER)
         C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
                 "tsasr_reduce_flush")
-        if k > 0:
+        if k > 1:
             _DEFER.setdefault("upload", []).append(k)   # captured: the table goes to the device after the capture (upload_captured_tables)
     _DEFER["keep"] = []
+
+
+def reduce_flush_own_stream():
+    """Run the queued reductions whose partial rows were produced on the CURRENT stream (complete in its order), keep the rest
+    queued: called on the main stream when its share of backward is enqueued and a forked stream is still busy with the speaker
+    branch's - the HBM-bound reduction then runs under those small, latency-bound kernels instead of after them."""
+    if not _DEFER["on"] or C.lib().tsasr_reduce_pending() == 0:
+        return
+    if C.lib().tsasr_reduce_pending() > _DEFER_MAX_JOBS:
+        raise C.TsasrHipError("more queued reductions than the job table holds")
+    k = table_slot(_DEFER, eager=1)
+    C.check(C.lib().tsasr_reduce_flush_stream(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
+            "tsasr_reduce_flush_stream")
+    if k > 1:
+        _DEFER.setdefault("upload", []).append(k)
 
 
 def upload_captured_tables():

@@ -7,6 +7,8 @@ the speaker branch: train_librispeechmix_pretrained.py:45-63, train_librispeechm
 (the [B,T',U+1,J] joint tensor is never built), lengths stay on the device, plotting/WER bookkeeping is left to the
 caller (out of scope).
 """
+import os
+
 import torch
 
 from .. import core, rnnt
@@ -14,6 +16,9 @@ from ..nnet import abs_lengths_round
 
 Stage = core.Stage
 
+
+_OVERLAP_MODE = os.environ.get("TSASR_OVERLAP", "1")
+_OVERLAP_DEFAULT = _OVERLAP_MODE != "0"   # A/B knob: speaker branch + predictor on a second stream
 
 class TSASR(core.Brain):
     variant = "scratch"  # "scratch" | "pretrained" | "none"
@@ -64,7 +69,7 @@ class TSASR(core.Brain):
         # encoder joins the first lazily at the injection, the joint waits for the second. Backward follows by itself (autograd
         # runs a node on the stream of its forward): the predictor's backward overlaps the last encoder layers', the speaker
         # branch's overlaps layer 0 / the front-end's. Works the same inside a captured hipGraph (fork / join become edges).
-        overlap = (stage == Stage.TRAIN and self.variant == "scratch" and getattr(self, "overlap_branches", True)
+        overlap = (stage == Stage.TRAIN and self.variant == "scratch" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT)
                    and torch.device(self.device).type == "cuda")
         dec_out = None
         if overlap:
@@ -74,7 +79,8 @@ class TSASR(core.Brain):
                 spk, enroll_lens = self._speaker_embedding(batch, epoch)
                 spk_ready = torch.cuda.Event()
                 spk_ready.record(side)
-                dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+                if _OVERLAP_MODE != "2":     # "2" (diagnostics): only the speaker branch forks, the predictor stays on the main stream
+                    dec_out = self._predictor(tokens_bos, tokens_bos_lens)
 
             def speaker_embs():
                 cur.wait_event(spk_ready)
