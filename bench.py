@@ -238,7 +238,7 @@ def main():
             roof = {"kernel": dom, "bound": "mfma", "achieved": fam[dom]["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fam[dom]["TFLOPps"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                     "algorithmic_flops_per_launch": fam[dom]["avg_GFLOP_per_launch"] * 1e9, "avg_launch_ms": fam[dom]["avg_ms"],
-                    "note": "2*M*N*K of every launch of this kernel / its HIP-event duration (net of the empty event-pair overhead, event_pair_overhead_ms), averaged over the launches of the instrumented steps",
+                    "note": "2*M*N*K of every launch of this kernel / its HIP-event duration (net of 0.8 x the empty event-pair time, event_pair_overhead_ms, calibrated against rocprofv3), averaged over the launches of the instrumented steps",
                     "event_pair_overhead_ms": round(prof.out_overhead[0], 5)}
         elif dom is not None and dom in ab:
             ach = ab[dom] / (fam[dom]["avg_ms"] * 1e-3) / 1e9

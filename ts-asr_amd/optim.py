@@ -14,6 +14,8 @@ from . import _capi as C
 from . import prof
 
 
+_HYPER_SLOTS = 64
+
 class FusedClipAdamW:
     """Exposes ``param_groups`` (the Noam scheduler writes ``lr`` there) and ``step()``; state = flat m, v."""
 
@@ -35,12 +37,25 @@ class FusedClipAdamW:
         g = self.param_groups[0]
         self.t += 1
         b1, b2 = g["betas"]
+        cuda = self.arena.device.type == "cuda"
         if self._hyper_host is None:
-            self._hyper_host = torch.empty(3, dtype=torch.float32).pin_memory() if self.arena.device.type == "cuda" else torch.empty(3)
+            # a RING of pinned staging rows: with graph replay the host runs many steps ahead of the GPU, and an asynchronous copy reads
+            # its pinned source when it EXECUTES - one reused row handed step i the learning rate of step i+k (run-to-run different
+            # losses in un-synchronised loops). A row is rewritten only after the copy that last used it has completed.
+            self._hyper_host = torch.empty(_HYPER_SLOTS, 3, dtype=torch.float32).pin_memory() if cuda else torch.empty(_HYPER_SLOTS, 3)
+            self._hyper_events = [None] * _HYPER_SLOTS
             self._hyper_dev = torch.empty(3, dtype=torch.float32, device=self.arena.device)
             self._ws = torch.empty(max(256, C.lib().tsasr_clip_adamw_workspace_bytes()), dtype=torch.uint8, device=self.arena.device)
-        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = g["lr"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        k = self.t % _HYPER_SLOTS
+        if cuda and self._hyper_events[k] is not None:
+            self._hyper_events[k].synchronize()
+        row = self._hyper_host[k]
+        row[0], row[1], row[2] = g["lr"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        self._hyper_dev.copy_(row, non_blocking=True)
+        if cuda:
+            ev = self._hyper_events[k] or torch.cuda.Event()
+            ev.record()
+            self._hyper_events[k] = ev
 
     def launch(self):
         """Device half: two kernel launches over the arena (graph-capturable)."""
