@@ -44,8 +44,11 @@ def event_overhead_ms(pairs=64):
     return ms[len(ms) // 2]
 
 
-def collect(subtract_overhead=True):
-    """{name: (count, mean_ms)} - call after torch.cuda.synchronize(). Durations are net of the empty-pair overhead."""
+def collect(subtract_overhead=True, repeats=1):
+    """{name: (count, mean_ms)} - call after torch.cuda.synchronize(). Durations are net of the empty-pair overhead. ``repeats``:
+    the instrumented region ran the same launch sequence that many times (steps); each launch is then represented by its FASTEST
+    repeat (a launch that happened to queue behind another stream's kernel otherwise drags the family's mean: one 3 ms stall among 120
+    launches doubled it)."""
     out = {}
     # 0.8: with a kernel between the two records its own dispatch hides part of the gap an empty pair shows; calibrated against the
     # rocprofv3 durations of the same launches (wave-K weight gradient 19.5 us, 128x64 ring GEMM 12.4 us, attention forward 28.7 us:
@@ -53,7 +56,12 @@ def collect(subtract_overhead=True):
     ov = 0.8 * event_overhead_ms() if (subtract_overhead and _records) else 0.0
     for name, evs in _records.items():
         ms = [max(a.elapsed_time(b) - ov, 0.0) for a, b in evs]
-        out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        if repeats > 1 and len(ms) % repeats == 0:
+            n = len(ms) // repeats
+            best = [min(ms[i + r * n] for r in range(repeats)) for i in range(n)]
+            out[name] = (len(ms), sum(best) / max(n, 1))
+        else:
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
     out_overhead[0] = ov
     return out
 
