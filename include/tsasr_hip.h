@@ -277,6 +277,20 @@ int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, voi
  * launch. jobs: DEVICE int32 [njobs][5] = {src offset, dst offset (elements), rows, cols, first 64x64 tile index}. */
 int tsasr_transpose_many_bf16(const void *src_base, void *dst_base, const void *jobs, int njobs, int ntiles, void *stream);
 
+/* Grouped weight gradients (csrc/wgrad.hip): replaces, for every Linear / kernel-size-1 Conv1d weight of the path, the reference's
+ * autograd AccumulateGrad of dW = dy^T . x (SB/nnet/linear.py:64-78, SB/nnet/attention.py:549-553,820-836,
+ * SB/lobes/models/transformer/Conformer.py:76-98) and the per-weight split-K launches of round 1. tsasr_wgrad_queue only records
+ *   dW[M,N] (fp32, row stride ldc) += dy[K,M]^T . x[K,N]      (bf16 row-major, K = tokens; M, N, ld_dy, ld_x multiples of 8)
+ * - dy, x and dW must stay alive and unmodified until tsasr_wgrad_flush runs every queued job in ONE launch of 256x256 output
+ * tiles (no split along K: each tile owns its piece of dW, plain read-add-store, bit-reproducible). Two queued jobs must not
+ * target overlapping dW. Job table protocol as tsasr_reduce_flush (pinned host + device table; under stream capture the caller
+ * uploads the table after the capture). */
+int tsasr_wgrad_queue(const void *dy, const void *x, float *dW, int M, int N, int K, long long ld_dy, long long ld_x, long long ldc);
+int tsasr_wgrad_pending(void);
+size_t tsasr_wgrad_table_bytes(int max_jobs);
+int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
+void tsasr_wgrad_discard(void);
+
 /* Batched deterministic reductions of partial gradient rows / split-K slabs (csrc/reduce.hip). While tsasr_reduce_defer(1) is in
  * force the parameter-gradient outputs of the *_bwd entry points (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias)
  * and of tsasr_gemm_bf16(accumulate = 2) are only QUEUED: their workspaces and outputs must stay alive and untouched until

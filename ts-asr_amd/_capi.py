@@ -92,6 +92,11 @@ _PROTOS = {
     "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
     "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_reduce_flush_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_wgrad_queue": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3),
+    "tsasr_wgrad_pending": (c_int, []),
+    "tsasr_wgrad_table_bytes": (c_size_t, [c_int]),
+    "tsasr_wgrad_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_wgrad_discard": (None, []),
     "tsasr_specaug_params_words": (c_size_t, [c_int] * 3),
     "tsasr_specaug_draw": (c_int, [c_void_p] + [c_int] * 10 + [c_ull, c_void_p, c_void_p]),
     "tsasr_specaug_workspace_bytes": (c_size_t, []),

@@ -68,8 +68,8 @@ class GradArena:
         self._handles = []
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
-        self._deferred, self._keepalive, self._defer_host, self._defer_dev, self._defer_key = [], None, None, None, None
-        self._defer_upload = []
+        self._deferred, self._keepalive, self._defer_ring = [], None, None
+        self.collect_wgrads = self.device.type == "cuda"   # weight-gradient GEMMs are queued and run as one grouped launch per flush
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -77,10 +77,7 @@ class GradArena:
             # pinned / device job tables are created NOW: their first use may be inside a hipGraph capture (multi-rank runs only
             # defer inside the captured step), where a host allocation is not permitted
             from . import ops
-            cap = max(1024, 2 * len(params)) * 20
-            self._defer_host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(ops._TABLE_PAIRS)]
-            self._defer_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(ops._TABLE_PAIRS)]
-            self._defer_state = {"captures": 0}
+            self._defer_ring = ops.TableRing(max(1024, 2 * len(params)) * 20, self.device)
             ops.reduce_defer_prepare(self.device)
 
     # ---- layout ---------------------------------------------------------------------------------------
@@ -177,35 +174,57 @@ class GradArena:
         from . import _capi as C
         n = len(self._deferred)
         from . import ops
-        if self._defer_host is None:            # CPU-constructed arena moved to the GPU later: allocate on first (eager) use
-            cap = max(1024, 2 * n) * 20
-            self._defer_host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(ops._TABLE_PAIRS)]
-            self._defer_dev = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(ops._TABLE_PAIRS)]
-            self._defer_state = {"captures": 0}
-        k = ops.table_slot(self._defer_state)   # slot 0 eagerly, a fresh pair per captured graph (its memcpy node re-reads the host table)
-        host, dev = self._defer_host[k], self._defer_dev[k]
+        if self._defer_ring is None:            # CPU-constructed arena moved to the GPU later: allocate on first (eager) use
+            self._defer_ring = ops.TableRing(max(1024, 2 * n) * 20, self.device)
+        k, host, dev, captured = self._defer_ring.acquire()   # ring of pairs eagerly (a pair is rewritten only after its launch ran), one per captured flush
         if host.numel() < n * 20:
             raise RuntimeError("deferred-gradient table too small")
         tab = np.empty(n * 20, np.uint8)
         tab[:n * 8].view(np.uint64)[:] = [g.data_ptr() for g, _ in self._deferred]
         tab[n * 8:n * 16].view(np.uint64)[:] = [p.grad.data_ptr() for _, p in self._deferred]
         tab[n * 16:].view(np.int32)[:] = [g.numel() for g, _ in self._deferred]
-        key = (k, tab.tobytes())
-        if k > 1:                               # captured: filled now, uploaded after the capture (upload_captured_tables) - no memcpy node
-            host[:n * 20].copy_(torch.from_numpy(tab))
-            self._defer_upload.append((k, n * 20))
-        elif key != self._defer_key:            # same pointers as the last eager step: skip the upload
-            host[:n * 20].copy_(torch.from_numpy(tab))
+        host[:n * 20].copy_(torch.from_numpy(tab))
+        if not captured:                        # captured: filled now, uploaded after the capture (upload_captured_tables) - no memcpy node
             dev[:n * 20].copy_(host[:n * 20], non_blocking=True)
-            self._defer_key = key
         C.check(C.lib().tsasr_accumulate_many(C.ptr(dev), n, C.stream_ptr()), "tsasr_accumulate_many")
+        self._defer_ring.launched(k, n * 20)
         self._keepalive = self._deferred    # the temporaries must outlive the launch
         self._deferred = []
 
     def upload_captured_tables(self):
-        for k, nb in self._defer_upload:
-            self._defer_dev[k][:nb].copy_(self._defer_host[k][:nb], non_blocking=True)
-        self._defer_upload = []
+        if self._defer_ring is not None:
+            self._defer_ring.upload_captured()
+
+    # ---- grouped weight gradients (csrc/wgrad.hip) -------------------------------------------------------
+    def wgrad_queued(self, p):
+        """ops._wgrad_into queued p's weight gradient. On a step that overlaps the all-reduce with backward, a bucket whose other
+        gradients are all in is completed by flushing the queue (one grouped launch), then sent."""
+        if not self._order_final:
+            self._order_seen.append(p)
+        if not self._sync_this_step or not self._order_final:
+            return
+        b = self.bucket_of[id(p)]
+        b["left"] -= 1
+        b["queued"] = b.get("queued", 0) + 1
+        if b["left"] == 0:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        """Run every queued weight gradient now, on the current stream, ordered after every stream of the step."""
+        from . import ops
+        if ops.wgrad_pending() == 0:
+            return
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream()
+            for st in [self._main_stream] + list(self.aux_streams):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+        ops.wgrad_flush()
+        if self._sync_this_step and self._order_final:
+            for b in self.buckets:
+                if b.get("queued", 0) and b["left"] == 0:
+                    b["queued"] = 0
+                    self._send(b)
 
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):
@@ -216,7 +235,7 @@ class GradArena:
             from . import ops
             ops.reduce_defer_begin(self.device)
         for b in self.buckets:
-            b["left"], b["sent"] = len(b["ids"]), False
+            b["left"], b["sent"], b["queued"] = len(b["ids"]), False, 0
         self._handles = []
 
     def _on_grad(self, p):
@@ -227,7 +246,10 @@ class GradArena:
         b = self.bucket_of[id(p)]
         b["left"] -= 1
         if b["left"] == 0:
-            self._send(b)
+            if b.get("queued", 0):
+                self.flush_wgrads()
+            else:
+                self._send(b)
 
     def _send(self, b):
         if b.get("sent"):
@@ -249,6 +271,7 @@ class GradArena:
     def finish_backward(self):
         if self.device.type == "cuda":
             from . import ops
+            self.flush_wgrads()         # every queued weight gradient, one grouped launch (accumulates into the arena)
             ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()
         self.in_backward = False

@@ -7,6 +7,7 @@ Two kinds of operator live here, and DESIGN.md lists which is which:
            next rounds. ``STATUS`` below is the machine-readable version of that list.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -48,9 +49,51 @@ def begin_step(device):
         C.check(C.lib().tsasr_seed_advance(C.ptr(seed_state(device)), 0x9E3779B97F4A7C15, C.stream_ptr()), "tsasr_seed_advance")
 
 
+# Job tables of the batched launches (csrc/reduce.hip, csrc/wgrad.hip, tsasr_accumulate_many): the host fills a PINNED table, an
+# asynchronous copy moves it to a device table, the kernel reads that. Both copies are read when the stream gets there, not when the
+# host enqueues them, so a pair may only be rewritten once the launch that used it has finished: eager launches rotate through a ring
+# of pairs, each guarded by an event (the host waits only when it laps the GPU by a whole ring); a flush inside a stream capture gets
+# a pair of its own for the life of the graph (filled at capture, uploaded once right after it - a replay carries no memcpy node).
+class TableRing:
+    def __init__(self, nbytes, device, eager_pairs=8, captured_pairs=120):
+        self.nbytes, self.device = int(nbytes), torch.device(device)
+        n = eager_pairs + captured_pairs
+        self.host = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(n)]
+        self.dev = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(n)]
+        self.eager_pairs, self.events, self.next_eager, self.captured, self.to_upload = eager_pairs, [None] * eager_pairs, 0, 0, []
+
+    def acquire(self):
+        """(index, host table, device table, captured?) for the flush being issued now."""
+        if torch.cuda.is_current_stream_capturing():
+            k = self.eager_pairs + self.captured
+            if k >= len(self.host):
+                raise RuntimeError("more captured flushes than job-table pairs (ops.TableRing captured_pairs)")
+            self.captured += 1
+            return k, self.host[k], self.dev[k], True
+        k = self.next_eager
+        self.next_eager = (k + 1) % self.eager_pairs
+        if self.events[k] is not None:
+            self.events[k].synchronize()   # the launch that last read this pair has finished (no-op unless the host is a ring ahead)
+        return k, self.host[k], self.dev[k], False
+
+    def launched(self, k, nbytes=None):
+        """Call right after the launch that reads pair k was enqueued."""
+        if k >= self.eager_pairs:
+            self.to_upload.append((k, self.nbytes if nbytes is None else int(nbytes)))
+            return
+        ev = self.events[k] or torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+    def upload_captured(self):
+        for k, nb in self.to_upload:
+            self.dev[k][:nb].copy_(self.host[k][:nb], non_blocking=True)
+        self.to_upload = []
+
+
 # Deferred reductions (csrc/reduce.hip): between GradArena.begin_backward and finish_backward the partial-sum reductions of
 # parameter gradients are queued and run as one launch; their workspaces must outlive the queue, so they are parked here.
-_DEFER = {"on": False, "keep": [], "host": None, "dev": None}
+_DEFER = {"on": False, "keep": [], "ring": None}
 _DEFER_MAX_JOBS = 4096
 
 
@@ -67,27 +110,13 @@ def _keep(*tensors):
         _DEFER["keep"].extend(t for t in tensors if t is not None)
 
 
-_TABLE_PAIRS = 128  # slots 0 / 1: eager flushes (final / early); slots 2.. : one per flush of every captured graph of this process (a graph's kernels keep reading ITS tables)
-
-
 def reduce_defer_prepare(device):
     """Allocate the job tables (pinned host + device) outside of any graph capture."""
-    if torch.device(device).type == "cuda" and _DEFER["host"] is None:
-        nb = C.lib().tsasr_reduce_table_bytes(_DEFER_MAX_JOBS)
-        _DEFER["host"] = [torch.empty(nb, dtype=torch.uint8).pin_memory() for _ in range(_TABLE_PAIRS)]
-        _DEFER["dev"] = [torch.empty(nb, dtype=torch.uint8, device=device) for _ in range(_TABLE_PAIRS)]
-        _DEFER["captures"] = 0
-
-
-def table_slot(state, eager=0):
-    """Index of the (pinned host, device) table pair to use now: `eager` (0 or 1) when executing eagerly, a fresh one per flush
-    inside a stream capture."""
-    if not torch.cuda.is_current_stream_capturing():
-        return eager
-    state["captures"] += 1
-    if state["captures"] + 1 >= _TABLE_PAIRS:
-        raise RuntimeError("more captured flushes than job-table slots (ops._TABLE_PAIRS)")
-    return state["captures"] + 1
+    if torch.device(device).type == "cuda":
+        if _DEFER["ring"] is None:
+            _DEFER["ring"] = TableRing(C.lib().tsasr_reduce_table_bytes(_DEFER_MAX_JOBS), device)
+        if _WG["ring"] is None:
+            _WG["ring"] = TableRing(C.lib().tsasr_wgrad_table_bytes(_WG_MAX_JOBS), device)
 
 
 def reduce_defer_begin(device):
@@ -98,18 +127,22 @@ def reduce_defer_begin(device):
     _DEFER["on"] = True
 
 
+def _reduce_flush(fn_name):
+    n = C.lib().tsasr_reduce_pending()
+    if n > _DEFER_MAX_JOBS:
+        raise C.TsasrHipError("more queued reductions than the job table holds")
+    if n > 0:
+        ring = _DEFER["ring"]
+        k, host, dev, _ = ring.acquire()
+        C.check(getattr(C.lib(), fn_name)(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), fn_name)
+        ring.launched(k)
+
+
 def reduce_flush():
     """Run the queued reductions now (one launch); the parked workspaces are released afterwards (stream order keeps them valid)."""
     if not _DEFER["on"]:
         return
-    if C.lib().tsasr_reduce_pending() > _DEFER_MAX_JOBS:
-        raise C.TsasrHipError("more queued reductions than the job table holds")
-    if C.lib().tsasr_reduce_pending() > 0:
-        k = table_slot(_DEFER)
-        C.check(C.lib().tsasr_reduce_flush(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
-                "tsasr_reduce_flush")
-        if k > 1:
-            _DEFER.setdefault("upload", []).append(k)   # captured: the table goes to the device after the capture (upload_captured_tables)
+    _reduce_flush("tsasr_reduce_flush")
     _DEFER["keep"] = []
 
 
@@ -119,21 +152,15 @@ def reduce_flush_own_stream():
     branch's - the HBM-bound reduction then runs under those small, latency-bound kernels instead of after them."""
     if not _DEFER["on"] or C.lib().tsasr_reduce_pending() == 0:
         return
-    if C.lib().tsasr_reduce_pending() > _DEFER_MAX_JOBS:
-        raise C.TsasrHipError("more queued reductions than the job table holds")
-    k = table_slot(_DEFER, eager=1)
-    C.check(C.lib().tsasr_reduce_flush_stream(C.ptr(_DEFER["host"][k]), C.ptr(_DEFER["dev"][k]), _DEFER["host"][k].numel(), C.stream_ptr()),
-            "tsasr_reduce_flush_stream")
-    if k > 1:
-        _DEFER.setdefault("upload", []).append(k)
+    _reduce_flush("tsasr_reduce_flush_stream")
 
 
 def upload_captured_tables():
     """After a stream capture: copy the job tables the captured flushes filled on the host to their device twins (a graph replay
     carries no memcpy node; each captured graph owns its pair for life)."""
-    for k in _DEFER.get("upload", []):
-        _DEFER["dev"][k].copy_(_DEFER["host"][k], non_blocking=True)
-    _DEFER["upload"] = []
+    for st in (_DEFER, _WG):
+        if st["ring"] is not None:
+            st["ring"].upload_captured()
 
 
 def reduce_defer_end():
@@ -142,6 +169,49 @@ def reduce_defer_end():
     reduce_flush()
     C.check(C.lib().tsasr_reduce_defer(0), "tsasr_reduce_defer")
     _DEFER["on"] = False
+
+
+# Grouped weight gradients (csrc/wgrad.hip): dW += dy^T . x feeds nothing downstream in backward, so _LinearFn / _FFNFn only QUEUE
+# it while the gradient arena is collecting (operands parked here); GradArena flushes the queue in one launch per bucket / step.
+_WG = {"keep": [], "ids": set(), "ring": None, "params": []}
+_WG_MAX_JOBS = 1024
+_WG_ENABLED = os.environ.get("TSASR_WGRAD_GROUP", "1") != "0"
+
+
+def wgrad_queue(weight, grad2d, dy2, x2):
+    """Queue grad2d [N, K] (fp32 view of weight.grad) += dy2[M, N]^T . x2[M, K]; False when the shapes do not fit the grouped kernel."""
+    N, K = grad2d.shape
+    M = dy2.shape[0]
+    if not _WG_ENABLED or _WG["ring"] is None or N % 8 or K % 8 or N < 8 or K < 8 or dy2.stride(1) != 1 or x2.stride(1) != 1 \
+            or dy2.stride(0) % 8 or x2.stride(0) % 8 or dy2.data_ptr() % 16 or x2.data_ptr() % 16 or grad2d.stride(1) != 1 \
+            or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or grad2d.dtype != torch.float32:
+        return False
+    if id(weight) in _WG["ids"] or C.lib().tsasr_wgrad_pending() >= _WG_MAX_JOBS:   # a second gradient into the same tiles: order them
+        wgrad_flush()
+    C.check(C.lib().tsasr_wgrad_queue(C.ptr(dy2), C.ptr(x2), C.ptr(grad2d), N, K, M, dy2.stride(0), x2.stride(0), grad2d.stride(0)),
+            "tsasr_wgrad_queue")
+    _WG["ids"].add(id(weight))
+    _WG["keep"] += [dy2, x2]
+    _WG["params"].append(weight)
+    return True
+
+
+def wgrad_pending():
+    return len(_WG["params"])
+
+
+def wgrad_flush():
+    """One launch for every queued weight gradient (on the current stream, which must be ordered after their producers); returns the
+    parameters whose gradients it completed."""
+    done = _WG["params"]
+    if done:
+        ring = _WG["ring"]
+        k, host, dev, _ = ring.acquire()
+        with prof.region("wgrad_group", _WG.get("flops", 0.0)):
+            C.check(C.lib().tsasr_wgrad_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_wgrad_flush")
+        ring.launched(k)
+    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"] = [], set(), [], 0.0
+    return done
 
 
 def _f32(p):
@@ -276,11 +346,23 @@ class _LinearFn(torch.autograd.Function):
             sink = _GRAD_SINK
             if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
                     and weight.grad.is_contiguous()):
-                gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out=weight.grad.view(N, K), accumulate=True, defer_ok=True)     # grad += dy^T . x
-                sink.mark_ready(weight)
+                _wgrad_into(sink, weight, weight.grad.view(N, K), dy2, x2)                           # grad += dy^T . x
             else:
                 dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
         return dx, dw
+
+
+def _wgrad_into(sink, weight, grad2d, dy2, x2):
+    """grad2d [N, K] += dy2 [M, N]^T . x2 [M, K]: queued for the arena's grouped launch (csrc/wgrad.hip) when it collects them,
+    else one split-K GEMM now."""
+    N, K = grad2d.shape
+    M = dy2.shape[0]
+    if getattr(sink, "collect_wgrads", False) and wgrad_queue(weight, grad2d, dy2, x2):
+        _WG["flops"] = _WG.get("flops", 0.0) + 2.0 * M * N * K
+        sink.wgrad_queued(weight)
+        return
+    gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, defer_ok=True)
+    sink.mark_ready(weight)
 
 
 def gemm_bf16_fused(a, b, M, N, K, lda, ldb, trans_a, trans_b, mode, bias=None, y=None, slope=-1.0, p=0.0, seed=0, dbias=None):
@@ -339,8 +421,7 @@ class _FFNFn(torch.autograd.Function):
 
         def wgrad(w, g, a, n_out, k_in):
             if sink is not None and w.is_leaf and sink.accepts(w) and w.grad.dtype == torch.float32 and w.grad.is_contiguous():
-                gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out=w.grad, accumulate=True, defer_ok=True)
-                sink.mark_ready(w)
+                _wgrad_into(sink, w, w.grad, g, a)
                 return None
             return gemm_bf16(g, a, n_out, k_in, M, n_out, k_in, 1, 1, out_dtype=torch.float32).to(w.dtype)
 
