@@ -537,10 +537,11 @@ def test_fbank_and_sentence_norm_known_answers(nn_, ops):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_fused_ffn_core(ops, p):
+@pytest.mark.parametrize("M", [777, 3999, 7995])   # 3999 / 7995 rows: the 8-wave 128- and 256-row tiles of csrc/gemm_big.hip, ragged last tile
+def test_fused_ffn_core(ops, p, M):
     """_FFNFn (two HIP GEMMs with fused bias/LeakyReLU/dropout epilogues) vs the unfused composition of already-tested ops
     sharing the same counter-based dropout stream, forward and every gradient."""
-    M, D, F1 = 777, 256, 2048
+    D, F1 = 256, 2048
     g = torch.Generator().manual_seed(21)
     x = torch.randn(3, M // 3, D, generator=g).to(torch.bfloat16)
     w1, b1 = torch.randn(F1, D, generator=g) / D ** 0.5, torch.randn(F1, generator=g) * 0.1

@@ -778,6 +778,12 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__re
     else { c[0] = s.x; c[1] = s.y; c[2] = s.z; c[3] = s.w; }
 }
 
+// csrc/gemm_big.hip: 256-column output tiles, 8 waves (the feed-forward's wide GEMMs); returns 1 when the shape does not fit
+int tsasr_gemm_big_bm(int M, int N, int K);
+int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int mode,
+                          const float *bias, const void *y, long long ldy, float slope, float p, unsigned long long seed,
+                          const unsigned long long *seed_dev, float *colpart, hipStream_t st);
+
 static int g_use_ring = getenv("TSASR_GEMM_RING") ? atoi(getenv("TSASR_GEMM_RING")) : 1;   // 0: never, 1: long K or small tiles, 2: always
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
@@ -915,6 +921,11 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
         else
             gemm_slab_reduce_kernel<<<(unsigned)cdiv((int)((ss + 3) / 4), 256), 256, 0, st>>>((const float *)workspace, (float *)C, M, N, ldc, p.splits, ss, accumulate != 0);
     } else if (out_dtype == TSASR_BF16) {
+        if (!transA && !transB && g_force_tile < 0 && ldc % 8 == 0 &&
+            tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, 0, nullptr, nullptr, 0, -1.f, 0.f, 0, nullptr, nullptr, st) == 0) {
+            TSASR_CHECK_LAUNCH("tsasr_gemm_bf16");
+            return 0;
+        }
         launch_tile<0>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     } else if (accumulate) {
         launch_tile<2>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
@@ -943,6 +954,15 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
     GemmPlan pl = plan(M, N, K, 0);
     hipStream_t st = (hipStream_t)stream;
+    if (!transA && !transB && g_force_tile < 0) {
+        const int bm = tsasr_gemm_big_bm(M, N, K);
+        float *colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;
+        if (bm && tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, epi_mode, bias, y, ldy, slope, p, seed, seed_dev, colpart, st) == 0) {
+            if (colpart) tsasr_reduce_submit(colpart, dbias, N, cdiv(M, bm), N, 0, st);
+            TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_fused");
+            return 0;
+        }
+    }
     EpiArgs ep{};
     ep.mode = epi_mode; ep.bias = bias; ep.y = (const bf16_t *)y; ep.ldy = ldy; ep.slope = slope; ep.p = p; ep.seed = seed; ep.seed_dev = seed_dev;
     ep.colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;
