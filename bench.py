@@ -22,6 +22,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "ts-asr_amd"
 B_LOCAL, T_MEL, T_ENROLL, U = 32, 1000, 500, 120
+# --config: the headline workload (BASELINE.json configs[1] / [2]) and the two other GPU configurations of BASELINE.json
+WORKLOADS = {
+    "scratch": dict(yaml="conformer-t_scratch_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides={}, emb=0,
+                    name="BASELINE.json configs[1]: conformer-t_scratch 12L d256 (+6L speaker encoder), mel [32,1000,80] + enrollment mel [32,500,80] + tokens [32,120], injection cat, dropout 0.1"),
+    "pretrained": dict(yaml="conformer-t_wavlm_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides={}, emb=512,
+                       name="BASELINE.json configs[3]: conformer-t_wavlm (frozen speaker encoder's x-vector given as [32,1,512] -> speaker_proj 512->256 -> cat injection), mel [32,1000,80] + tokens [32,120], dropout 0.1"),
+    "longform": dict(yaml="conformer-t_scratch_mi355x.yaml", B=1, T=16000, Te=500, U=1920, emb=0,
+                     overrides=dict(causal_encoder=True, frontend_padding="causal"),
+                     name="BASELINE.json configs[4]: causal conformer-t (causal encoder + causal front-end padding, as the reference's --causal_encoder True --frontend_padding causal), B=1/GPU, mel [1,16000,80] -> T'=4000, tokens [1,1920], enrollment mel [1,500,80], dropout 0.1"),
+    "longform_chunk40": dict(yaml="conformer-t_scratch_mi355x.yaml", B=1, T=16000, Te=500, U=1920, emb=0,
+                             overrides=dict(causal_encoder=True, frontend_padding="causal", attention_chunk_size=40),
+                             name="BASELINE.json configs[4] with the BUILD EXTENSION chunk=40 (block-causal attention: a frame sees its whole 40-frame chunk and everything before it; the reference has no chunked attention), B=1/GPU, mel [1,16000,80] -> T'=4000, tokens [1,1920]"),
+}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
 
@@ -34,13 +47,13 @@ def log(msg):
     print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_brain(device, compute_dtype="bf16", accum=1, overrides=None):
+def build_brain(device, compute_dtype="bf16", accum=1, overrides=None, yaml_name="conformer-t_scratch_mi355x.yaml"):
     import torch
     hp = importlib.import_module(PKG + ".hparams")
     tsasr = importlib.import_module(PKG + ".recipes.tsasr")
     ov = dict(input_is_feats=True, compute_dtype=compute_dtype, grad_accumulation_factor=accum)
     ov.update(overrides or {})
-    with open(os.path.join(ROOT, "hparams", "conformer-t_scratch_mi355x.yaml")) as f:
+    with open(os.path.join(ROOT, "hparams", yaml_name)) as f:
         h = hp.load_hyperpyyaml(f, ov)
     run_opts = {"device": device, "compute_dtype": compute_dtype, "grad_accumulation_factor": accum,
                 "distributed_launch": int(os.environ.get("WORLD_SIZE", "1")) > 1}
@@ -113,7 +126,11 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="lengths U(0.6,1) sorted ascending instead of all 1.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--config", default="scratch", choices=sorted(WORKLOADS), help="workload (default: the headline, BASELINE.json configs[1])")
     args = ap.parse_args()
+    wl = WORKLOADS[args.config]
+    global B_LOCAL, T_MEL, T_ENROLL, U
+    B_LOCAL, T_MEL, T_ENROLL, U = wl["B"], wl["T"], wl["Te"], wl["U"]
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,12 +153,12 @@ def main():
 
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # GLUE convs/LSTM: no exhaustive MIOpen search on first use
     log("building model")
-    brain, h, _ = build_brain(device, args.dtype, args.accum)
+    brain, h, _ = build_brain(device, args.dtype, args.accum, wl["overrides"], wl["yaml"])
     log("model built")
     if world > 1:  # identical initial weights on every rank (reference: DDP constructor broadcast)
         for p in brain.modules.parameters():
             torch.distributed.broadcast(p.data, 0)
-    batch = batch_mod.synthetic_batch(B_LOCAL, T_MEL, T_ENROLL, U, feats=True, seed=1234 + rank, ragged=args.ragged).to(device)
+    batch = batch_mod.synthetic_batch(B_LOCAL, T_MEL, T_ENROLL, U, feats=True, seed=1234 + rank, ragged=args.ragged, enroll_emb_dim=wl["emb"]).to(device)
 
     def sync():
         if world > 1:
@@ -220,7 +237,7 @@ def main():
     if rank == 0:
         frames = world * B_LOCAL * T_MEL * args.steps
         ms_step = elapsed / args.steps * 1e3
-        ab = algorithmic_bytes()
+        ab = algorithmic_bytes(B_LOCAL, T_MEL // 4, U + 1)
         wk = prof.work()
         fam = {}
         for k, (n, ms) in kern.items():
@@ -249,13 +266,12 @@ def main():
             roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])
         rnnt_ms = sum(fam[k]["avg_ms"] for k in ("joint_fwd", "rnnt_loss_fwd", "rnnt_loss_bwd", "joint_bwd") if k in fam)
         out = {
-            "metric": "utterance-frames/sec (conformer-t_scratch training step, T=1000, B=32/GPU)",
+            "metric": f"utterance-frames/sec (conformer-t_scratch training step, T={T_MEL}, B={B_LOCAL}/GPU)" if args.config != "pretrained"
+                      else f"utterance-frames/sec (conformer-t_wavlm training step, T={T_MEL}, B={B_LOCAL}/GPU)",
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: conformer-t_scratch 12L d256 (+6L speaker encoder), mel [32,1000,80] + "
-                                   "enrollment mel [32,500,80] + tokens [32,120], injection cat, dropout 0.1, lens "
-                                   + ("U(0.6,1) ascending" if args.ragged else "1.0"),
+            "config": {"workload": wl["name"] + ", lens " + ("U(0.6,1) ascending" if args.ragged else "1.0"),
                        "global_batch": world * B_LOCAL, "grad_accumulation_factor": args.accum, "parallelism": f"dp{world}",
                        "hip_graph": brain._graph is not None},
             "frames_per_sec_per_gpu": round(frames / elapsed / world, 1),
@@ -266,7 +282,7 @@ def main():
             "hip_kernels": fam,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "scratch":
             out["cpu_baseline"] = cpu_baseline(brain, torch)
         print(json.dumps(out))
     if world > 1:

@@ -104,3 +104,11 @@ def golden_inputs(cfg=CFG1):
         mixed_sig=mix, mixed_lens=mix_lens, enroll_sig=enr, enroll_lens=enr_lens,
         tokens=tokens, tokens_lens=tok_lens, tokens_bos=tokens_bos, tokens_bos_lens=tokens_bos_lens,
     )
+
+
+SPEAKER_EMBEDDING_DIM = 512   # hparams/LibriSpeechMix/conformer-t_wavlm.yaml:123 (microsoft/wavlm-base-sv x-vector size)
+
+
+def golden_enroll_emb(cfg=CFG1):
+    """Stand-in for the frozen WavLM x-vector of train_librispeechmix_pretrained.py:45-63: [B, 1, 512] N(0,1)."""
+    return det_tensor("in.enroll_emb", (cfg["B"], 1, SPEAKER_EMBEDDING_DIM), 1.0)

@@ -133,8 +133,10 @@ def relpos_mha(x, pe, sd, p, H, key_padding_mask=None, causal=False, return_attn
     idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1)  # [T,T]
     bd = torch.gather(bd_raw, 3, idx.expand(B, H, T, T))
     score = (ac + bd) * (1.0 / math.sqrt(D))  # 1/sqrt(embed_dim)  (:452,604)
-    if causal:
-        score = score + torch.full((T, T), float("-inf")).triu(1)  # float look-ahead mask is added (:615-616)
+    if causal:   # float look-ahead mask is added (:615-616); causal = C > 1: the build's block-causal extension (chunks of C frames:
+        ii = torch.arange(T)   # a frame sees its whole chunk and everything before it) - not a reference feature, see DESIGN.md
+        lim = ii if int(causal) <= 1 else (ii // int(causal) + 1) * int(causal) - 1
+        score = score + torch.zeros(T, T).masked_fill(ii[None, :] > lim[:, None], float("-inf"))
     if key_padding_mask is not None:
         score = score.masked_fill(key_padding_mask.view(B, 1, 1, T), float("-inf"))
     attn = torch.softmax(score, dim=-1)
@@ -326,14 +328,17 @@ def compute_forward(batch, sd, cfg, injection_mode="cat", causal=False, frontend
     c = {} if collect is None else collect
     H = cfg["nhead"]
     if from_feats:  # bench workload: mel features given (already normalised), SURVEY.md section 8d
-        sf, f = batch["enroll_feats"], batch["mixed_feats"]
+        sf, f = batch.get("enroll_feats"), batch["mixed_feats"]
     else:
-        sf = sentence_norm(fbank(batch["enroll_sig"]), batch["enroll_lens"])
+        sf = sentence_norm(fbank(batch["enroll_sig"]), batch["enroll_lens"]) if "enroll_sig" in batch and "enroll_emb" not in batch else None
         f = sentence_norm(fbank(batch["mixed_sig"]), batch["mixed_lens"])
         c["spk_norm"], c["norm"] = sf, f
     sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}  # noqa: E731
     spk = None
-    if "speaker_encoder.norm.norm.weight" in sd:
+    if "enroll_emb" in batch:   # pretrained-speaker variant (train_librispeechmix_pretrained.py:45-63,80): the frozen speaker encoder's
+        spk = linear(batch["enroll_emb"], sd, "speaker_proj.")   # embedding [B,1,E] (or hidden states [B,S,E]) is an input; only speaker_proj is on the path
+        c["spk_emb"] = spk
+    elif "speaker_encoder.norm.norm.weight" in sd:
         se = frontend(sf, sub("speaker_frontend."), "same")
         se = conformer_encoder(se, batch["enroll_lens"], sd, "speaker_encoder.", H, cfg["speaker_num_layers"])
         c["spk_enc"] = se

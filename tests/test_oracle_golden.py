@@ -321,3 +321,40 @@ def test_resample_vs_reference(golden, speed):
         half = R.resample(sine, 16000, 8000)
         close(half, g["sp_sine_half"], atol=2e-6)
         assert half.allclose(sine[:, ::2], atol=3e-1)          # the reference's own assertion
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]: pretrained-speaker variant
+@pytest.mark.parametrize("mode", ["cat", "sum", "prod"])
+def test_oracle_pretrained_variant_vs_reference_golden(golden, mode):
+    """train_librispeechmix_pretrained.py:45-135 with the frozen encoder's x-vector given (tests/golden/c1_pretrained.npz, generated by
+    oracle/gen_golden_pretrained.py from the reference's own modules): speaker_proj(512 -> D), injection, encoder, transducer logits."""
+    from oracle.golden_recipe import SPEAKER_EMBEDDING_DIM, golden_enroll_emb
+    g = golden["c1_pretrained"]
+    inp = golden_inputs()
+    sd = full_state_dict(CFG1, mode)
+    sd = {k: v for k, v in sd.items() if not k.startswith(("speaker_frontend.", "speaker_encoder."))}
+    sd["speaker_proj.w.weight"] = T(det_weight("speaker_proj.w.weight", (CFG1["d_model"], SPEAKER_EMBEDDING_DIM)))
+    batch = torch_batch(inp)
+    batch["enroll_emb"] = T(golden_enroll_emb())
+    if mode == "cat":
+        for v in sd.values():
+            v.requires_grad_(True)
+    c = {}
+    with torch.set_grad_enabled(mode == "cat"):
+        logits = R.compute_forward(batch, sd, CFG1, mode, collect=c)
+    np.testing.assert_allclose(c["spk_emb"].detach().numpy(), g[f"spk_emb:{mode}"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(c["enc"].detach().numpy(), g[f"enc:{mode}"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(logits.detach().numpy(), g[f"logits:{mode}"], atol=2e-4, rtol=1e-4)
+    if mode == "cat":   # gradients for the fixed probe: norms of every parameter, values of the small ones
+        probe = T(det_tensor("probe.logits", tuple(logits.shape), 1.0))
+        (logits * probe).sum().mul(1.0 / logits.numel()).backward()
+        n = 0
+        for k in g.files:
+            if k.startswith("norm:"):
+                name = k[5:]
+                if name in sd and sd[name].grad is not None:
+                    assert float(sd[name].grad.double().norm()) == pytest.approx(float(g[k]), rel=2e-3, abs=1e-7), name
+                    n += 1
+            elif k.startswith("grad:") and k[5:] in sd:
+                np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=2e-6, rtol=2e-3)
+        assert n >= 60

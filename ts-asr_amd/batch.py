@@ -35,7 +35,7 @@ class PaddedBatch:
         return iter(getattr(self, k) for k in self._keys)
 
 
-def synthetic_batch(B, n_mix, n_enroll, U, vocab_size=29, seed=1234, ragged=False, feats=False, n_mels=80, device="cpu"):
+def synthetic_batch(B, n_mix, n_enroll, U, vocab_size=29, seed=1234, ragged=False, feats=False, n_mels=80, device="cpu", enroll_emb_dim=0):
     """Seeded synthetic TS-ASR batch. ``feats=False``: waveforms N(0, 0.1^2) of n_mix / n_enroll samples;
     ``feats=True``: already-normalised mel features N(0,1) of n_mix / n_enroll FRAMES
     carried in the same fields (the recipe skips Fbank+norm when hparams['input_is_feats'])."""
@@ -62,10 +62,13 @@ def synthetic_batch(B, n_mix, n_enroll, U, vocab_size=29, seed=1234, ragged=Fals
         enr[b, int(round(float(enr_l[b]) * n_enroll)):] = 0
     tokens_bos = torch.cat([torch.zeros(B, 1, dtype=torch.long), tokens], 1)
     bos_l = (tok_abs + 1).float() / (U + 1)
-    batch = PaddedBatch({
+    fields = {
         "id": [f"syn-{seed}-{i}" for i in range(B)],
         "mixed_sig": PaddedData(mix, mix_l), "enroll_sig": PaddedData(enr, enr_l),
         "tokens_bos": PaddedData(tokens_bos, bos_l), "tokens": PaddedData(tokens, tok_l),
         "target_words": [["x"] for _ in range(B)],
-    })
+    }
+    if enroll_emb_dim:   # pretrained-speaker variant: the frozen encoder's x-vector N(0,1) [B,1,E] is an input
+        fields["enroll_emb"] = PaddedData(torch.randn(B, 1, enroll_emb_dim, generator=g), torch.ones(B))
+    batch = PaddedBatch(fields)
     return batch.to(device) if device != "cpu" else batch

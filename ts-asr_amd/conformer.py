@@ -58,7 +58,7 @@ class ConformerEncoder(nn.Module):
     def __init__(self, input_size, d_model=512, nhead=8, num_layers=6, d_ffn=2048, dropout=0.0, activation=nn.ReLU,
                  positional_encoding="fixed_abs_sine", kernel_size=31, bias=True, attention_type="RelPosMHAXL",
                  max_length=2500, causal=False, injection_mode: "Optional[str]" = "prod",
-                 injection_after: "Union[int, List[int]]" = 0):
+                 injection_after: "Union[int, List[int]]" = 0, chunk_size: int = 0):   # chunk_size: build extension (nnet.ConformerEncoderLayer)
         super().__init__()
         if attention_type != "RelPosMHAXL":
             raise NotImplementedError("attention_type must be RelPosMHAXL on this path")
@@ -70,7 +70,7 @@ class ConformerEncoder(nn.Module):
         self.custom_src_module = _SrcModule(input_size, d_model, dropout)
         self.layers = nn.ModuleList([
             ConformerEncoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, dropout=dropout, activation=activation,
-                                  kernel_size=kernel_size, bias=bias, causal=causal, attention_type=attention_type)
+                                  kernel_size=kernel_size, bias=bias, causal=causal, attention_type=attention_type, chunk_size=chunk_size)
             for _ in range(num_layers)])
         self.norm = LayerNorm(d_model, eps=1e-6)
         if injection_mode == "cat":

@@ -45,6 +45,11 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // block and is waited for where it stands, so a prologue of 160 guarded element loads or a staging loop of six guarded row
 // pieces costs that many serialized memory round trips (the same finding as in csrc/rnnt.hip's backward kernels).
 
+// `causal` argument of every kernel: 0 = no look-ahead mask; 1 = the reference's look-ahead mask (a frame sees keys j <= i:
+// Transformer.py:890-914 via models/conformer.py:279-280); C > 1 = BUILD EXTENSION "chunk = C frames" (BASELINE.json configs[4]):
+// block-causal, a frame sees its whole chunk of C frames and everything before it. Last key query i may attend:
+__device__ __forceinline__ int causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
+
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) {
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
     const DropKey dkey = drop_key(seed);
 
     int j_end = len;
-    if (causal) j_end = min(j_end, i0 + AT_QB);  // keys beyond the last query of the workgroup are never attended
+    if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);  // keys beyond the last query's limit are never attended
     const bool pipe = (Dh % 8) == 0;   // 16-byte aligned row pieces: tiles are requested one iteration ahead (StagePieces)
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
         for (int sub = 0; sub < 2; ++sub) {
             const int jb = j0 + 32 * sub;
             if (jb >= j_end) break;                                       // wave-uniform
-            if (causal && jb > i0 + wave * AT_QW + 31) break;              // whole sub-block is in the future of this wave
+            if (causal && jb > causal_limit(i0 + wave * AT_QW + 31, causal)) break;              // whole sub-block is in the future of this wave
             // ---- AC^T: rows = keys, col = query
             f32x16 s_acc = {0};
 #pragma unroll
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
                 const float bd = g_lds[(jl - r + 31) * 32 + r];
                 const int j = jb + jl;
                 float x = (s_acc[g] + bd) * scale;
-                if (j >= len || (causal && j > iq)) x = -INFINITY;
+                if (j >= len || (causal && j > causal_limit(iq, causal))) x = -INFINITY;
                 sc[g] = x;
                 mx = fmaxf(mx, x);
             }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
     int j_end = len;
-    if (causal) j_end = min(j_end, i0 + AT_QB);
+    if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);
     const bool pipe = (Dh % 8) == 0;
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
         for (int sub = 0; sub < 2; ++sub) {
             const int jb = j0 + 32 * sub;
             if (jb >= j_end) break;
-            if (causal && jb > i0 + wave * AT_QW + 31) break;
+            if (causal && jb > causal_limit(i0 + wave * AT_QW + 31, causal)) break;
             f32x16 s_acc = {0}, dpd = {0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
                 const float bd = g_lds[(jl - r + 31) * 32 + r];
                 const int j = jb + jl;
-                const bool masked = (j >= len) || (causal && j > iq);
+                const bool masked = (j >= len) || (causal && j > causal_limit(iq, causal));
                 const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
                 float keep = 1.f;
                 if (pdrop > 0.f) {
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
     load8_clamped<float>(bias_v + h * Dh, c, Dh, fast_d, bv8);
     f32x16 dk = {0}, dv = {0};
     // queries that can reach these keys: all of them, or (causal) those at or after the first key of the workgroup
-    const int i_begin = causal ? (j0 / 64) * 64 : 0;
+    const int i_begin = causal ? (((j0 / causal) * causal) / 64) * 64 : 0;
     float xpv[2][8], xsv[2][8], dov[2][8], qv8[2][8];
     auto request = [&](int i0n) {   // always-issued clamped loads; masked at the LDS store
 #pragma unroll
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ d
                 for (int q = 0; q < 16; ++q) {
                     const int il = il0 + q, i = i0 + il, j = jlo + rl + il;
                     const float x = (float)raw[il * SH_LD + off + rl + il];
-                    v16[q] = (i < Tn && j >= 0 && j < len && !(causal && j > i)) ? x : 0.f;
+                    v16[q] = (i < Tn && j >= 0 && j < len && !(causal && j > causal_limit(i, causal))) ? x : 0.f;
                 }
                 st8(a_tile + rl * DPK_LD + il0, *reinterpret_cast<float(*)[8]>(&v16[0]));
                 st8(a_tile + rl * DPK_LD + il0 + 8, *reinterpret_cast<float(*)[8]>(&v16[8]));

@@ -497,8 +497,12 @@ class ConvolutionModule(nn.Module):
 
 class ConformerEncoderLayer(nn.Module):
     def __init__(self, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=nn.LeakyReLU, bias=True,
-                 dropout=0.0, causal=False, attention_type="RelPosMHAXL"):
+                 dropout=0.0, causal=False, attention_type="RelPosMHAXL", chunk_size=0):
         super().__init__()
+        # chunk_size (BUILD EXTENSION, not in the reference: BASELINE.json configs[4] "chunk=40 frames"): with causal=True and chunk_size > 1
+        # the look-ahead mask becomes block-causal - a frame attends its whole chunk and everything before it; the convolution module and
+        # the front-end stay strictly causal. 0 / 1 = the reference's look-ahead mask.
+        self.chunk_size = int(chunk_size or 0)
         if attention_type != "RelPosMHAXL":
             raise NotImplementedError("the TS-ASR encoder always uses RelPosMHAXL (models/conformer.py:131-132)")
         self.mha_layer = RelPosMHAXL(num_heads=nhead, embed_dim=d_model, dropout=dropout, mask_pos_future=causal)
@@ -530,7 +534,8 @@ class ConformerEncoderLayer(nn.Module):
         y, x = ops.layer_norm_res(x, ln1.weight, ln1.bias, 1e-5)     # x is read twice (here and as the residual): one backward kernel sums both gradients
         h = ops.ffn_core(y, pff1[0].weight, pff1[0].bias, pff1[3].weight, self.slope, p, tr)
         x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
-        o, attn = mha._context(y, pos_embs, valid_lens, self.causal or src_mask is not None, need_attn)
+        causal = self.causal or src_mask is not None
+        o, attn = mha._context(y, pos_embs, valid_lens, (max(self.chunk_size, 1) if causal else 0), need_attn)
         x, y = ops.add_layer_norm(ops.matmul_nt(o, mha.out_proj.weight), mha.out_proj.bias, x, conv.layer_norm)   # + skip ; conv LN
         c = conv.core(y)
         x, y = ops.add_layer_norm(c, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)          # + conv ; ffn2 LN

@@ -1008,11 +1008,11 @@ class _RelPosAttnFn(torch.autograd.Function):
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkvc.device)
         with prof.region("relpos_attn_fwd"):
             C.check(C.lib().tsasr_relpos_attn_fwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(lse),
-                                                  B, T, H, Dh, float(scale), int(bool(causal)), float(pdrop), seed,
+                                                  B, T, H, Dh, float(scale), int(causal), float(pdrop), seed,
                                                   C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc),
                                                   C.stream_ptr()), "tsasr_relpos_attn_fwd")
         ctx.save_for_backward(qkvc, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
-        ctx.cfg = (H, float(scale), bool(causal), float(pdrop), seed)
+        ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed)
         return out
 
     @staticmethod
@@ -1061,8 +1061,9 @@ def _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, 
     idx = torch.arange(T, device=qkv.device)
     rel = (idx[None, :] - idx[:, None] + T - 1).expand(B, H, T, T)
     score = (ac + torch.gather(bd_raw, 3, rel)).float() * scale
-    if causal:
-        score = score.masked_fill(idx[None, :] > idx[:, None], float("-inf"))
+    if causal:   # 1 / True: look-ahead mask; C > 1: block-causal chunks of C frames (build extension, csrc/attention.hip)
+        lim = idx if int(causal) <= 1 else (idx // int(causal) + 1) * int(causal) - 1
+        score = score.masked_fill(idx[None, :] > lim[:, None], float("-inf"))
     if key_lens is not None:
         score = score.masked_fill((idx[None, :] >= key_lens[:, None]).view(B, 1, 1, T), float("-inf"))
     attn = torch.softmax(score, dim=-1)

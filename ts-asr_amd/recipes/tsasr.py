@@ -21,15 +21,49 @@ _OVERLAP_MODE = os.environ.get("TSASR_OVERLAP", "1")
 _OVERLAP_DEFAULT = _OVERLAP_MODE != "0"   # A/B knob: speaker branch + predictor on a second stream
 
 class TSASR(core.Brain):
-    variant = "scratch"  # "scratch" | "pretrained" | "none"
+    """One class for the reference's three recipe scripts; ``variant`` says which speaker branch runs:
+    "scratch" (train_librispeechmix_scratch.py), "pretrained" (train_librispeechmix_pretrained.py, frozen speaker encoder) or "none"
+    (train_librispeechmix_none.py). Taken from hparams["variant"] / run_opts when given, else from what the YAML declares: the
+    pretrained YAML has `speaker_encoder_path` and no speaker front-end (conformer-t_wavlm.yaml:121-123), the `none` YAML no speaker_proj."""
+
+    def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None, profiler=None):
+        super().__init__(modules, opt_class, hparams, run_opts, checkpointer, profiler)
+        hp, ro = hparams or {}, run_opts or {}
+        variant = ro.get("variant", hp.get("variant"))
+        if variant is None:
+            if "speaker_proj" not in self.modules:
+                variant = "none"
+            elif "speaker_encoder_path" in hp or "speaker_frontend" not in self.modules:
+                variant = "pretrained"
+            else:
+                variant = "scratch"
+        if variant not in ("scratch", "pretrained", "none"):
+            raise ValueError(f"unknown TSASR variant {variant!r}")
+        self.variant = variant
 
     # ---- speaker branch (train_librispeechmix_scratch.py:44-80) ------------------------------------
     def _speaker_embedding(self, batch, epoch):
         hp = self.hparams
         if self.variant == "none":
             return None, None
-        if self.variant == "pretrained":  # frozen speaker encoder's output is an input here (WavLM itself is out of scope)
-            embs, lens = batch.enroll_emb
+        if self.variant == "pretrained":
+            # train_librispeechmix_pretrained.py:45-63,80: the frozen speaker encoder's x-vector [B,1,E] (cross_attention: its last hidden
+            # states [B,S,E]) goes through speaker_proj. The embedding arrives with the batch (`enroll_emb`, the synthetic / precomputed
+            # form); a module registered as `speaker_encoder` (Hugging Face AutoModelForAudioXVector signature) is run as the reference does.
+            if hasattr(batch, "enroll_emb"):
+                embs, lens = batch.enroll_emb
+            elif "speaker_encoder" in self.modules:
+                enroll, lens = batch.enroll_sig
+                with torch.no_grad():
+                    self.modules.speaker_encoder.eval()
+                    L = enroll.shape[-1]
+                    n = (lens * L).ceil().clamp(max=L).int()
+                    out = self.modules.speaker_encoder(input_values=enroll, attention_mask=(torch.arange(L, device=enroll.device)[None, :] < n[:, None]).long(),
+                                                       output_attentions=False, output_hidden_states=hp.injection_mode == "cross_attention")
+                embs = (out.hidden_states[-1][..., :hp.speaker_embedding_dim] if hp.injection_mode == "cross_attention"
+                        else out.embeddings[:, None, :])
+            else:
+                raise ValueError("pretrained variant: the batch needs an `enroll_emb` field or modules['speaker_encoder'] must be set")
             return self.modules.speaker_proj(embs), lens
         enroll, enroll_lens = batch.enroll_sig
         if getattr(hp, "input_is_feats", False):
@@ -69,7 +103,7 @@ class TSASR(core.Brain):
         # encoder joins the first lazily at the injection, the joint waits for the second. Backward follows by itself (autograd
         # runs a node on the stream of its forward): the predictor's backward overlaps the last encoder layers', the speaker
         # branch's overlaps layer 0 / the front-end's. Works the same inside a captured hipGraph (fork / join become edges).
-        overlap = (stage == Stage.TRAIN and self.variant == "scratch" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT)
+        overlap = (stage == Stage.TRAIN and self.variant != "none" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT)
                    and torch.device(self.device).type == "cuda")
         dec_out = None
         if overlap:
