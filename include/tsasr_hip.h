@@ -192,6 +192,8 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
  * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
  * p, g, m, v: flat fp32 [n]; p_bf16 (may be NULL): bf16 shadow of p rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
+ * norm_out (may be NULL): DEVICE float[2]: [0] = L2 norm of g before clipping; [1] += 1 when that norm is not finite - the update is then SKIPPED
+ * (parameters and moments untouched; the reference's clip_grad_norm_ would write NaN into every weight, SB/core.py:1082-1093).
  * ------------------------------------------------------------------------------------------ */
 /* dst[i] += src[i] for `count` small fp32 vectors in one launch; table (DEVICE) = [count src ptrs][count dst ptrs][count int32 lengths]. */
 int tsasr_accumulate_many(const void *table, int count, void *stream);
@@ -267,7 +269,8 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
 /* Whole-sequence LSTM recurrences (all U steps of tsasr_lstm_step_fwd / _bwd). bf16, H in {256, 512}, B <= 256: one persistent
  * launch per direction (workgroups exchange h_t / dG_t through write-through stores and an arrival counter); otherwise a loop of
  * the per-step kernels. Replaces the time loop inside torch.nn.LSTM (speechbrain/nnet/RNN.py:244-278). */
-size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H);
+int tsasr_lstm_seq_persistent(int B, int H, int io_dtype);   /* 1: one persistent launch per direction on this device for this shape */
+size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H);   /* first 256 bytes: uint32 {arrival counter, error word} per batch group; a non-zero error word = an inter-workgroup wait timed out (outputs poisoned with NaN) */
 int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, int H, int io_dtype, void *workspace,
                        size_t workspace_bytes, void *stream);
 int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, int H,
@@ -290,6 +293,19 @@ int tsasr_wgrad_pending(void);
 size_t tsasr_wgrad_table_bytes(int max_jobs);
 int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 void tsasr_wgrad_discard(void);
+
+/* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module
+ * DistributedDataParallel reducers (SB/core.py:1464-1484; `no_sync` :1585-1615) and SB/utils/distributed.py:123-201's process-group
+ * collectives for the gradient path. One communicator per process (one process per GPU). librccl is dlopen()ed
+ * (tsasr_allreduce_load; NULL = "librccl.so" on the loader path - pass the copy PyTorch has loaded); rank 0 makes the 128-byte unique
+ * id (tsasr_allreduce_unique_id), the caller ships it to the other ranks, every rank calls tsasr_allreduce_init. A bucket is reduced
+ * IN PLACE on `stream` (sum or average over the ranks), asynchronously and graph-capturably; "wait" is a stream join by the caller. */
+int tsasr_allreduce_load(const char *librccl_path);
+int tsasr_allreduce_unique_id(void *host_id128);
+int tsasr_allreduce_init(const void *host_id128, int nranks, int rank);
+int tsasr_allreduce_ready(void);   /* number of ranks of the communicator, 0 = none */
+int tsasr_allreduce_bucket(void *buf, size_t count, int dtype, int average, void *stream);
+int tsasr_allreduce_destroy(void);
 
 /* Batched deterministic reductions of partial gradient rows / split-K slabs (csrc/reduce.hip). While tsasr_reduce_defer(1) is in
  * force the parameter-gradient outputs of the *_bwd entry points (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias)

@@ -1,0 +1,53 @@
+"""Multi-rank machinery on the one-GPU box. Real RCCL: a one-rank "nccl" group with the arena told there are two ranks, so that the
+bucketed all-reduces are issued during backward, CAPTURED into the step's hipGraph and replayed (tools/rccl_single_rank_check.py, run
+as a child process: a process group per run, never a re-exec of a process that touched the GPU). N > 1 is covered by the gloo tests
+of tests/test_host_cpu.py and stays unmeasured on hardware until a multi-GPU node runs bench.py --gpus N."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DEV = "cuda:0"
+
+
+def test_rccl_collectives_captured_in_graph_and_replayed():
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], env=env, capture_output=True, text=True, timeout=420)
+    sys.stdout.write(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL single-rank path OK" in r.stdout
+
+
+def test_speed_perturbation_varies_under_hip_graph():
+    """`augment: True` + enable_hip_graph(): the speed SpeedPerturb picks per batch (speech_augmentation.py:480-493) must keep varying -
+    drawn on the host before each replay, one graph per (batch shape, speed) - and the run must equal the eager run step for step."""
+    import __graft_entry__ as entry
+    from oracle.golden_recipe import golden_inputs
+    from tests.test_variants_gpu import make_batch
+    inp = golden_inputs()
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(77)                  # the speed draws come from torch's CPU generator, as in the reference
+        importlib.import_module("ts-asr_amd.ops")._seed_dev.clear()
+        brain, h = entry._config1_brain(DEV, "bf16", augment=True)
+        brain.modules.train()
+        if mode == "graph":
+            brain.enable_hip_graph(warmup_steps=2)
+        batch = make_batch(inp).to(DEV)
+        seq, ls = [], []
+        for _ in range(14):
+            ls.append(float(brain.fit_batch(batch)))
+            seq.append(brain.modules.speed_perturb.samp_index)
+        runs[mode] = (seq, ls, len(brain._graphs))
+    seq, ls, ngraphs = runs["graph"]
+    assert len(set(seq)) == 3, seq                      # all three speeds (95 / 100 / 105 %) were used
+    assert seq == runs["eager"][0]                      # the same draws as the eager run
+    assert ngraphs == 3                                 # one captured graph per speed
+    np.testing.assert_allclose(ls, runs["eager"][1], rtol=2e-5)

@@ -127,6 +127,11 @@ def _dp_worker(rank, world, port, out_dir):
     torch.manual_seed(0)
     mods = {"a": torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16)),
             "b": torch.nn.Linear(16, 3)}
+    if rank != 0:       # ranks start from DIFFERENT weights: the arena must adopt rank 0's (the reference's DDP constructor broadcast)
+        with torch.no_grad():
+            for m in mods.values():
+                for p_ in m.parameters():
+                    p_.add_(1.0)
 
     class Toy(core.Brain):
         def compute_forward(self, batch, stage):
@@ -145,7 +150,8 @@ def _dp_worker(rank, world, port, out_dir):
     for step, (x, y) in enumerate(data):   # each rank trains on its half of every batch
         brain.fit_batch((x[rank::world], y[rank::world]))
     torch.save({k: v.clone() for k, v in brain.modules.state_dict().items()}, os.path.join(out_dir, f"w{rank}.pt"))
-    torch.save({"steps": brain.optimizer_step, "buckets": len(brain.arena.buckets)}, os.path.join(out_dir, f"m{rank}.pt"))
+    torch.save({"steps": brain.optimizer_step, "buckets": len(brain.arena.buckets),
+                "order": [[id(q) for q in brain.arena.params_initial].index(id(p_)) for p_ in brain.arena.params_ordered]}, os.path.join(out_dir, f"m{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -158,6 +164,7 @@ def test_data_parallel_arena_gloo_world2(tmp_path):
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k                          # ranks stay in lock-step
     assert torch.load(tmp_path / "m0.pt")["steps"] == 3               # 6 micro-batches / accumulation 2
+    assert torch.load(tmp_path / "m0.pt")["order"] == torch.load(tmp_path / "m1.pt")["order"]   # every rank laid its arena out in rank 0's order
     # single-process reference on the full batches
     core = importlib.import_module("ts-asr_amd.core")
     torch.manual_seed(0)
@@ -311,3 +318,43 @@ def test_no_swapped_opsel_packed_fp32_in_device_code(tmp_path):
         hits = [l.strip() for l in asm.splitlines() if bad.search(l)]
         assert not hits, f"{os.path.basename(o)}: {hits[:3]}"
     assert n_pk > 0   # the disassembly really saw packed fp32 code
+
+
+def _dp_bf16_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dp = importlib.import_module("ts-asr_amd.dp")
+    dp.ddp_init_group({"distributed_launch": True, "distributed_backend": "gloo"})
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleDict({"a": torch.nn.Linear(64, 64), "b": torch.nn.Linear(64, 8)})
+    out = {}
+    for dtype in ("fp32", "bf16"):
+        arena = dp.GradArena(mods, world_size=world, bucket_bytes=4096)
+        arena.comm_dtype = dtype
+        arena._order_final = True
+        g = torch.Generator().manual_seed(5 + rank)
+        x = torch.randn(16, 64, generator=g)
+        arena.grads.zero_()
+        arena.begin_backward(True)
+        mods["b"](torch.tanh(mods["a"](x))).square().mean().backward()
+        arena.finish_backward()
+        out[dtype] = arena.grads.clone()
+        out[dtype + "_sent"] = len(arena.sent_log)
+        for h_ in arena._hooks:
+            h_.remove()
+    torch.save(out, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bf16_allreduce_payload_gloo_world2(tmp_path):
+    """TSASR_ALLREDUCE_DTYPE=bf16: buckets are rounded to bf16, averaged and written back into the fp32 arena - every rank ends with the
+    same gradients, within bf16 rounding of the fp32-payload average; the same number of bucket collectives is issued."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_dp_bf16_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert torch.equal(g0["fp32"], g1["fp32"]) and torch.equal(g0["bf16"], g1["bf16"])
+    assert g0["fp32_sent"] == g0["bf16_sent"] >= 2
+    rel = float((g0["bf16"] - g0["fp32"]).norm() / g0["fp32"].norm())
+    assert 0 < rel < 8e-3, rel

@@ -83,6 +83,7 @@ _PROTOS = {
     "tsasr_add_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
     "tsasr_add_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
     "tsasr_add_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_lstm_seq_persistent": (c_int, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_lstm_seq_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
@@ -92,6 +93,12 @@ _PROTOS = {
     "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
     "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_reduce_flush_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),
+    "tsasr_allreduce_unique_id": (c_int, [c_void_p]),
+    "tsasr_allreduce_init": (c_int, [c_void_p, c_int, c_int]),
+    "tsasr_allreduce_ready": (c_int, []),
+    "tsasr_allreduce_bucket": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "tsasr_allreduce_destroy": (c_int, []),
     "tsasr_wgrad_queue": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3),
     "tsasr_wgrad_pending": (c_int, []),
     "tsasr_wgrad_table_bytes": (c_size_t, [c_int]),

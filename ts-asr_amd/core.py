@@ -29,6 +29,7 @@ logger = logging.getLogger(__name__)
 
 
 _EARLY_FLUSH = os.environ.get("TSASR_EARLY_FLUSH", "0") != "0"   # A/B knob (measured neutral on the step: off by default)
+_GRAPH_COMM = os.environ.get("TSASR_GRAPH_COMM", "1") != "0"     # multi-rank graph mode: bucketed all-reduces captured inside the step's graph
 
 class Stage(enum.Enum):
     TRAIN = enum.auto()
@@ -146,7 +147,8 @@ class Brain:
         if self.compute_dtype is None:
             self.compute_dtype = "bf16" if (self.auto_mix_prec and self.bfloat16_mix_prec) else "fp32"
         self.valid_step = self.step = self.optimizer_step = 0
-        self.nonfinite_count = 0
+        self.nonfinite_count, self.skipped_steps = 0, 0
+        self.nonfinite_flush_every = 100     # steps between host reads of the device-side non-finite counters (the reference checks every step)
         self._nonfinite_dev = None
         self.avg_train_loss = 0.0
         self.grad_norm_epoch = []
@@ -200,6 +202,8 @@ class Brain:
         # backward produces them (dp.GradArena docstring)
         self.arena = _dp.GradArena(self.modules, world_size=_dp.world_size() if self.distributed else 1)
         self.arena.aux_streams = self._aux_streams     # same list object: streams the recipe forks register themselves there
+        if self.distributed:
+            self.arena.broadcast_parameters()          # identical initial weights on every rank (reference: DDP's constructor broadcast)
         self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm)
         from . import ops as _ops
         _ops.set_grad_sink(self.arena)
@@ -250,8 +254,8 @@ class Brain:
             torch.cuda.current_stream().wait_stream(s)
         self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
         if should_step and (comm or not self.distributed):
-            if comm:
-                self.optimizer.prepare()
+            if comm and not (torch.device(self.device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                self.optimizer.prepare()      # host half (step count, lr -> device): never inside a capture (_fit_batch_graph does it before a replay)
             self.optimizer.launch()           # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
             self.arena.zero_()
         return loss.detach(), outputs
@@ -262,8 +266,11 @@ class Brain:
         ~1000 launches collapse into one graph launch. One graph per distinct set of batch tensor shapes (and per flavour, see
         _fit_batch_graph), up to ``max_shapes`` shapes: with length-bucketed batches padded to the bucket edge
         (dataio.DynamicBatchSampler) a real epoch replays a handful of graphs; all graphs share one memory pool (they never run
-        concurrently). A shape beyond the cap runs eagerly. With more than one rank the gradient all-reduce runs between two
-        graphs (forward+backward | optimizer)."""
+        concurrently). A shape beyond the cap runs eagerly. With more than one rank the bucketed gradient all-reduces are CAPTURED with
+        the step (RCCL kernels as graph nodes on the communication stream, launched when a bucket's gradients are complete, joined before
+        the optimizer): the replayed step issues exactly the collectives an eager step issues, in the same order, so ranks may mix eager
+        and replayed steps freely (length-bucketed batches: one rank meets a new shape while another replays). TSASR_GRAPH_COMM=0 restores
+        round 1's form (ONE un-overlapped all-reduce between the captured step and the optimizer) for A/B runs."""
         self._graph_mode, self._graph_warmup, self._graph_max_shapes = True, int(warmup_steps), int(max_shapes)
 
     @staticmethod
@@ -275,10 +282,20 @@ class Brain:
                 key.append((k,) + tuple(tuple(t.shape) for t in v))
         return tuple(key)
 
+    def _host_draws(self):
+        """Random choices the reference makes on the HOST inside compute_forward (SpeedPerturb's speed: speech_augmentation.py:480-493)
+        are made here, before the step, and become part of the graph key: one captured graph per (batch shape, speed) - the resampled
+        length differs per speed anyway - instead of the capture-time choice replayed for ever."""
+        hp = self.hparams
+        if (getattr(hp, "augment", False) and not getattr(hp, "input_is_feats", False) and "speed_perturb" in self.modules
+                and self.modules.training):
+            return (("speed_perturb",) + tuple(self.modules["speed_perturb"].draw()),)
+        return ()
+
     def _fit_batch_graph(self, batch, should_step=True):
         """Two flavours per batch shape: the micro-step that only accumulates gradients and the one that also clips / steps / clears
         (gradient accumulation: grad_accumulation_factor - 1 replays of the first, one of the second)."""
-        key = self._shape_key(batch)
+        key = self._shape_key(batch) + self._host_draws()
         full = key not in self._static_batches and len(self._static_batches) >= self._graph_max_shapes
         first = key not in self._seen_shapes      # a new shape runs eagerly once: per-shape caches (positional tables, ...) must be
         self._seen_shapes.add(key)                # filled outside a capture, where their memory would belong to the graph pool
@@ -301,7 +318,7 @@ class Brain:
             self._copy_batch(batch, key)
         self._graphs[flavour].replay()
         if should_step:
-            if self.distributed:                # one big averaged all-reduce between the two halves of the step
+            if self.distributed and not _GRAPH_COMM:   # A/B form: one big averaged all-reduce between the two halves of the step
                 self.arena.allreduce_all()
                 self.optimizer.launch()
                 self.arena.zero_()
@@ -319,7 +336,7 @@ class Brain:
         # invalidating the capture (single rank keeps the strict default)
         mode = "thread_local" if self.distributed else "global"
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
-            loss, _ = self._device_step(self._static_batches[key], should_step, comm=False)
+            loss, _ = self._device_step(self._static_batches[key], should_step, comm=self.distributed and _GRAPH_COMM)
         from . import ops as _ops
         _ops.upload_captured_tables()             # job tables of the captured flushes: uploaded once, now (replays carry no memcpy node)
         self.arena.upload_captured_tables()
@@ -351,6 +368,13 @@ class Brain:
         if self._nonfinite_dev is not None:
             self.nonfinite_count += int(self._nonfinite_dev.item())
             self._nonfinite_dev.zero_()
+        if self.optimizer is not None and hasattr(self.optimizer, "take_skipped_steps"):
+            self.skipped_steps += self.optimizer.take_skipped_steps()   # non-finite gradient norm: the fused optimizer left the weights alone
+        if "cuda" in self.device:
+            from . import ops as _ops
+            if _ops.lstm_timeouts():
+                raise RuntimeError("persistent LSTM kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
+                                   "set TSASR_LSTM_PERSISTENT=0 to use the per-step kernels")
         if self.nonfinite_count > self.nonfinite_patience:
             raise ValueError("Loss is not finite and patience is exhausted.")
         return self.nonfinite_count
@@ -371,6 +395,8 @@ class Brain:
                 loss = self.fit_batch(batch)
                 total = loss if total is None else total + loss
                 n += 1
+                if self.nonfinite_flush_every and n % self.nonfinite_flush_every == 0:
+                    self.flush_nonfinite()   # raises as the reference does once patience is exceeded (SB/core.py:1115-1150), at most that many steps late
                 if self.optimizer_step_limit is not None and self.optimizer_step >= self.optimizer_step_limit:
                     break
             self.flush_nonfinite()

@@ -8,6 +8,8 @@
 // h [B, U, H] in the activation dtype (it is the next step's GEMM operand and the layer output).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: 5 transcendentals per cell sit on the recurrence's critical path
@@ -492,9 +494,30 @@ size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H) {
     return 256 + align_up(G * U * 32 * 4 * (size_t)H * sizeof(bf16_t), 256) + align_up((size_t)B * H * sizeof(float), 256);
 }
 
-static bool seq_persistent_ok(int B, int H, int io_dtype) {   // sync words: 2 per batch group in a 256-byte block; all workgroups resident
-    return io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, LQ_BR) <= 16 && cdiv(B, LQ_BR) * (H / LQ_UN) <= 256;
+// compute units of the current device (partitioned / CU-masked devices report fewer than the full chip's 256)
+static int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
 }
+
+// The persistent kernels spin-wait between workgroups: every workgroup of the grid must be resident at once. One workgroup fits a CU
+// (96 KB of dynamic LDS, launch bound 1), so the grid may not exceed the CUs THIS device exposes; otherwise the per-step kernels run.
+static bool seq_persistent_ok(int B, int H, int io_dtype) {   // sync words: 2 per batch group in a 256-byte block
+    static const int force_off = getenv("TSASR_LSTM_PERSISTENT") ? (atoi(getenv("TSASR_LSTM_PERSISTENT")) == 0) : 0;
+    return !force_off && io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, LQ_BR) <= 16 &&
+           cdiv(B, LQ_BR) * (H / LQ_UN) <= device_cu_count();
+}
+
+/* 1 when tsasr_lstm_seq_fwd/bwd run as ONE persistent launch for this shape on the current device (the workspace's first 256 bytes
+ * are then the {arrival counter, error word} pairs), 0 when they loop over the per-step kernels. */
+int tsasr_lstm_seq_persistent(int B, int H, int io_dtype) { return seq_persistent_ok(B, H, io_dtype) ? 1 : 0; }
 
 /* The whole forward recurrence (t = 0 .. U-1) of tsasr_lstm_step_fwd. bf16 with H in {256, 512} and B <= 256: ONE persistent launch
  * (csrc/lstm.hip, "Whole-sequence persistent kernels"); otherwise the per-step kernels in a loop. workspace: tsasr_lstm_seq_workspace_bytes. */

@@ -15,6 +15,7 @@ process group. Here instead:
     ``require_backward_grad_sync = False`` (core.py:1585-1615).
 No data-path collective other than this one exists on the path.
 """
+import ctypes
 import os
 
 import torch
@@ -44,6 +45,36 @@ def ddp_init_group(run_opts):
     dist.init_process_group(backend=backend)
 
 
+_DIRECT = {"ranks": 0}
+
+
+def direct_rccl_init(world, rank, device, force=False):
+    """One RCCL communicator per process through the C-ABI (csrc/comm.hip), next to torch.distributed's process group: the unique id
+    is made on rank 0 and travels through the process group (one 128-byte broadcast). Returns the communicator's rank count, 0 when
+    the backend is not RCCL ("gloo" rehearsals keep torch.distributed collectives) or TSASR_RCCL_DIRECT=0."""
+    if _DIRECT["ranks"]:
+        return _DIRECT["ranks"]
+    if os.environ.get("TSASR_RCCL_DIRECT", "1") == "0" or torch.device(device).type != "cuda":
+        return 0
+    if not force and not (is_initialized() and dist.get_backend() == "nccl"):
+        return 0
+    from . import _capi as C
+    lib = C.lib()
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")   # the copy PyTorch ships (already mapped once RCCL is in use)
+    C.check(lib.tsasr_allreduce_load(path.encode() if os.path.exists(path) else None), "tsasr_allreduce_load")
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        C.check(lib.tsasr_allreduce_unique_id(C.ptr(uid)), "tsasr_allreduce_unique_id")
+    if world > 1:
+        box = [uid.numpy().tobytes()]
+        dist.broadcast_object_list(box, src=0)
+        uid = torch.frombuffer(bytearray(box[0]), dtype=torch.uint8).clone()
+    torch.cuda.set_device(torch.device(device))
+    C.check(lib.tsasr_allreduce_init(C.ptr(uid), world, rank), "tsasr_allreduce_init")
+    _DIRECT["ranks"] = world
+    return world
+
+
 class GradArena:
     def __init__(self, modules, world_size=1, bucket_bytes=32 << 20, group=None):
         seen, params = set(), []
@@ -54,7 +85,15 @@ class GradArena:
         if not params:
             raise ValueError("no trainable parameters")
         self.params_ordered = params
+        self.params_initial = list(params)          # construction order: the same on every rank (index space of _agree_order)
         self.world_size, self.group, self.bucket_bytes = world_size, group, bucket_bytes
+        # payload of the gradient all-reduce: "fp32" (the reference's DDP) or "bf16" (half the xGMI bytes: a bucket is rounded to bf16,
+        # averaged, and written back; the arena and the optimizer stay fp32)
+        self.comm_dtype = os.environ.get("TSASR_ALLREDUCE_DTYPE", "fp32")
+        # direct RCCL communicator (csrc/comm.hip) when the process group's backend is RCCL: the bucket all-reduces are then plain launches
+        # on self.comm_stream - the form that can be captured into the step's hipGraph; else torch.distributed (gloo rehearsals, CPU tests)
+        self.direct = bool(world_size > 1 and direct_rccl_init(world_size, dist.get_rank() if is_initialized() else 0, params[0].device))
+        self.comm_stream = None
         self.device = params[0].device
         self.numel = sum(p.numel() for p in params)
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
@@ -65,7 +104,7 @@ class GradArena:
         self.sync_enabled = True
         self._sync_this_step = False
         self._order_seen, self._order_final = [], False
-        self._handles = []
+        self._handles, self.sent_log = [], []
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_ring = [], None, None
@@ -236,7 +275,7 @@ class GradArena:
             ops.reduce_defer_begin(self.device)
         for b in self.buckets:
             b["left"], b["sent"], b["queued"] = len(b["ids"]), False, 0
-        self._handles = []
+        self._handles, self.sent_log = [], []
 
     def _on_grad(self, p):
         if not self._order_final:
@@ -263,10 +302,23 @@ class GradArena:
             for st in [self._main_stream] + list(self.aux_streams):
                 if st is not None and st != cur:
                     cur.wait_stream(st)
+        payload = chunk.to(torch.bfloat16) if self.comm_dtype == "bf16" else chunk
+        back = chunk if payload is not chunk else None
+        if self.direct:   # bare ncclAllReduce on the communication stream (csrc/comm.hip): capturable, no watchdog, ordered by stream joins only
+            from . import _capi as C
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=self.device)
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            C.check(C.lib().tsasr_allreduce_bucket(C.ptr(payload), payload.numel(), C.BF16 if payload.dtype == torch.bfloat16 else C.F32, 1,
+                                                   ctypes.c_void_p(self.comm_stream.cuda_stream)), "tsasr_allreduce_bucket")
+            self._handles.append((None, None, payload, back))
+            self.sent_log.append((b["lo"], b["hi"]))
+            return
         if dist.get_backend(self.group) == "nccl":
-            self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+            self._handles.append((dist.all_reduce(payload, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, payload, back))
         else:  # gloo has no AVG
-            self._handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+            self._handles.append((dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group, async_op=True), self.world_size, payload, back))
+        self.sent_log.append((b["lo"], b["hi"]))
 
     def finish_backward(self):
         if self.device.type == "cuda":
@@ -278,10 +330,15 @@ class GradArena:
         if self._sync_this_step:
             for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step
                 self._send(b)
-            for h, chunk in self._handles:
-                h.wait()
-                if chunk is not None:
-                    chunk.div_(self.world_size)
+            if self.direct and self.comm_stream is not None and self._handles:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)   # "wait" = one join of the communication stream
+            for h, div, payload, back in self._handles:
+                if h is not None:
+                    h.wait()
+                if div is not None:
+                    payload.div_(div)
+                if back is not None:          # bf16 payload: the averaged bucket goes back into the fp32 arena
+                    back.copy_(payload)
             self._handles = []
         if not self._order_final and self._order_seen:
             self._finalize_order()
@@ -302,8 +359,32 @@ class GradArena:
             for p in self.params_ordered:  # parameters that never produced a gradient go last
                 if id(p) not in seen:
                     order.append(p)
+            order = self._agree_order(order)
             self._layout(order)
             self._order_final, self._reorder_pending, self._order_seen = True, False, []
+
+    def _agree_order(self, order):
+        """Every rank must cut the SAME buckets: rank 0's recorded backward order is broadcast (as indices into the construction
+        order, which is identical on every rank) and adopted by all - the reference's DDP does the same when it rebuilds its buckets."""
+        if self.world_size <= 1 or not is_initialized():
+            return order
+        index = {id(p): i for i, p in enumerate(self.params_initial)}
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        idx = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=dev)
+        dist.broadcast(idx, 0, group=self.group)
+        return [self.params_initial[i] for i in idx.cpu().tolist()]
+
+    def broadcast_parameters(self):
+        """Rank 0's parameter values to every rank (the reference's DDP constructor does this: SB/core.py:1464-1484)."""
+        if self.world_size <= 1 or not is_initialized():
+            return
+        if dist.get_backend(self.group) == "nccl" or self.device.type == "cpu":
+            dist.broadcast(self.flat_params, 0, group=self.group)
+        else:
+            t = self.flat_params.cpu()
+            dist.broadcast(t, 0, group=self.group)
+            self.flat_params.copy_(t)
+        self.refresh_shadow()
 
     def allreduce_all(self):
         """Average the whole arena over the ranks (graph mode: between the captured step and the optimizer)."""

@@ -286,11 +286,22 @@ class SpeedPerturb(nn.Module):
         self.samp_index = 0
         self.resamplers = [Resample(orig_freq=orig_freq, new_freq=orig_freq * speed // 100) for speed in self.speeds]
 
+    def draw(self):
+        """The reference's two CPU draws for the NEXT forward (torch.rand(1) against perturb_prob, torch.randint over the speeds),
+        taken ahead of it: the host picks the speed before a hipGraph replay and the Brain keys its graphs by the result - a draw made
+        inside a captured forward would be frozen into every replay. Returns (skip, speed index)."""
+        skip = bool(torch.rand(1) > self.perturb_prob)
+        if not skip:
+            self.samp_index = int(torch.randint(len(self.speeds), (1,))[0])
+        self._pending = (skip, self.samp_index)
+        return self._pending
+
     def forward(self, waveform):
-        if torch.rand(1) > self.perturb_prob:
+        skip, idx = self._pending if getattr(self, "_pending", None) is not None else self.draw()
+        self._pending = None
+        if skip:
             return waveform.clone()
-        self.samp_index = int(torch.randint(len(self.speeds), (1,))[0])
-        return self.resamplers[self.samp_index](waveform)
+        return self.resamplers[idx](waveform)
 
 # ------------------------------------------------------------------------------------------------------
 # A3 convolutional front-end

@@ -458,6 +458,23 @@ def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
     return bias_act_dropout(matmul_nt(x, weight), bias, act_slope, dropout_p, training)
 
 
+_LSTM_WS = []   # sync blocks of the most recent persistent-recurrence launches (error words: include/tsasr_hip.h, tsasr_lstm_seq_workspace_bytes)
+
+
+def _note_lstm_ws(ws):
+    _LSTM_WS.append(ws[:256])
+    del _LSTM_WS[:-4]
+
+
+def lstm_timeouts():
+    """Number of raised error words in the kept sync blocks (a host read): > 0 means a persistent LSTM launch gave up waiting for
+    another workgroup - its outputs were poisoned with NaN, the optimizer skipped that step; the caller should raise."""
+    n = 0
+    for blk in _LSTM_WS:
+        n += int((blk.view(torch.int32)[1::2] != 0).sum().item())
+    return n
+
+
 class _LstmFn(torch.autograd.Function):
     """Single-layer LSTM over [B,U,I] in bf16: input projection = HIP GEMM (the 28 embedding columns padded to 32, bias folded into the
     padding), recurrence = one persistent HIP kernel per direction (H in {256, 512}; else per-step HIP GEMM + cell kernel); the
@@ -489,6 +506,8 @@ class _LstmFn(torch.autograd.Function):
         whh16 = _bf16_weight(w_hh).contiguous()
         lib, st = C.lib(), C.stream_ptr()
         ws = _ws(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dev)
+        if lib.tsasr_lstm_seq_persistent(B, H, C.BF16):
+            _note_lstm_ws(ws)
         with prof.region("lstm_fwd"):   # the whole recurrence: one persistent launch (H in {256, 512}), else one fused launch per step
             C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh16), B, U, H, C.BF16, C.ptr(ws), ws.numel(), st),
                     "tsasr_lstm_seq_fwd")
@@ -512,6 +531,8 @@ class _LstmFn(torch.autograd.Function):
             whhT = whh16.t().contiguous()
         lib, st = C.lib(), C.stream_ptr()
         ws = _ws(lib.tsasr_lstm_seq_workspace_bytes(B, U, H), dev)
+        if lib.tsasr_lstm_seq_persistent(B, H, C.BF16):
+            _note_lstm_ws(ws)
         with prof.region("lstm_bwd"):   # dh = dout[:, t] + dgates[:, t+1] . W_hh, cell backward, t = U-1 .. 0 in one launch
             C.check(lib.tsasr_lstm_seq_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), B, U, H, C.BF16,
                                            C.ptr(ws), ws.numel(), st), "tsasr_lstm_seq_bwd")

@@ -28,7 +28,8 @@ class FusedClipAdamW:
         self.exp_avg_sq = torch.zeros_like(arena.grads)
         arena.companions += [self.exp_avg, self.exp_avg_sq]  # follow the arena's one-time re-layout
         self.t = 0
-        self.last_grad_norm = torch.zeros((), device=arena.device)  # device scalar, never synced in the step
+        self._norm_buf = torch.zeros(2, device=arena.device)        # [grad norm, steps skipped for a non-finite norm]: device memory, never synced in the step
+        self.last_grad_norm = self._norm_buf[0]
         self._hyper_host = self._hyper_dev = self._ws = None
 
     def prepare(self):
@@ -65,7 +66,7 @@ class FusedClipAdamW:
         C.require_gpu(a.flat_params)
         with prof.region("clip_adamw"):
             C.check(C.lib().tsasr_clip_adamw_step(C.ptr(a.flat_params), C.ptr(a.flat_params16), C.ptr(a.grads), C.ptr(self.exp_avg),
-                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self.last_grad_norm), a.numel,
+                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self._norm_buf), a.numel,
                                                   float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.max_grad_norm,
                                                   C.ptr(self._ws), self._ws.numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
             a.refresh_transposed()
@@ -73,6 +74,13 @@ class FusedClipAdamW:
     def step(self):
         self.prepare()
         self.launch()
+
+    def take_skipped_steps(self):
+        """Steps the kernel skipped because the gradient norm was not finite, since the last call (one host read)."""
+        n = int(self._norm_buf[1].item())
+        if n:
+            self._norm_buf[1].zero_()
+        return n
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
