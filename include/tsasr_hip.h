@@ -294,6 +294,16 @@ size_t tsasr_wgrad_table_bytes(int max_jobs);
 int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 void tsasr_wgrad_discard(void);
 
+/* Recipe glue on the device (csrc/misc.hip), each ONE launch instead of a chain of tiny library kernels:
+ * tsasr_mean_pool_*: masked mean over time of the speaker encoder's output (train_librispeechmix_scratch.py:52-64);
+ * tsasr_abs_lengths: relative -> absolute lengths (round half to even: models/conformer.py:272, SB/nnet/losses.py:58-59; floor:
+ *   SB/nnet/RNN.py:35; ceil clamped: train_librispeechmix_scratch.py:54-58) for up to 8 vectors at once;
+ * tsasr_count_nonfinite: the non-finite-loss counter of SB/core.py:1115-1150 kept on the device. */
+int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T, int D, int io_dtype, void *stream);
+int tsasr_mean_pool_bwd(const void *dout, const float *rel, void *dx, int B, int T, int D, int io_dtype, void *stream);
+int tsasr_abs_lengths(const float *const *rel, int *const *out, const int *dim, const int *mode, int n, int B, void *stream);
+int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);
+
 /* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module
  * DistributedDataParallel reducers (SB/core.py:1464-1484; `no_sync` :1585-1615) and SB/utils/distributed.py:123-201's process-group
  * collectives for the gradient path. One communicator per process (one process per GPU). librccl is dlopen()ed

@@ -32,5 +32,5 @@ for e in prof.events():
     agg[(e.name, src)][0] += 1
     agg[(e.name, src)][1] += t
 print(f"{'op':28s} {'calls':>5s} {'gpu us':>8s}  source")
-for (name, src), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for (name, src), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     print(f"{name:28s} {n:5d} {t:8.0f}  {src}")

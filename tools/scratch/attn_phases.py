@@ -23,8 +23,8 @@ for _ in range(2):
     C.check(lib.tsasr_relpos_attn_fwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, T, H, Dh, 1 / 16.0, 0, 0.0, 0,
                                       None, C.BF16, C.stream_ptr()), "fwd")
 torch.cuda.synchronize()
-fst = lse.view(-1)[:12].view(torch.int64).cpu().tolist()
-fnames = ["prologue", "staging", "AC + G mfma, G store", "skew read / softmax / P", "P.V (last sub-block)", "epilogue"]
+fst = lse.view(-1)[:14].view(torch.int64).cpu().tolist()
+fnames = ["DMA issue + q loads", "wait staged tiles", "AC + G mfma, G store", "skew read / softmax / P", "P.V", "barrier before merge", "merge + epilogue"]
 ftot = sum(fst)
 print("fwd wave 1 of workgroup 0, cycles:")
 for n, c in zip(fnames, fst):

@@ -93,6 +93,10 @@ _PROTOS = {
     "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
     "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_reduce_flush_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_mean_pool_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "tsasr_mean_pool_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "tsasr_abs_lengths": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "tsasr_count_nonfinite": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),
     "tsasr_allreduce_unique_id": (c_int, [c_void_p]),
     "tsasr_allreduce_init": (c_int, [c_void_p, c_int, c_int]),

@@ -28,7 +28,10 @@ class _SrcModule(nn.Module):
         self.layers = nn.ModuleList([Linear(input_size=input_size, n_neurons=d_model, bias=True, combine_dims=False), nn.Dropout(dropout)])
 
     def forward(self, x):
-        return self.layers[1](self.layers[0](x))
+        lin, drop = self.layers[0], self.layers[1]
+        if x.ndim == 4 and lin.combine_dims:
+            x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+        return ops.linear(_cd(x), lin.w.weight, lin.w.bias, None, drop.p, self.training)   # bias + Dropout in ONE epilogue pass
 
 
 class _SpeakerAttention(nn.Module):

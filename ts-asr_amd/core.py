@@ -360,7 +360,11 @@ class Brain:
         """Counts non-finite losses on the device (reference: counted, the step is NOT skipped; core.py:1115-1150)."""
         if self._nonfinite_dev is None:
             self._nonfinite_dev = torch.zeros((), dtype=torch.int32, device=loss.device)
-        self._nonfinite_dev.add_((~torch.isfinite(loss.detach())).to(torch.int32).reshape(()))
+        if loss.is_cuda:
+            from . import ops as _ops
+            _ops.count_nonfinite(loss, self._nonfinite_dev)      # one launch (torch.isfinite alone is five)
+        else:
+            self._nonfinite_dev.add_((~torch.isfinite(loss.detach())).to(torch.int32).reshape(()))
         return True
 
     def flush_nonfinite(self):

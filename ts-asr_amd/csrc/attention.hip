@@ -50,6 +50,15 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // block-causal, a frame sees its whole chunk of C frames and everything before it. Last key query i may attend:
 __device__ __forceinline__ int causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
 
+// Opaque to the optimiser: the value must exist in a register HERE. Used on LDS reads whose only consumer sits behind a mask test:
+// left alone, hipcc sinks each read into the branch that uses it - 16 guarded reads = 16 serialized LDS round trips per 32 x 32 score
+// block (s_and_saveexec / ds_read / s_waitcnt lgkmcnt(0) each; "a guarded load is a serialized load") - 49 % of the forward
+// kernel's cycles sat in that phase.
+__device__ __forceinline__ float pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) {
@@ -279,12 +288,14 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             __builtin_amdgcn_wave_barrier();
             ATF_STAMP(2);   // AC + G MFMAs, G tile to LDS
             // ---- scores for this lane's query: 16 keys j = jb + (g&3) + 8(g>>2) + 4hh ; BD via the skewed read
-            float sc[16];
+            float sc[16], bdv[16];
             float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
-                const float bd = g_lds[(jl - r + 31) * 32 + r];
+                const float bd = bdv[g];
                 const int j = jb + jl;
                 float x = (s_acc[g] + bd) * scale;
                 if (j >= len || (causal && j > causal_limit(iq, causal))) x = -INFINITY;
@@ -361,6 +372,249 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
 #endif
 }
 
+
+
+// =====================================================================================================================
+// Forward for short sequences (T <= 256: the mixture encoder's T' = 250 and the speaker encoder's 125 at BASELINE configs[1]),
+// bf16, Dh = 64. The streaming kernel above runs ONE wave per SIMD there (256 workgroups x 4 waves on 256 CUs) through four
+// key tiles of [stage through registers -> barrier -> MFMA -> G tile through LDS -> softmax]: stamped, 49 % of a wave's cycles
+// sit in the softmax phase, 24 % in staging, 22 % around the MFMAs - serial latencies that nothing else on the SIMD covers. Here
+//   * everything a workgroup needs is staged ONCE by LDS-DMA (inline-asm global_load_lds_dwordx4, see csrc/wgrad.hip): all K and V
+//     rows of the (b, h) pair, and the band of positional rows its queries can reach - 32 + 32 + 48 KiB at T' = 250;
+//   * a workgroup is 8 waves = (query blocks of 32) x (key parts): 4 x 2 for 128 queries (T' > 128), 2 x 4 for 64 queries; two
+//     waves per SIMD cover each other's LDS / transcendental latencies; the key parts of a query block are merged at the end
+//     through LDS with the usual (m, l, O) rescale;
+//   * the band products are ROLLED: the 64 band rows a 32 x 32 block of scores needs overlap the next block's by 32, so each
+//     sub-block computes one new 32-row G block (4 MFMAs) instead of two; G tiles live in LDS as fp16 (4 KiB per wave: the
+//     rounding, 2^-11 relative, is far below that of the bf16 operands).
+// Same arithmetic, masks, dropout stream and outputs as relpos_attn_fwd_kernel.
+// =====================================================================================================================
+__device__ __forceinline__ void at_dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int QH>   // queries per workgroup: 128 (keys padded to 256, 2 key parts) or 64 (keys padded to 128, 4 key parts)
+__global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
+                                                                       const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                       const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
+                                                                       float *__restrict__ lse, int Tn, int H, float scale, int causal,
+                                                                       float pdrop, unsigned long long seed,
+                                                                       const unsigned long long *__restrict__ seed_dev) {
+    constexpr int Dh = 64, NQB = QH / 32, NKP = 8 / NQB, TPAD = 2 * QH, KP = TPAD / NKP, NB = QH + TPAD;   // NB band rows staged
+    constexpr int K_OFF = 0, V_OFF = TPAD * 128, P_OFF = 2 * TPAD * 128, G_OFF = P_OFF + NB * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (seed_dev) seed += *seed_dev;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * QH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const int qb = wave % NQB, kp = wave / NQB;
+    const int D = H * Dh;
+    const long long row_stride = 3LL * D;
+    const bf16_t *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+#ifdef AT_PROFILE
+    long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#define ATS_STAMP(i) do { const long long n_ = clock64(); sacc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define ATS_STAMP(i)
+#endif
+    // ---- stage K, V (all keys) and the band: piece = 8 rows x 128 B; LDS slot (row, pos) <- global chunk pos ^ swizzle(row)
+    {
+        const int prow = lane >> 3, pos = lane & 7;
+        const int r_lo = (Tn - 1) - (i0 + QH - 1);
+        for (int pc = wave; pc < (2 * TPAD + NB) / 8; pc += 8) {
+            const void *g;
+            unsigned dst;
+            if (pc < TPAD / 8) {                     // K: row-wise b128 fragment reads
+                const int row = pc * 8 + prow;
+                g = q_base + (long long)min(row, Tn - 1) * row_stride + Dh + ((pos ^ ((row >> 1) & 7)) << 3);
+                dst = K_OFF + pc * 1024;
+            } else if (pc < 2 * TPAD / 8) {          // V: transposing reads (k = key)
+                const int pv = pc - TPAD / 8, row = pv * 8 + prow;
+                g = q_base + (long long)min(row, Tn - 1) * row_stride + 2 * Dh + ((pos ^ (((row >> 1) & 1) << 2)) << 3);
+                dst = V_OFF + pv * 1024;
+            } else {                                 // band rows r_lo + R, clamped into the table (out-of-table rows only meet masked keys)
+                const int pp = pc - 2 * TPAD / 8, row = pp * 8 + prow;
+                g = pk + (long long)min(max(r_lo + row, 0), 2 * Tn - 2) * D + (long long)h * Dh + ((pos ^ ((row >> 1) & 7)) << 3);
+                dst = P_OFF + pp * 1024;
+            }
+            at_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + dst));
+        }
+    }
+    // ---- this lane's query: Q + u, Q + v as B operands (dims 16s + 8hh + [0,8))
+    const int iq = i0 + 32 * qb + r, iqc = min(iq, Tn - 1);
+    bf16x8 qu[4], qv[4];
+    {
+        float q8[4][8], u8[4][8], v8[4][8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            ld8(q_base + (long long)iqc * row_stride + 16 * s + 8 * hh, q8[s]);
+            ld8(bias_u + h * Dh + 16 * s + 8 * hh, u8[s]);
+            ld8(bias_v + h * Dh + 16 * s + 8 * hh, v8[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qu[s][j] = (bf16_t)(q8[s][j] + u8[s][j]);
+                qv[s][j] = (bf16_t)(q8[s][j] + v8[s][j]);
+            }
+    }
+    ATS_STAMP(0);   // DMA issue + q loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ATS_STAMP(1);   // wait for the staged tiles
+
+    f32x16 o_acc[2];
+    o_acc[0] = (f32x16){0};
+    o_acc[1] = (f32x16){0};
+    float m_run = -INFINITY, l_run = 0.f;
+    const unsigned thr = drop_thr16(pdrop);
+    const float keep_scale = drop_scale16(thr);
+    const DropKey dkey = drop_key(seed);
+    const int lim_q = causal ? causal_limit(iq, causal) : 0x3fffffff;
+    const int lim_blk = causal ? causal_limit(min(i0 + 32 * qb + 31, Tn - 1), causal) : 0x3fffffff;   // last key any query of this wave attends
+    const char *k_lds = smem + K_OFF, *v_lds = smem + V_OFF, *p_lds = smem + P_OFF;
+    _Float16 *g_lds = reinterpret_cast<_Float16 *>(smem + G_OFF + wave * 4096);   // two slots of [32 band rows][32 queries]
+    const int fr_swz = (r >> 1) & 7;   // fragment rows are 32-aligned + r: the swizzle term of a b128 fragment read is the lane's own
+    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+
+    auto g_block = [&](int Rblk, int slot) {   // G^T rows Rblk .. Rblk+31 = Pband . (Q+v)^T  -> fp16 slot
+        f32x16 g_acc = {0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(p_lds + (Rblk + r) * 128 + (((2 * s + hh) ^ fr_swz) << 4));
+            g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, qv[s], g_acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) g_lds[slot * 1024 + ((g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = (_Float16)g_acc[g];
+    };
+    const int j_first = kp * KP;
+    int j_last = min(min((kp + 1) * KP, len), lim_blk + 1);    // keys [j_first, j_last) are live for this wave
+    if (i0 + 32 * qb >= Tn) j_last = j_first;                   // a query block beyond the sequence
+    const int nsub = j_last > j_first ? (j_last - j_first + 31) / 32 : 0;
+    if (nsub > 0) g_block(j_first - 32 * qb + QH - 32, 0);
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int jb = j_first + 32 * sub;
+        const int Rb = jb - 32 * qb + QH - 32;      // band block A = rows Rb.. (slot sub & 1), block B = rows Rb + 32.. (slot (sub + 1) & 1)
+        f32x16 s_acc = {0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(k_lds + (jb + r) * 128 + (((2 * s + hh) ^ fr_swz) << 4));
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qu[s], s_acc, 0, 0, 0);
+        }
+        g_block(Rb + 32, (sub + 1) & 1);
+        __builtin_amdgcn_wave_barrier();
+        ATS_STAMP(2);   // AC + G MFMAs, G store
+        float sc[16], bdv[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {   // all 16 skewed reads issued back to back, unconditionally
+            const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh, rowq = jl - r + 31;
+            bdv[g] = pin((float)g_lds[(((rowq >> 5) ^ sub) & 1) * 1024 + (rowq & 31) * 32 + r]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
+            const float bd = bdv[g];
+            const int j = jb + jl;
+            float x = (s_acc[g] + bd) * scale;
+            if (j >= len || j > lim_q) x = -INFINITY;
+            sc[g] = x;
+            mx = fmaxf(mx, x);
+        }
+        __builtin_amdgcn_wave_barrier();
+        mx = fmaxf(mx, other_half(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x8 pb[2];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float p = (m_new == -INFINITY) ? 0.f : __expf(sc[g] - m_new);
+            psum += p;
+            if (pdrop > 0.f) {
+                const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
+                p = drop_keep1(idx, dkey, thr) ? p * keep_scale : 0.f;
+            }
+            pb[g >> 3][g & 7] = (bf16_t)p;
+        }
+        psum += other_half(psum);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o_acc[db][g] *= alpha;
+        ATS_STAMP(3);   // skewed read, softmax, P fragments, O rescale
+        // O^T += V^T . P^T ; A = V^T through the transposing read (k order of pb = accumulator row order)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row_lo = jb + 16 * s + 4 * hh + q4, row_hi = row_lo + 8, col = 32 * db + 16 * mhalf + 4 * p4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4 *)(v_lds + row_lo * 128 + (((col >> 3) ^ (((row_lo >> 1) & 1) << 2)) << 4) + (col & 7) * 2));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4 *)(v_lds + row_hi * 128 + (((col >> 3) ^ (((row_hi >> 1) & 1) << 2)) << 4) + (col & 7) * 2));
+                bf16x8 va;
+                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3]; va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[s], o_acc[db], 0, 0, 0);
+            }
+    }
+    ATS_STAMP(4);   // P.V
+    // ---- merge the key parts of each query block: parts kp > 0 hand (m, l, O) to part 0 through LDS (K / V / band are dead now)
+    __syncthreads();
+    ATS_STAMP(5);   // barrier before the merge
+    float *mrg = reinterpret_cast<float *>(smem);   // [(kp - 1) * NQB + qb][64 dims x 32 queries | m[32] | l[32]]
+    constexpr int MSZ = 64 * 32 + 64;
+    static_assert((NKP - 1) * NQB * MSZ * 4 <= G_OFF, "merge buffers fit the dead K / V / band region");
+    if (kp > 0) {
+        float *mine = mrg + ((kp - 1) * NQB + qb) * MSZ;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mine[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = o_acc[db][g];
+        if (hh == 0) { mine[2048 + r] = m_run; mine[2048 + 32 + r] = l_run; }
+    }
+    __syncthreads();
+    if (kp > 0) return;
+#pragma unroll
+    for (int part = 1; part < NKP; ++part) {
+        const float *oth = mrg + ((part - 1) * NQB + qb) * MSZ;
+        const float m_o = oth[2048 + r], l_o = oth[2048 + 32 + r];
+        const float m_new = fmaxf(m_run, m_o);
+        const float a_me = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new), a_o = (m_o == -INFINITY) ? 0.f : __expf(m_o - m_new);
+        l_run = l_run * a_me + l_o * a_o;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                o_acc[db][g] = o_acc[db][g] * a_me + oth[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] * a_o;
+    }
+    if (iq < Tn) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t *orow = out + ((long long)b * Tn + iq) * D + (long long)h * Dh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * db + 8 * q + 4 * hh;
+                st4(orow + d, o_acc[db][4 * q] * inv, o_acc[db][4 * q + 1] * inv, o_acc[db][4 * q + 2] * inv, o_acc[db][4 * q + 3] * inv);
+            }
+        if (hh == 0 && lse) lse[((long long)b * H + h) * Tn + iq] = m_run + __logf(l_run);
+    }
+#ifdef AT_PROFILE
+    ATS_STAMP(6);   // merge + epilogue
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && lse)
+        for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(lse)[i] = sacc[i];   // (profile build: clobbers the first lse values)
+#endif
+}
 
 // =====================================================================================================================
 // Backward. Two deterministic passes that both recompute the probabilities from (q,k,p,lse) - no T x T tensor, no atomics:
@@ -496,11 +750,13 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
             }
             __builtin_amdgcn_wave_barrier();
             AT_STAMP(2);   // S, dP, G MFMAs + G tile to LDS
-            float ds[16], pdv[16];
+            float ds[16], pdv[16], bdv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
-                const float bd = g_lds[(jl - r + 31) * 32 + r];
+                const float bd = bdv[g];
                 const int j = jb + jl;
                 const bool masked = (j >= len) || (causal && j > causal_limit(iq, causal));
                 const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
@@ -550,10 +806,13 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) {
                 bf16x8 dgb;
+                float dgv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dgv[e] = pin(g_lds[(16 * sp + 8 * hh + e) * 32 + r]);   // unconditional reads, masked afterwards (see pin())
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int rl = 16 * sp + 8 * hh + e, jl = rl + r - 31;
-                    dgb[e] = (bf16_t)((jl >= 0 && jl < 32) ? g_lds[rl * 32 + r] : 0.f);
+                    dgb[e] = (bf16_t)((jl >= 0 && jl < 32) ? dgv[e] : 0.f);
                 }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -867,6 +1126,22 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
     const size_t lds = tsasr_relpos_attn_lds_bytes();
     dim3 grid(cdiv(T, AT_QB), H, B);
     hipStream_t st = (hipStream_t)stream;
+    static const int use_short = getenv("TSASR_ATTN_SHORT") ? atoi(getenv("TSASR_ATTN_SHORT")) : 1;
+    if (use_short && io_dtype == TSASR_BF16 && Dh == 64 && T <= 256 && T >= 2) {
+        if (T > 128) {
+            constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 4096;   // K, V (256 rows), band (384 rows), 8 fp16 G tiles
+            (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
+            relpos_attn_fwd_short_kernel<128><<<dim3(cdiv(T, 128), H, B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
+                                                                                        (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev);
+        } else {
+            constexpr int LDSS = (2 * 128 + 64 + 128) * 128 + 8 * 4096;
+            (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
+            relpos_attn_fwd_short_kernel<64><<<dim3(cdiv(T, 64), H, B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
+                                                                                      (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev);
+        }
+        TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
+        return 0;
+    }
     if (io_dtype == TSASR_F32) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         relpos_attn_fwd_kernel<float><<<grid, AT_TH, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);

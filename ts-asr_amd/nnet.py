@@ -45,7 +45,10 @@ def _cd(x):
 
 
 def abs_lengths_round(rel, dim):
-    """(rel * dim).round() kept on the device (models/conformer.py:272, SB/nnet/losses.py:58-59)."""
+    """(rel * dim).round() kept on the device (models/conformer.py:272, SB/nnet/losses.py:58-59): one HIP launch
+    (round half to even like torch.round) instead of mul + round + cast."""
+    if rel.is_cuda and rel.shape[0] <= 1024:
+        return ops.abs_lengths(rel, dim, 0)
     return (rel * dim).round().to(torch.int32)
 
 
@@ -122,10 +125,8 @@ class LSTM(nn.Module):
         if self.reshape and x.ndim == 4:
             x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
         out, hn = ops.lstm(_cd(x), self.rnn, hx)
-        if lengths is not None:
-            n = (lengths * x.shape[1]).long()
-            mask = (torch.arange(x.shape[1], device=x.device)[None, :] < n[:, None]).unsqueeze(-1)
-            out = out * mask.to(out.dtype)
+        if lengths is not None:     # zero the outputs beyond floor(len * T) (pad_packed_sequence's padding): one masking launch each way
+            out = ops.mask_time(out, ops.abs_lengths(lengths, x.shape[1], 1))
         return out, hn
 
 

@@ -810,6 +810,55 @@ def add_layer_norm(x, bias, res, ln, alpha=1.0, p=0.0, training=False, valid_len
     return _AddLayerNormFn.apply(x, bias, res, ln.weight, ln.bias, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, eps)
 
 
+class _MeanPoolFn(torch.autograd.Function):
+    """Masked mean over time of [B,T,D] -> [B,1,D] (train_librispeechmix_scratch.py:52-64), one HIP launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, rel_lens):
+        C.require_gpu(x, rel_lens)
+        xc = x.contiguous()
+        B, T, D = xc.shape
+        rel = rel_lens.detach().float().contiguous()
+        out = torch.empty(B, 1, D, dtype=xc.dtype, device=xc.device)
+        C.check(C.lib().tsasr_mean_pool_fwd(C.ptr(xc), C.ptr(rel), C.ptr(out), B, T, D, C.io_dtype(xc), C.stream_ptr()), "tsasr_mean_pool_fwd")
+        ctx.save_for_backward(rel)
+        ctx.shape = (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rel,) = ctx.saved_tensors
+        B, T, D = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty(B, T, D, dtype=dout.dtype, device=dout.device)
+        C.check(C.lib().tsasr_mean_pool_bwd(C.ptr(dout), C.ptr(rel), C.ptr(dx), B, T, D, C.io_dtype(dout), C.stream_ptr()), "tsasr_mean_pool_bwd")
+        return dx, None
+
+
+def mean_pool(x, rel_lens):
+    return _MeanPoolFn.apply(x, rel_lens)
+
+
+def abs_lengths(rel, dim, mode=0):
+    """int32 [B] absolute lengths from relative ones on the device, one launch: mode 0 = (rel * dim).round() (half to even, as
+    torch.round: models/conformer.py:272, SB/nnet/losses.py:58-59), 1 = floor (SB/nnet/RNN.py:35), 2 = ceil clamped to dim."""
+    import ctypes
+    C.require_gpu(rel)
+    r = rel.detach().float().contiguous()
+    out = torch.empty(r.shape[0], dtype=torch.int32, device=r.device)
+    pr, po = (ctypes.c_void_p * 1)(r.data_ptr()), (ctypes.c_void_p * 1)(out.data_ptr())
+    pd, pm = (ctypes.c_int * 1)(int(dim)), (ctypes.c_int * 1)(int(mode))
+    C.check(C.lib().tsasr_abs_lengths(pr, po, pd, pm, 1, r.shape[0], C.stream_ptr()), "tsasr_abs_lengths")
+    return out
+
+
+def count_nonfinite(x, counter):
+    """counter (int32 device scalar) += number of NaN / Inf in x (fp32, any shape): one launch."""
+    C.require_gpu(x, counter)
+    xf = x.detach().float().contiguous().view(-1)
+    C.check(C.lib().tsasr_count_nonfinite(C.ptr(xf), xf.numel(), C.ptr(counter), C.stream_ptr()), "tsasr_count_nonfinite")
+
+
 def mask_time(x, valid_lens):
     """Zero frames t >= valid_lens[b] of x [B,T,D] (ConvolutionModule's masked_fill_, Conformer.py:113-114)."""
     return dropout_add(x, None, None, 1.0, 0.0, False, valid_lens)

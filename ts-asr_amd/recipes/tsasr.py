@@ -73,11 +73,9 @@ class TSASR(core.Brain):
             feats = self.modules.speaker_normalizer(feats, enroll_lens, epoch=epoch)
         feats = self.modules.speaker_frontend(feats)
         embs = self.modules.speaker_encoder(feats, enroll_lens)
-        if hp.injection_mode != "cross_attention":
-            Te = embs.shape[-2]
-            n = (enroll_lens * Te).ceil().clamp(max=Te)
-            mask = (torch.arange(Te, device=embs.device)[None, :] < n[:, None]).unsqueeze(-1).to(embs.dtype)
-            embs = (embs * mask).sum(dim=-2, keepdim=True) / mask.sum(dim=-2, keepdim=True)
+        if hp.injection_mode != "cross_attention":     # masked mean-pool over the first ceil(len * T'e) frames (:52-64): one HIP launch
+            from .. import ops
+            embs = ops.mean_pool(embs, enroll_lens)
         return self.modules.speaker_proj(embs), enroll_lens
 
     def _predictor(self, tokens_bos, tokens_bos_lens):

@@ -123,8 +123,9 @@ def transducer_loss(logits, targets, input_lens, target_lens, blank_index, reduc
     = torchaudio semantics (no division by T); False = the Numba kernel's convention cost/T
     (speechbrain/nnet/loss/transducer_loss.py:104-106). Both run on the same HIP kernels.
     """
-    tl = (input_lens * logits.shape[1]).round().int()
-    ul = (target_lens * targets.shape[1]).round().int()
+    from .nnet import abs_lengths_round
+    tl = abs_lengths_round(input_lens, logits.shape[1])
+    ul = abs_lengths_round(target_lens, targets.shape[1])
     costs = rnnt_costs(logits, targets, tl, ul, blank_index)
     if not use_torchaudio:
         costs = costs / tl.to(costs.dtype)
