@@ -358,3 +358,30 @@ def test_bf16_allreduce_payload_gloo_world2(tmp_path):
     assert g0["fp32_sent"] == g0["bf16_sent"] >= 2
     rel = float((g0["bf16"] - g0["fp32"]).norm() / g0["fp32"].norm())
     assert 0 < rel < 8e-3, rel
+
+
+def test_manifest_batches_mix_and_bucket(tmp_path):
+    """dataio.manifest_batches: a LibriSpeechMix-format manifest (librispeechmix_prepare.py:206-218 keys) -> mixed, trimmed, sorted, batched."""
+    import json
+    dataio = importlib.import_module("ts-asr_amd.dataio")
+    g = torch.Generator().manual_seed(0)
+    man = {}
+    for i, dur in enumerate([0.5, 0.25, 0.4, 0.3]):
+        n = int(dur * 16000)
+        t = {"sigs": [torch.randn(n, generator=g), torch.randn(n // 2, generator=g)], "enroll_sig": torch.randn(8000, generator=g),
+             "tokens": torch.randint(1, 29, (5 + i,), generator=g)}
+        torch.save(t, tmp_path / f"u{i}.pt")
+        man[f"u{i}"] = {"wavs": ["a.flac", "b.flac"], "enroll_wav": "e.flac", "delays": [0.0, 0.1], "start": 0.0, "duration": dur,
+                        "durations": [dur, dur / 2], "target_speaker_idx": 0, "wrd": "x", "speakers": ["s1", "s2"], "genders": ["m", "f"],
+                        "tensors": str(tmp_path / f"u{i}.pt")}
+    (tmp_path / "train.json").write_text(json.dumps(man))
+    batches = dataio.manifest_batches(str(tmp_path / "train.json"), {"batch_size": 2, "trim_enroll": 0.25, "blank_index": 0})
+    assert [b.id for b in batches] == [["u1", "u3"], ["u2", "u0"]]                       # ascending duration
+    b0 = batches[0]
+    assert b0.mixed_sig.data.shape == (2, int(0.3 * 16000)) and b0.enroll_sig.data.shape == (2, 4000)   # enrollment trimmed to 0.25 s
+    assert torch.allclose(b0.mixed_sig.lengths, torch.tensor([4000 / 4800, 1.0]))
+    t1 = torch.load(tmp_path / "u1.pt")
+    ref = t1["sigs"][0].clone()
+    ref[1600:3600] += t1["sigs"][1]                                                         # second source (2000 samples) delayed by 0.1 s
+    assert torch.allclose(b0.mixed_sig.data[0, :4000], ref)
+    assert b0.tokens_bos.data[0, 0] == 0 and torch.equal(b0.tokens_bos.data[0, 1:7], t1["tokens"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase split of relpos_attn_bwd_q (debug build -DAT_PROFILE): s_memtime deltas of wave 1 of workgroup (0,0,0)."""
 import importlib, sys, os, subprocess
-root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import torch
 C = importlib.import_module("ts-asr_amd._capi")

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void fe_c1_bwd_kernel(const T *__restrict__ x,
     // they compiled to v_pk_add_f32 with swapped op_sel halves (op_sel:[0,1] op_sel_hi:[1,0]) - the only such instruction in the
     // library - and exactly those sums (even channels of db1) came out different in the low bits from run to run whenever a second
     // hardware queue had kernels in flight (hipGraph replay with the forked speaker branch): an instruction-timing hazard, not a
-    // data race (found by hashing every parameter gradient of identical replays, tools/scratch/grad_det.py).
+    // data race (found by hashing every parameter gradient of identical replays, tests/test_recipe_gpu.py).
     float one = 1.f;
     asm volatile("" : "+v"(one));
     for (long long p = (long long)blockIdx.x * ppb + pl; p < P; p += (long long)gridDim.x * ppb) {

@@ -167,3 +167,29 @@ def collate(examples, blank_index=0):
         "tokens_bos": pad([torch.cat([torch.tensor([blank_index]), t]) for t in toks]),
         "tokens": pad(toks),
     })
+
+
+def manifest_batches(json_path, hparams, data_folder=None, device="cpu"):
+    """Batches for Brain.fit / evaluate from a LibriSpeechMix manifest (the JSON of librispeechmix_prepare.py:206-218). Decoding audio
+    and tokenising text are the caller's job (no torchaudio / dataset on the GPU box): every entry names, next to the reference's keys,
+    a `tensors` file (torch.save of {"sigs": [1-D waveforms of the sources], "enroll_sig": 1-D, "tokens": 1-D int}). The mixture is
+    built here as audio_pipeline does (mix_sources: gains, delays, sum, crop; trim_enroll), examples are sorted by duration
+    (`sorting: ascending`) and grouped by DynamicBatchSampler when hparams has `max_batch_length`, else in fixed `batch_size` groups."""
+    entries = load_manifest(json_path, {"data_folder": data_folder} if data_folder else None)
+    sr = int(hparams.get("sample_rate", 16000))
+    items = []
+    for uid, e in entries.items():
+        t = torch.load(e["tensors"])
+        mixed = mix_sources([s.float() for s in t["sigs"]], e["delays"], e.get("start", 0.0), e["duration"], e["target_speaker_idx"], sr,
+                            hparams.get("gain_nontarget", 0))
+        enroll = trim_enroll(t["enroll_sig"].float(), hparams.get("trim_enroll", 20.0), sr)
+        items.append({"id": uid, "duration": float(e["duration"]), "mixed_sig": mixed, "enroll_sig": enroll, "tokens": t["tokens"]})
+    items.sort(key=lambda x: x["duration"])
+    if hparams.get("max_batch_length"):
+        sampler = DynamicBatchSampler(items, hparams["max_batch_length"], num_buckets=hparams.get("num_buckets", 20), shuffle=False,
+                                      batch_ordering="ascending", lengths_list=[x["duration"] for x in items])
+        groups = [list(b) for b in sampler]
+    else:
+        bs = int(hparams.get("batch_size", 8))
+        groups = [list(range(i, min(i + bs, len(items)))) for i in range(0, len(items), bs)]
+    return [collate([items[i] for i in g], hparams.get("blank_index", 0)).to(device) for g in groups]

@@ -45,6 +45,8 @@ def ddp_init_group(run_opts):
     dist.init_process_group(backend=backend)
 
 
+# single-rank steps: flush the queued weight gradients on a side stream once they fill this many 256 x 256 tiles (0 = one flush at the end)
+_WGRAD_ASYNC_TILES = int(os.environ.get("TSASR_WGRAD_ASYNC_TILES", "0"))   # measured: 80-240 tiles -> 15.2-15.8 ms against 14.6 ms for one flush at the end (the 128 KB-LDS, 8-wave workgroups starve the main chain's kernels of CUs): off
 _DIRECT = {"ranks": 0}
 
 
@@ -109,6 +111,7 @@ class GradArena:
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_ring = [], None, None
         self.collect_wgrads = self.device.type == "cuda"   # weight-gradient GEMMs are queued and run as one grouped launch per flush
+        self.wgrad_stream, self._wgrad_hold, self._wgrad_side_busy = None, [], False
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -237,10 +240,15 @@ class GradArena:
     # ---- grouped weight gradients (csrc/wgrad.hip) -------------------------------------------------------
     def wgrad_queued(self, p):
         """ops._wgrad_into queued p's weight gradient. On a step that overlaps the all-reduce with backward, a bucket whose other
-        gradients are all in is completed by flushing the queue (one grouped launch), then sent."""
+        gradients are all in is completed by flushing the queue (one grouped launch), then sent. Otherwise the queue is flushed
+        whenever it holds about half a chip's worth of output tiles, on a stream of its own: the grouped launch then runs BESIDE the
+        rest of backward (a long kernel on fewer than 256 CUs next to many short, latency-bound ones) instead of after it."""
         if not self._order_final:
             self._order_seen.append(p)
+        from . import ops
         if not self._sync_this_step or not self._order_final:
+            if _WGRAD_ASYNC_TILES and ops.wgrad_pending_tiles() >= _WGRAD_ASYNC_TILES:
+                self.flush_wgrads(side=True)
             return
         b = self.bucket_of[id(p)]
         b["left"] -= 1
@@ -248,17 +256,30 @@ class GradArena:
         if b["left"] == 0:
             self.flush_wgrads()
 
-    def flush_wgrads(self):
-        """Run every queued weight gradient now, on the current stream, ordered after every stream of the step."""
+    def flush_wgrads(self, side=False):
+        """Run every queued weight gradient now, ordered after every stream of the step: on the current stream, or (side) on the
+        arena's weight-gradient stream, which finish_backward joins."""
         from . import ops
         if ops.wgrad_pending() == 0:
             return
+        if side and self.device.type == "cuda":
+            if self.wgrad_stream is None:
+                self.wgrad_stream = torch.cuda.Stream(device=self.device)
+            ws, cur = self.wgrad_stream, torch.cuda.current_stream()
+            for st in {id(x): x for x in [cur, self._main_stream] + list(self.aux_streams) if x is not None}.values():
+                ws.wait_stream(st)
+            with torch.cuda.stream(ws):
+                ops.wgrad_flush(hold=self._wgrad_hold)     # operands stay referenced until the join (their memory must not be recycled under the launch)
+            self._wgrad_side_busy = True
+            return
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream()
-            for st in [self._main_stream] + list(self.aux_streams):
+            for st in [self._main_stream, self.wgrad_stream if self._wgrad_side_busy else None] + list(self.aux_streams):
                 if st is not None and st != cur:
                     cur.wait_stream(st)
         ops.wgrad_flush()
+        if self._wgrad_side_busy:
+            self._wgrad_side_busy, self._wgrad_hold = False, []
         if self._sync_this_step and self._order_final:
             for b in self.buckets:
                 if b.get("queued", 0) and b["left"] == 0:
@@ -324,6 +345,9 @@ class GradArena:
         if self.device.type == "cuda":
             from . import ops
             self.flush_wgrads()         # every queued weight gradient, one grouped launch (accumulates into the arena)
+            if self._wgrad_side_busy:   # nothing was left to flush: still join the weight-gradient stream
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+                self._wgrad_side_busy, self._wgrad_hold = False, []
             ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()
         self.in_backward = False

@@ -193,16 +193,23 @@ def wgrad_queue(weight, grad2d, dy2, x2):
     _WG["ids"].add(id(weight))
     _WG["keep"] += [dy2, x2]
     _WG["params"].append(weight)
+    _WG["tiles"] = _WG.get("tiles", 0) + ((N + 255) // 256) * ((K + 255) // 256)
     return True
+
+
+def wgrad_pending_tiles():
+    """256 x 256 output tiles of the queued weight gradients (one workgroup each in the grouped launch)."""
+    return _WG.get("tiles", 0)
 
 
 def wgrad_pending():
     return len(_WG["params"])
 
 
-def wgrad_flush():
+def wgrad_flush(hold=None):
     """One launch for every queued weight gradient (on the current stream, which must be ordered after their producers); returns the
-    parameters whose gradients it completed."""
+    parameters whose gradients it completed. `hold`: a list that takes over the operand references (a launch on a side stream: the
+    caller releases them once the consumer stream has joined it)."""
     done = _WG["params"]
     if done:
         ring = _WG["ring"]
@@ -210,7 +217,9 @@ def wgrad_flush():
         with prof.region("wgrad_group", _WG.get("flops", 0.0)):
             C.check(C.lib().tsasr_wgrad_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_wgrad_flush")
         ring.launched(k)
-    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"] = [], set(), [], 0.0
+        if hold is not None:
+            hold.extend(_WG["keep"])
+    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"] = [], set(), [], 0.0, 0
     return done
 
 

@@ -44,7 +44,7 @@ def event_overhead_ms(pairs=64):
     return ms[len(ms) // 2]
 
 
-def collect(subtract_overhead=True, repeats=1):
+def collect(subtract_overhead=True, repeats=1, fastest=True):
     """{name: (count, mean_ms)} - call after torch.cuda.synchronize(). Durations are net of the empty-pair overhead. ``repeats``:
     the instrumented region ran the same launch sequence that many times (steps); each launch is then represented by its FASTEST
     repeat (a launch that happened to queue behind another stream's kernel otherwise drags the family's mean: one 3 ms stall among 120
@@ -56,7 +56,7 @@ def collect(subtract_overhead=True, repeats=1):
     ov = 0.8 * event_overhead_ms() if (subtract_overhead and _records) else 0.0
     for name, evs in _records.items():
         ms = [max(a.elapsed_time(b) - ov, 0.0) for a, b in evs]
-        if repeats > 1 and len(ms) % repeats == 0:
+        if fastest and repeats > 1 and len(ms) % repeats == 0:
             n = len(ms) // repeats
             best = [min(ms[i + r * n] for r in range(repeats)) for i in range(n)]
             out[name] = (len(ms), sum(best) / max(n, 1))
