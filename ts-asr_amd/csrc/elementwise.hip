@@ -35,6 +35,7 @@ template <> __device__ __forceinline__ void stv<bf16_t, 8>(bf16_t *p, const floa
 
 // block-wide sum for TPR (threads per row) = 64 (one wave) or 256 (one workgroup)
 template <int TPR> __device__ __forceinline__ float row_sum(float v, float *red) {
+    if (TPR == 32) return half_wave_sum(v);   // two rows per wave (256 bf16 columns = 32 lanes x 16 bytes: a whole wave per row left half of it idle)
     v = wave_sum(v);
     if (TPR == 64) return v;
     const int w = threadIdx.x >> 6;
@@ -55,9 +56,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
     constexpr int N = Vec<T>::N;
     __shared__ float red[4];
     const int rows_per_blk = 256 / TPR;
-    const long long row = (long long)blockIdx.x * rows_per_blk + threadIdx.x / TPR;
+    long long row = (long long)blockIdx.x * rows_per_blk + threadIdx.x / TPR;
     const int l = threadIdx.x % TPR;
     if (TPR == 64 && row >= M) return;
+    const bool row_valid = row < M;               // TPR == 32: the other half of the wave may still own a row - no early exit
+    if (TPR == 32 && !row_valid) row = M - 1;
     const T *xr = x + row * D;
     float v[ITERS][N];
     float s = 0.f;
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
         }
     }
     const float rs = rsqrtf(row_sum<TPR>(q, red) / D + eps);
+    if (TPR == 32 && !row_valid) return;
     if (l == 0) { mean[row] = mu; rstd[row] = rs; }
     T *yr = y + row * D;
 #pragma unroll
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256) void dropout_add_bwd_kernel(const T *__restric
 // Backward: d_s = LayerNorm_bwd(dy) + dout (gradient arriving through the residual path);  dres = d_s ;
 //           dx = alpha * timemask * dropmask/(1-p) * d_s ;  column partials for dgamma, dbeta, dbias.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int ITERS>
+template <typename T, int ITERS, bool HW = false>   // HW: two rows per wave (D <= 32 lanes x 16 bytes)
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
                                                                 const T *__restrict__ res, T *__restrict__ s_out, T *__restrict__ y,
                                                                 float *__restrict__ mean, float *__restrict__ rstd,
@@ -686,10 +690,12 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
                                                                 long long M, int D, float alpha, float p, unsigned long long seed,
                                                                 const unsigned long long *__restrict__ seed_dev,
                                                                 const int32_t *__restrict__ valid_lens, int Trows, float eps) {
-    constexpr int N = Vec<T>::N;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int l = threadIdx.x & 63;
-    if (row >= M) return;
+    constexpr int N = Vec<T>::N, LPR = HW ? 32 : 64;   // lanes per row
+    long long row = HW ? ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x >> 5) & 1) : (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & (LPR - 1);
+    if (!HW && row >= M) return;
+    const bool row_valid = row < M;                    // HW: no early exit, the other half-wave may own a row (loads clamped, stores guarded)
+    if (HW && !row_valid) row = M - 1;
     if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_thr16(p);
     const DropKey dk = drop_key(seed);
@@ -699,14 +705,14 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     float gv[ITERS][N], bt[ITERS][N];      // requested with the row, used after the two reductions
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = min((it * 64 + l) * N, D - N);
+        const int c = min((it * LPR + l) * N, D - N);
         ldv<float, N>(gamma + c, gv[it]);
         ldv<float, N>(beta + c, bt[it]);
     }
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + l) * N;
+        const int c = (it * LPR + l) * N;
         if (c < D) {
             float xv[N], rv[N], bv[N];
             ldv<T, N>(x + row * D + c, xv);
@@ -724,24 +730,25 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
                 v[it][j] = t;
                 sum += t;
             }
-            stv<T, N>(s_out + row * D + c, v[it]);
+            if (row_valid) stv<T, N>(s_out + row * D + c, v[it]);
         }
     }
-    const float mu = wave_sum(sum) / D;
+    const float mu = (HW ? half_wave_sum(sum) : wave_sum(sum)) / D;
     float q = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + l) * N;
+        const int c = (it * LPR + l) * N;
         if (c < D) {
 #pragma unroll
             for (int j = 0; j < N; ++j) { const float d = v[it][j] - mu; q += d * d; }
         }
     }
-    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    const float rs = rsqrtf((HW ? half_wave_sum(q) : wave_sum(q)) / D + eps);
+    if (!row_valid) return;
     if (l == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + l) * N;
+        const int c = (it * LPR + l) * N;
         if (c < D) {
             float o[N];
 #pragma unroll
@@ -910,7 +917,9 @@ static int launch_ln_fwd(const void *x, const float *g, const float *b, void *y,
     const int rpw = (int)std::max<long long>(4, (M + 1023) / 1024);      // wide rows: ~1024 workgroups walking rpw rows each
 #define LN_FWD_WIDE(IT)                                                                                                   \
     layernorm_fwd_wide_kernel<T, IT><<<(unsigned)((M + rpw - 1) / rpw), 256, 0, st>>>((const T *)x, g, b, (T *)y, mean, rstd, M, D, eps, slope, rpw)
-    if (D <= per_wave) LN_FWD(64, 1);
+    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    if (half_rows && D <= per_wave / 2) LN_FWD(32, 1);
+    else if (D <= per_wave) LN_FWD(64, 1);
     else if (D <= 2 * per_wave) LN_FWD(64, 2);
     else if (D <= 4 * per_wave) LN_FWD(64, 4);
     else if (D <= 2 * per_wg) LN_FWD_WIDE(2);
@@ -1157,8 +1166,11 @@ int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, v
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((M + 3) / 4);
 #define ALN_F(TT, IT) add_layernorm_fwd_kernel<TT, IT><<<grid, 256, 0, st>>>((const TT *)x, bias, (const TT *)res, (TT *)s, (TT *)y, mean, rstd, gamma, beta, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps)
+    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
     if (io_dtype == TSASR_BF16) {
-        if (D <= 512) ALN_F(bf16_t, 1); else if (D <= 1024) ALN_F(bf16_t, 2); else if (D <= 2048) ALN_F(bf16_t, 4);
+        if (half_rows && D <= 256)
+            add_layernorm_fwd_kernel<bf16_t, 1, true><<<(unsigned)((M + 7) / 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)s, (bf16_t *)y, mean, rstd, gamma, beta, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps);
+        else if (D <= 512) ALN_F(bf16_t, 1); else if (D <= 1024) ALN_F(bf16_t, 2); else if (D <= 2048) ALN_F(bf16_t, 4);
         else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_fwd: D=%d too large", D);
     } else if (io_dtype == TSASR_F32) {
         if (D <= 256) ALN_F(float, 1); else if (D <= 512) ALN_F(float, 2); else if (D <= 1024) ALN_F(float, 4); else if (D <= 2048) ALN_F(float, 8);

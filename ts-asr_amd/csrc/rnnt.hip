@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
 // ============================================================================================
 // joint backward: shared "masked dh tile" machinery
 // ============================================================================================
-#define KB 3  // 32-wide k-blocks per wave
+#ifndef KB
+#define KB 3  // 32-wide k-blocks per wave (measured on the step: 2 -> 0.87 ms, 3 -> 0.67, 4 -> 0.72, 5 -> 1.14)
+#endif
 
 struct BwdFrags {
     bf16x8 wf[KB][2];  // B operand of D = dlogits . W : W[v = 16s+8h+j][k_r + 32 kb]
@@ -201,12 +203,14 @@ __device__ __forceinline__ void cvt_a(float (&af)[2][8], bool valid, bf16x8 (&a)
         }
 }
 
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_j;
+
 // u index (within the 32-row tile) of accumulator register g for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // ---- X: ddec + head-weight slabs ------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
+__global__ __launch_bounds__(256) void joint_bwd_x_kernel(
     const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
     const float *__restrict__ W, T *__restrict__ ddec, float *__restrict__ slab_w /*[B*nut][32][J]*/,
     float *__restrict__ slab_b /*[B*nut][32]*/, const int32_t *__restrict__ tlen, const int32_t *__restrict__ ulen,
@@ -288,11 +292,20 @@ __global__ __launch_bounds__(256, 1) void joint_bwd_x_kernel(
         }
         __builtin_amdgcn_wave_barrier();  // same-wave LDS write -> read (DS ops retire in order)
         // A' operand of dW = dlogits^T . H : rows = v_r, inner index i <-> u = 16s + 8(j>>2) + 4h + (j&3)
+        // (two transposing LDS reads per fragment: the tile is [u][v] with 64-byte rows, lane (v = r, h) needs u = 16s + 8(j>>2) + 4h + (j&3);
+        //  sixteen 2-byte reads, waited for in pairs, were eight serialized LDS round trips per frame)
         bf16x8 at[2];
+        {
+            const int q4 = (lane & 15) >> 2, p4 = lane & 3, vhalf = (lane >> 4) & 1;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) at[s][j] = my_lds[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * 32 + r];
+            for (int s = 0; s < 2; ++s) {
+                const bf16_t *a0 = my_lds + (16 * s + 4 * h + q4) * 32 + 16 * vhalf + 4 * p4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_j *)(a0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_j *)(a0 + 8 * 32));
+                at[s][0] = lo[0]; at[s][1] = lo[1]; at[s][2] = lo[2]; at[s][3] = lo[3];
+                at[s][4] = hi[0]; at[s][5] = hi[1]; at[s][6] = hi[2]; at[s][7] = hi[3];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             if (f.kb[i] < 0) continue;   // wave-uniform
