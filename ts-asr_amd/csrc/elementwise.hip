@@ -129,9 +129,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
 #pragma unroll
         for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = 0.f;
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
-    for (int rr = sub; rr < rows_per_wg; rr += rpb) {
+    // TPR == 32: the two halves of a wave share the loop bound (row_sum is made of wave-wide instructions); the odd half may idle
+    for (int rb = (TPR == 32 ? (sub & ~1) : sub); rb < rows_per_wg; rb += rpb) {
+        const int rr = TPR == 32 ? rb + (sub & 1) : rb;
         const long long row = r0 + rr;
-        const bool live = row < M;
+        const bool live = row < M && rr < rows_per_wg;
         if (TPR == 64 && !live) break;
         const T *xr = x + row * D, *dyr = dy + row * D;
         const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
 }
 
 // part rows per workgroup: [dgamma D | dbeta D | dbias D]
-template <typename T, int ITERS>
+template <typename T, int ITERS, bool HW = false>   // HW: two rows per wave, one per half (D <= 32 lanes x 16 bytes)
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ dout,
                                                                 const T *__restrict__ s_in, const float *__restrict__ gamma,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -767,13 +769,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
                                                                 long long M, int D, float alpha, float p, unsigned long long seed,
                                                                 const unsigned long long *__restrict__ seed_dev,
                                                                 const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
-    constexpr int N = Vec<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [4 waves][3][D]
+    constexpr int N = Vec<T>::N, LPR = HW ? 32 : 64, RPP = HW ? 8 : 4;   // lanes per row; rows per workgroup pass
+    extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [RPP row slots][3][D]
     if (seed_dev) seed += *seed_dev;
     const unsigned thr = drop_thr16(p);
     const DropKey dk = drop_key(seed);
     const float ks = drop_scale16(thr);
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int slot = threadIdx.x / LPR, l = threadIdx.x & (LPR - 1);
     float ag[ITERS][N], abt[ITERS][N], abx[ITERS][N];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it)
@@ -785,13 +787,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     float gm[ITERS][N];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + l) * N;
+        const int c = (it * LPR + l) * N;
         ok[it] = c < D;
         cc[it] = ok[it] ? c : 0;
         ldv<float, N>(gamma + cc[it], gm[it]);
     }
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
-    // a wave walks rows r0 + wave, +4, ...: the next row (s, dy, dout, mean, rstd) is requested before this row's reductions
+    // a row slot (wave, or half-wave) walks rows r0 + slot, +RPP, ...: the next row (s, dy, dout, mean, rstd) is requested before this row's reductions
     float sn[ITERS][N], dn[ITERS][N], on[ITERS][N], mu_n = 0.f, rs_n = 0.f;
     auto request = [&](long long row) {
 #pragma unroll
@@ -803,8 +805,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
         mu_n = mean[row];
         rs_n = rstd[row];
     };
-    if (r0 + wave < r1) request(r0 + wave);
-    for (long long row = r0 + wave; row < r1; row += 4) {
+    // HW: both halves of a wave stay in the loop together (the reductions are wave-wide instructions); a half without a row
+    // re-reads the last row and contributes nothing
+    if (HW ? r0 + (slot & ~1) < r1 : r0 + slot < r1) request(min(r0 + slot, r1 - 1));
+    for (long long row_w = r0 + (HW ? (slot & ~1) : slot); row_w < r1; row_w += RPP) {
+        const long long row_u = HW ? row_w + (slot & 1) : row_w;
+        const bool row_valid = row_u < r1;
+        const long long row = row_valid ? row_u : r1 - 1;
         const float mu = mu_n, rs = rs_n;
         const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
         float xh[ITERS][N], gd[ITERS][N], dov[ITERS][N];
@@ -813,7 +820,8 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
         for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const float h = ok[it] ? (sn[it][j] - mu) * rs : 0.f, dv = ok[it] ? dn[it][j] : 0.f;
+                const bool use = HW ? (ok[it] && row_valid) : ok[it];
+                const float h = use ? (sn[it][j] - mu) * rs : 0.f, dv = use ? dn[it][j] : 0.f;
                 xh[it][j] = h;
                 ag[it][j] += dv * h;
                 abt[it][j] += dv;
@@ -824,11 +832,11 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
                 dov[it][j] = dout ? on[it][j] : 0.f;
             }
         }
-        if (row + 4 < r1) request(row + 4);
-        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+        if (row_w + RPP < r1) request(min(row_u + RPP, r1 - 1));
+        const float m1 = (HW ? half_wave_sum(s1) : wave_sum(s1)) / D, m2 = (HW ? half_wave_sum(s2) : wave_sum(s2)) / D;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            if (ok[it]) {
+            if (HW ? (ok[it] && row_valid) : ok[it]) {
                 const int c = cc[it];
                 float ds[N], dxv[N];
                 const unsigned long long idx = (unsigned long long)row * D + c;
@@ -849,19 +857,23 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + l) * N;
+        const int c = (it * LPR + l) * N;
         if (c < D) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                colbuf[(wave * 3 + 0) * D + c + j] = ag[it][j];
-                colbuf[(wave * 3 + 1) * D + c + j] = abt[it][j];
-                colbuf[(wave * 3 + 2) * D + c + j] = abx[it][j];
+                colbuf[(slot * 3 + 0) * D + c + j] = ag[it][j];
+                colbuf[(slot * 3 + 1) * D + c + j] = abt[it][j];
+                colbuf[(slot * 3 + 2) * D + c + j] = abx[it][j];
             }
         }
     }
     __syncthreads();
     float *pw = part + (size_t)blockIdx.x * 3 * D;
-    for (int i = threadIdx.x; i < 3 * D; i += 256) pw[i] = colbuf[i] + colbuf[3 * D + i] + colbuf[6 * D + i] + colbuf[9 * D + i];
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
+        float a = colbuf[i] + colbuf[3 * D + i] + colbuf[6 * D + i] + colbuf[9 * D + i];
+        if (HW) a += colbuf[12 * D + i] + colbuf[15 * D + i] + colbuf[18 * D + i] + colbuf[21 * D + i];
+        pw[i] = a;
+    }
 }
 
 // out3[k][c] = sum_parts part[n][k*D + c], k = 0..2 (dgamma, dbeta, dbias) ; any out pointer may be NULL
@@ -940,11 +952,13 @@ static int launch_ln_bwd(const void *dy, const void *x, const float *g, const fl
     constexpr int N = Vec<T>::N;
     const int per_wave = 64 * N, per_wg = 256 * N;
 #define LN_BWD(TPR, IT)                                                                                                  \
-    layernorm_bwd_kernel<T, TPR, IT><<<nwg, 256, (TPR == 64 ? (size_t)4 * 2 * D * sizeof(float) : 0), st>>>(             \
+    layernorm_bwd_kernel<T, TPR, IT><<<nwg, 256, (TPR <= 64 ? (size_t)(256 / TPR) * 2 * D * sizeof(float) : 0), st>>>(   \
         (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw, (const T *)dadd)
 #define LN_BWD_WIDE(IT)                                                                                                   \
     layernorm_bwd_wide_kernel<T, IT><<<nwg, 256, 0, st>>>((const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
-    if (D <= per_wave) LN_BWD(64, 1);
+    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    if (half_rows && D <= per_wave / 2) LN_BWD(32, 1);
+    else if (D <= per_wave) LN_BWD(64, 1);
     else if (D <= 2 * per_wave) LN_BWD(64, 2);
     else if (D <= 4 * per_wave) LN_BWD(64, 4);
     else if (D <= 2 * per_wg) LN_BWD_WIDE(2);
@@ -1201,8 +1215,11 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
     float *part = (float *)workspace;
     const size_t lds = (size_t)12 * D * sizeof(float);
 #define ALN_B(TT, IT) add_layernorm_bwd_kernel<TT, IT><<<nwg, 256, lds, st>>>((const TT *)dy, (const TT *)dout, (const TT *)s, gamma, mean, rstd, (TT *)dres, (TT *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw)
+    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
     if (io_dtype == TSASR_BF16) {
-        if (D <= 512) ALN_B(bf16_t, 1); else if (D <= 1024) ALN_B(bf16_t, 2); else if (D <= 2048) ALN_B(bf16_t, 4);
+        if (half_rows && D <= 256)
+            add_layernorm_bwd_kernel<bf16_t, 1, true><<<nwg, 256, 2 * lds, st>>>((const bf16_t *)dy, (const bf16_t *)dout, (const bf16_t *)s, gamma, mean, rstd, (bf16_t *)dres, (bf16_t *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);
+        else if (D <= 512) ALN_B(bf16_t, 1); else if (D <= 1024) ALN_B(bf16_t, 2); else if (D <= 2048) ALN_B(bf16_t, 4);
         else TSASR_CHECK_ARG(false, "tsasr_add_layernorm_bwd: D=%d too large", D);
     } else if (io_dtype == TSASR_F32) {
         if (D <= 256) ALN_B(float, 1); else if (D <= 512) ALN_B(float, 2); else if (D <= 1024) ALN_B(float, 4); else if (D <= 2048) ALN_B(float, 8);
