@@ -163,6 +163,31 @@ int tsasr_frontend_c1_bwd(const void *x, const void *dy1, const void *dy2, float
 int tsasr_frontend_im2col(const void *x, void *A, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
 int tsasr_frontend_col2im(const void *dA, const void *dR, void *dx, int B, int T, int F, int C, int causal, int io_dtype, void *stream);
 
+/* One whole ConvBlock per direction (SB/lobes/models/convolution.py:187-266: convs = Conv2d 3x3 s2 -> LayerNorm([F',C]) -> LeakyReLU ->
+ * Dropout; reduce_conv = Conv2d 1x1 s2 -> LayerNorm([F',C]); out = Dropout(convs(x) + reduce_conv(x))):
+ *   out = Drop_p_outer( LN_r(r) + Drop_p_inner( LeakyReLU_slope( LN_y(y) ) ) ),   (y, r) = the two convolution outputs.
+ * x != NULL (block 1, C_in = 1): (y, r) are computed on the fly from the features x [B,T,F] with filters w1 [C,1,3,3] (kernel axes (F,T)),
+ *   b1, w2 [C], b2, and recomputed in the backward: nothing but `out` and 4 floats of statistics per (b, t') reach memory.
+ * x == NULL (wider blocks): (y, r) = y1, y2 [B*T', F', C] as produced by the im2col GEMMs; the backward writes their gradients dy1, dy2.
+ * T, F are always the block's INPUT sizes (T' = (T-1)/2+1, F' likewise). g1/be1, g2/be2 fp32 [F'*C] = LayerNorm affine of the 3x3 / 1x1
+ * branch. stats fp32 [B*T'][4] = (mean_y, rstd_y, mean_r, rstd_r). Dropout masks are f(seed + *seed_dev, element index of out).
+ * dparams fp32 (tsasr_frontend_block_dparams floats, overwritten): [dw1 C*9 | db1 C | dw2 C | db2 C] (x != NULL only), then
+ * [dg1 | dbe1 | dg2 | dbe2] (F'*C each). Supported: tsasr_frontend_block_supported(F', C) (C = 128, F' <= 40). */
+int tsasr_frontend_block_supported(int Fo, int C);
+int tsasr_frontend_block_fwd(const void *x, const void *y1, const void *y2, const float *w1, const float *b1, const float *w2,
+                             const float *b2, const float *g1, const float *be1, const float *g2, const float *be2, void *out,
+                             float *stats, int B, int T, int F, int C, int causal, float slope, float eps, float p_inner,
+                             unsigned long long seed_inner, float p_outer, unsigned long long seed_outer,
+                             const unsigned long long *seed_dev, int io_dtype, void *stream);
+size_t tsasr_frontend_block_dparams(int Fo, int C, int with_conv);
+size_t tsasr_frontend_block_bwd_workspace_bytes(int Fo, int C, int with_conv);
+int tsasr_frontend_block_bwd(const void *x, const void *y1, const void *y2, const void *dout, const float *w1, const float *b1,
+                             const float *w2, const float *b2, const float *g1, const float *be1, const float *g2,
+                             const float *stats, void *dy1, void *dy2, float *dparams, int B, int T, int F, int C, int causal,
+                             float slope, float p_inner, unsigned long long seed_inner, float p_outer,
+                             unsigned long long seed_outer, const unsigned long long *seed_dev, int io_dtype, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Fused relative-position multi-head self-attention: replaces the body of RelPosMHAXL.forward between in_proj and out_proj,

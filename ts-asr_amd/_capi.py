@@ -60,6 +60,11 @@ _PROTOS = {
     "tsasr_frontend_c1_bwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_frontend_im2col": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "tsasr_frontend_col2im": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "tsasr_frontend_block_supported": (c_int, [c_int, c_int]),
+    "tsasr_frontend_block_fwd": (c_int, [c_void_p] * 13 + [c_int] * 5 + [c_float, c_float, c_float, c_ull, c_float, c_ull, c_void_p, c_int, c_void_p]),
+    "tsasr_frontend_block_dparams": (c_size_t, [c_int] * 3),
+    "tsasr_frontend_block_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_frontend_block_bwd": (c_int, [c_void_p] * 15 + [c_int] * 5 + [c_float, c_float, c_ull, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_relpos_attn_lds_bytes": (c_size_t, []),
     "tsasr_relpos_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p]),
     "tsasr_relpos_attn_bwd_workspace_bytes": (c_size_t, [c_int] * 3),

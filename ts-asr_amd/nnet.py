@@ -315,6 +315,9 @@ class _Holder(nn.Module):
         self.add_module(name, child)
 
 
+_FUSED_CONVBLOCK = os.environ.get("TSASR_FUSED_CONVBLOCK", "1") != "0"   # A/B: 0 = conv kernel + 2 LayerNorm kernels + dropout-add kernel
+
+
 class ConvBlock(nn.Module):
     def __init__(self, in_channels, out_channels, in_freq, kernel_size=3, stride=2, padding="same"):
         super().__init__()
@@ -332,6 +335,9 @@ class ConvBlock(nn.Module):
         """x [B,T,F,C] (channels-last all the way: this IS the NHWC layout of a conv over (T,F))."""
         c, n = self.convs.conv_0.conv, self.convs.norm_0.norm
         rc, rn = self.reduce_conv.conv.conv, self.reduce_conv.norm.norm
+        if _FUSED_CONVBLOCK and ops.frontend_block_supported(x, c.weight.shape[0]):   # the whole block in one kernel per direction
+            return ops.frontend_block(x, c.weight, c.bias, rc.weight, rc.bias, n.weight, n.bias, rn.weight, rn.bias, self.padding,
+                                      0.01, 1e-5, dropout, training)
         y, r = ops.frontend_convs(x, c.weight, c.bias, rc.weight, rc.bias, self.padding)
         y = ops.layer_norm(y, n.weight, n.bias, 1e-5, act_slope=0.01)               # LN over [F,C] + LeakyReLU, one pass
         r = ops.layer_norm(r, rn.weight, rn.bias, 1e-5)

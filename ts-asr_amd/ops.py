@@ -1063,6 +1063,98 @@ class _FrontendConvFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None
 
 
+class _FrontendBlockFn(torch.autograd.Function):
+    """A whole ConvBlock in one kernel per direction (csrc/frontend_block.hip): out = Drop(LN_r(r) + Drop(LeakyReLU(LN_y(y)))).
+    ``feats`` [B,T,F] given (block 1): (y, r) are convolved on the fly and recomputed in the backward; else (y, r) = ``y1``, ``y2``
+    (the im2col GEMM outputs of a wider block, input sizes ``tin``, ``fin``) and the backward returns their gradients."""
+
+    @staticmethod
+    def forward(ctx, feats, y1, y2, conv_params, ln_params, tin, fin, causal, slope, eps, p_inner, seed_inner, p_outer, seed_outer,
+                *flat_params):
+        conv = feats is not None
+        src = feats if conv else y1
+        C.require_gpu(src)
+        f = lambda t: _f32(t).contiguous()  # noqa: E731
+        if conv:
+            xc = feats.contiguous()
+            B, T, Fq = xc.shape
+            Co = conv_params[0].shape[0]
+            y1c = y2c = None
+            cw = [f(t) for t in conv_params]
+        else:
+            xc = None
+            y1c, y2c = y1.contiguous(), y2.contiguous()
+            B, T, Fq, Co = y1c.shape[0], int(tin), int(fin), y1c.shape[-1]
+            cw = [None] * 4
+        To, Fo = _out_len(T), _out_len(Fq)
+        ln = [f(t).reshape(-1) for t in ln_params]
+        ref = xc if conv else y1c
+        out = torch.empty(B, To, Fo, Co, dtype=ref.dtype, device=ref.device)
+        stats = torch.empty(B * To, 4, dtype=torch.float32, device=ref.device)
+        with prof.region("frontend_block_fwd"):
+            C.check(C.lib().tsasr_frontend_block_fwd(C.ptr(xc), C.ptr(y1c), C.ptr(y2c), C.ptr(cw[0]), C.ptr(cw[1]), C.ptr(cw[2]), C.ptr(cw[3]),
+                                                     C.ptr(ln[0]), C.ptr(ln[1]), C.ptr(ln[2]), C.ptr(ln[3]), C.ptr(out), C.ptr(stats),
+                                                     B, T, Fq, Co, int(causal), float(slope), float(eps), float(p_inner), seed_inner,
+                                                     float(p_outer), seed_outer, C.ptr(seed_state(ref.device)), C.io_dtype(ref),
+                                                     C.stream_ptr()), "tsasr_frontend_block_fwd")
+        ctx.save_for_backward(xc, y1c, y2c, stats, *cw, *ln[:3])
+        ctx.cfg = (conv, B, T, Fq, Co, bool(causal), float(slope), float(p_inner), seed_inner, float(p_outer), seed_outer,
+                   conv_params, ln_params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, y1c, y2c, stats, w1, b1, w2, b2, g1, be1, g2 = ctx.saved_tensors
+        conv, B, T, Fq, Co, causal, slope, p1, s1, p2, s2, conv_params, ln_params = ctx.cfg
+        To, Fo = _out_len(T), _out_len(Fq)
+        dout = dout.contiguous()
+        n = C.lib().tsasr_frontend_block_dparams(Fo, Co, int(conv))
+        dpar = torch.empty(n, dtype=torch.float32, device=dout.device)
+        _keep(dpar)
+        dy1 = dy2 = None
+        if not conv:
+            dy1, dy2 = torch.empty_like(y1c), torch.empty_like(y2c)
+        ws = _ws(C.lib().tsasr_frontend_block_bwd_workspace_bytes(Fo, Co, int(conv)), dout.device)
+        with prof.region("frontend_block_bwd"):
+            C.check(C.lib().tsasr_frontend_block_bwd(C.ptr(xc), C.ptr(y1c), C.ptr(y2c), C.ptr(dout), C.ptr(w1), C.ptr(b1), C.ptr(w2), C.ptr(b2),
+                                                     C.ptr(g1), C.ptr(be1), C.ptr(g2), C.ptr(stats), C.ptr(dy1), C.ptr(dy2), C.ptr(dpar),
+                                                     B, T, Fq, Co, int(causal), slope, p1, s1, p2, s2, C.ptr(seed_state(dout.device)),
+                                                     C.io_dtype(dout), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_frontend_block_bwd")
+        o = 0
+        grads = []
+        if conv:
+            for prm, width in zip(conv_params, (Co * 9, Co, Co, Co)):
+                grads.append(_pgrad(prm, dpar[o:o + width]))
+                o += width
+        for prm in ln_params:
+            grads.append(_pgrad(prm, dpar[o:o + Fo * Co]))
+            o += Fo * Co
+        if not conv:
+            grads = [None] * 4 + grads
+        return (None, dy1, dy2, None, None, None, None, None, None, None, None, None, None, None, *grads)
+
+
+def frontend_block_supported(x, out_channels):
+    """True when the fused ConvBlock kernels take this block (bf16/fp32 on the GPU, 128 output channels, F' <= 40)."""
+    return x.is_cuda and bool(C.lib().tsasr_frontend_block_supported(_out_len(x.shape[2]), int(out_channels)))
+
+
+def frontend_block(x, conv_w, conv_b, red_w, red_b, ln_w, ln_b, rln_w, rln_b, padding, slope, eps, p, training):
+    """ConvBlock forward: Dropout_p(LN(conv1x1_s2(x)) + Dropout_p(LeakyReLU(LN(conv3x3_s2(x))))); x [B,T,F,C_in] channels-last."""
+    if padding not in ("same", "causal"):
+        raise ValueError("Padding must be 'same' or 'causal'. Got " + str(padding))
+    p = float(p) if training else 0.0
+    s1, s2 = (next_seed(), next_seed()) if p > 0 else (0, 0)
+    causal = padding == "causal"
+    conv_params, ln_params = (conv_w, conv_b, red_w, red_b), (ln_w, ln_b, rln_w, rln_b)
+    if x.shape[-1] == 1:
+        return _FrontendBlockFn.apply(x.squeeze(-1), None, None, conv_params, ln_params, 0, 0, causal, slope, eps, p, s1, p, s2,
+                                      *conv_params, *ln_params)
+    y1, y2 = _FrontendConvFn.apply(x, conv_w, conv_b, red_w, red_b, causal)
+    return _FrontendBlockFn.apply(None, y1, y2, None, ln_params, x.shape[1], x.shape[2], causal, slope, eps, p, s1, p, s2,
+                                  None, None, None, None, *ln_params)
+
+
 def frontend_convs(x, w1, b1, w2, b2, padding):
     """x [B,T,F,C] -> (conv3x3_s2(x) + b1, conv1x1_s2(x) + b2), both [B,T',F',C_out]; padding 'same' (reflect) or 'causal'."""
     if padding not in ("same", "causal"):
