@@ -241,6 +241,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         ab = algorithmic_bytes(B_LOCAL, T_MEL // 4, U + 1)
         wk = prof.work()
+        wb = prof.algorithmic_bytes()
         fam = {}
         for k, (n, ms) in kern.items():
             e = {"launches": n, "avg_ms": round(ms, 4)}
@@ -249,6 +250,8 @@ def main():
             if wk.get(k, 0) > 0 and ms > 0:
                 e["avg_GFLOP_per_launch"] = round(wk[k] / n / 1e9, 3)
                 e["TFLOPps"] = round(wk[k] / n / (ms * 1e-3) / 1e12, 1)
+            if wb.get(k, 0) > 0:
+                e["algorithmic_MB_per_launch"] = round(wb[k] / n / 1e6, 1)
             fam[k] = e
         # dominant hand-written kernel = largest share of the step among the instrumented launches
         dom = max(fam, key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)

@@ -214,12 +214,12 @@ def wgrad_flush(hold=None):
     if done:
         ring = _WG["ring"]
         k, host, dev, _ = ring.acquire()
-        with prof.region("wgrad_group", _WG.get("flops", 0.0)):
+        with prof.region("wgrad_group", _WG.get("flops", 0.0), _WG.get("bytes", 0.0)):
             C.check(C.lib().tsasr_wgrad_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_wgrad_flush")
         ring.launched(k)
         if hold is not None:
             hold.extend(_WG["keep"])
-    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"] = [], set(), [], 0.0, 0
+    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"], _WG["bytes"] = [], set(), [], 0.0, 0, 0.0
     return done
 
 
@@ -368,6 +368,7 @@ def _wgrad_into(sink, weight, grad2d, dy2, x2):
     M = dy2.shape[0]
     if getattr(sink, "collect_wgrads", False) and wgrad_queue(weight, grad2d, dy2, x2):
         _WG["flops"] = _WG.get("flops", 0.0) + 2.0 * M * N * K
+        _WG["bytes"] = _WG.get("bytes", 0.0) + 2.0 * M * (N + K) + 8.0 * N * K   # dy and x (bf16) read once, the fp32 gradient read and written
         sink.wgrad_queued(weight)
         return
     gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, defer_ok=True)

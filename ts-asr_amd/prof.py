@@ -8,11 +8,13 @@ import torch
 ENABLED = False
 _records = {}
 _work = {}
+_bytes = {}
 
 
 @contextlib.contextmanager
-def region(name, work=0.0):
-    """``work`` = algorithmic FLOPs (or bytes) of this launch; summed per name so that achieved rate = work / time."""
+def region(name, work=0.0, nbytes=0.0):
+    """``work`` = algorithmic FLOPs of this launch, ``nbytes`` = its algorithmic HBM bytes (operands read once, results written once);
+    both are summed per name so that achieved rate = work / time."""
     if not ENABLED:
         yield
         return
@@ -24,10 +26,15 @@ def region(name, work=0.0):
         b.record()
         _records.setdefault(name, []).append((a, b))
         _work[name] = _work.get(name, 0.0) + float(work)
+        _bytes[name] = _bytes.get(name, 0.0) + float(nbytes)
 
 
 def work():
     return dict(_work)
+
+
+def algorithmic_bytes():
+    return dict(_bytes)
 
 
 def event_overhead_ms(pairs=64):
@@ -72,3 +79,4 @@ out_overhead = [0.0]
 def reset():
     _records.clear()
     _work.clear()
+    _bytes.clear()
