@@ -327,6 +327,9 @@ void tsasr_wgrad_discard(void);
 int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_mean_pool_bwd(const void *dout, const float *rel, void *dx, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_abs_lengths(const float *const *rel, int *const *out, const int *dim, const int *mode, int n, int B, void *stream);
+/* TEST AID (tests / tools only): overwrite the whole LDS of every CU with a 32-bit pattern, so that a kernel reading LDS it never wrote
+ * sees the pattern instead of whatever the previous kernel left there. */
+int tsasr_debug_fill_lds(unsigned pattern, void *stream);
 int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);
 
 /* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module

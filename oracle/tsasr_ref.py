@@ -119,20 +119,24 @@ def relpos_table(T, D, dtype=torch.float32):
 # ----------------------------------------------------------------------------------------------
 # A7  RelPosMHAXL  (SB/nnet/attention.py:485-639)
 # ----------------------------------------------------------------------------------------------
-def relpos_mha(x, pe, sd, p, H, key_padding_mask=None, causal=False, return_attn=False):
-    B, T, D = x.shape
+def relpos_core(qkv, pk, pos_bias_u, pos_bias_v, H, scale, key_padding_mask=None, causal=False):
+    """Attention proper of RelPosMHAXL, after the input / positional projections and before out_proj (SB/nnet/attention.py:549-633):
+    qkv [B,T,3D] per-head interleaved Q|K|V, pk [2T-1, D], biases in their (Dh,H) storage. Returns (context [B,T,D], attn [B,H,T,T]).
+    relpos_mha below is this function between the projections, so the golden vectors that pin relpos_mha pin it too; the GPU tests
+    of the fused attention kernels call it directly."""
+    B, T, D3 = qkv.shape
+    D = D3 // 3
     Dh = D // H
-    qkv = (x @ sd[p + "in_proj_weight"].t()).view(B, T, H, 3 * Dh)  # per-head interleaved (:549-553)
-    q, k, v = qkv.chunk(3, dim=-1)
-    pk = (pe @ sd[p + "linear_pos.weight"].t()).view(1, -1, H, Dh)  # [1,2T-1,H,Dh]
-    u = sd[p + "pos_bias_u"].view(1, 1, H, Dh)  # reinterpreting view of (Dh,H) storage (:586-592)
-    vb = sd[p + "pos_bias_v"].view(1, 1, H, Dh)
+    q, k, v = qkv.view(B, T, H, 3 * Dh).chunk(3, dim=-1)
+    pk = pk.view(1, -1, H, Dh)  # [1,2T-1,H,Dh]
+    u = pos_bias_u.view(1, 1, H, Dh)  # reinterpreting view of (Dh,H) storage (:586-592)
+    vb = pos_bias_v.view(1, 1, H, Dh)
     ac = torch.matmul((q + u).transpose(1, 2), k.permute(0, 2, 3, 1))  # [B,H,T,T]
     bd_raw = torch.matmul((q + vb).transpose(1, 2), pk.permute(0, 2, 3, 1))  # [B,H,T,2T-1]
     # rel_shift closed form (:468-483): BD[i,j] = BDraw[i, j - i + T - 1]
     idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1)  # [T,T]
     bd = torch.gather(bd_raw, 3, idx.expand(B, H, T, T))
-    score = (ac + bd) * (1.0 / math.sqrt(D))  # 1/sqrt(embed_dim)  (:452,604)
+    score = (ac + bd) * scale
     if causal:   # float look-ahead mask is added (:615-616); causal = C > 1: the build's block-causal extension (chunks of C frames:
         ii = torch.arange(T)   # a frame sees its whole chunk and everything before it) - not a reference feature, see DESIGN.md
         lim = ii if int(causal) <= 1 else (ii // int(causal) + 1) * int(causal) - 1
@@ -141,6 +145,16 @@ def relpos_mha(x, pe, sd, p, H, key_padding_mask=None, causal=False, return_attn
         score = score.masked_fill(key_padding_mask.view(B, 1, 1, T), float("-inf"))
     attn = torch.softmax(score, dim=-1)
     o = torch.matmul(attn, v.transpose(1, 2)).transpose(1, 2).reshape(B, T, D)
+    return o, attn
+
+
+def relpos_mha(x, pe, sd, p, H, key_padding_mask=None, causal=False, return_attn=False):
+    B, T, D = x.shape
+    qkv = x @ sd[p + "in_proj_weight"].t()  # per-head interleaved (:549-553)
+    pk = pe @ sd[p + "linear_pos.weight"].t()
+    pk = pk.reshape(-1, D)
+    o, attn = relpos_core(qkv, pk, sd[p + "pos_bias_u"], sd[p + "pos_bias_v"], H, 1.0 / math.sqrt(D),  # 1/sqrt(embed_dim)  (:452,604)
+                          key_padding_mask, causal)
     o = o @ sd[p + "out_proj.weight"].t() + sd[p + "out_proj.bias"]
     return (o, attn) if return_attn else o
 

@@ -333,7 +333,8 @@ def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
-    """HIP backward (dQ/dK/dV, d pos_bias_u/v, d pk) vs autograd through the fp32 formula."""
+    """HIP backward (dQ/dK/dV, d pos_bias_u/v, d pk) vs autograd through the ORACLE's attention (oracle/tsasr_ref.py relpos_core, the
+    function the reference-generated golden vectors pin through relpos_mha) - not through product code."""
     D = H * Dh
     g = torch.Generator().manual_seed(Tn * 3 + Dh)
     qkv = torch.randn(B, Tn, 3 * D, generator=g).to(dtype)
@@ -343,7 +344,9 @@ def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
     lens = torch.tensor([Tn, max(1, Tn // 2), max(1, Tn - 7)][:B], dtype=torch.int32)
     scale = 1.0 / D ** 0.5
     leaf = [t.float().clone().requires_grad_() for t in (qkv, pk, u, v)]
-    ref, _ = ops._relpos_attention_glue(leaf[0], leaf[1], leaf[2], leaf[3], lens, H, scale, causal, 0.0, False)
+    R = importlib.import_module("oracle.tsasr_ref")
+    pad = torch.arange(Tn)[None, :] >= lens[:, None].long()
+    ref, _ = R.relpos_core(leaf[0], leaf[1], leaf[2], leaf[3], H, scale, pad, causal)
     ref.backward(dout.float())
     dev = [t.to(DEV).requires_grad_() for t in (qkv, pk, u, v)]
     out, _ = ops.relpos_attention(dev[0], dev[1], dev[2], dev[3], lens.to(DEV), H, scale, causal, 0.0, False)

@@ -275,6 +275,11 @@ def test_mixing_arithmetic_and_collate():
     interferer = m2 - a
     assert float((interferer[:4] ** 2).mean() / (a ** 2).mean()) == pytest.approx(0.1, rel=1e-5) and torch.all(interferer[4:] == 0)
     assert torch.equal(dataio.trim_enroll(torch.arange(100.0), 2.55, sr), torch.arange(26.0))
+    # three sources: the sum runs left to right in fp32 like the reference's `mixed_sig += sig` loop (:375-377) - bitwise, not just close
+    g = torch.Generator().manual_seed(0)
+    s3 = [torch.randn(1000, generator=g) * 10 ** k for k in (0, 3, -3)]
+    m3 = dataio.mix_sources(s3, [0.0, 0.0, 0.0], 0.0, 100.0, 1, sr)
+    assert torch.equal(m3, (s3[0] + s3[1]) + s3[2])
     batch = dataio.collate([dict(id="u1", mixed_sig=torch.randn(50), enroll_sig=torch.randn(30), tokens=[3, 4, 5]),
                             dict(id="u2", mixed_sig=torch.randn(40), enroll_sig=torch.randn(15), tokens=[7])])
     assert batch.mixed_sig.data.shape == (2, 50) and batch.mixed_sig.lengths.tolist() == pytest.approx([1.0, 0.8])

@@ -45,7 +45,27 @@ __global__ void count_nonfinite_kernel(const float *__restrict__ x, int n, int *
     if (threadIdx.x == 0 && c) *counter += c;
 }
 
+// test aid: every CU's whole LDS is overwritten with `pattern` (a kernel that reads LDS it never wrote then sees this, not leftovers)
+__global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, int words, unsigned *sink) {
+    extern __shared__ unsigned fill_lds[];
+    for (int i = threadIdx.x; i < words; i += 256) fill_lds[i] = pattern;
+    __syncthreads();
+    if (sink && fill_lds[(threadIdx.x * 97) % words] != pattern) *sink = 1;   // keeps the stores alive
+}
+
 extern "C" {
+
+/* TEST AID: fill the LDS of every CU with a 32-bit pattern (160 KB workgroups, enough of them that every CU runs at least one). */
+int tsasr_debug_fill_lds(unsigned pattern, void *stream) {
+    const int bytes = 160 * 1024;
+    (void)hipFuncSetAttribute((const void *)fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    fill_lds_kernel<<<4 * cus, 256, bytes, (hipStream_t)stream>>>(pattern, bytes / 4, nullptr);
+    TSASR_CHECK_LAUNCH("tsasr_debug_fill_lds");
+    return 0;
+}
 
 /* out[B,1,D] = masked mean over the first ceil(rel[b]*T) (clamped to T) frames of x [B,T,D] (io_dtype). */
 int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T, int D, int io_dtype, void *stream) {

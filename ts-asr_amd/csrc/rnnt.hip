@@ -214,14 +214,19 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
     const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
     const float *__restrict__ W, T *__restrict__ ddec, float *__restrict__ slab_w /*[B*nut][32][J]*/,
     float *__restrict__ slab_b /*[B*nut][32]*/, const int32_t *__restrict__ tlen, const int32_t *__restrict__ ulen,
-    int Tn, int U1, int J, int V, int ldl, float slope, float *__restrict__ denc_part /*[nut][B][T][J] or NULL*/) {
+    int Tn, int U1, int J, int V, int ldl, float slope, float *__restrict__ denc_part /*[nut][B][T][J] or NULL*/,
+    int TS, float *__restrict__ ddec_part /*[TS][B][U1][J], TS > 1*/) {
     __shared__ __attribute__((aligned(16))) bf16_t a_lds[4][32 * 32];  // per-wave dlogits tile [u][v]
-    const int b = blockIdx.z, ut = blockIdx.x, u0 = ut * 32, nut = gridDim.x;
+    // blockIdx.z = b * TS + ts: the frames are cut into TS ranges (one workgroup each) when B * tiles alone leave CUs with a single
+    // workgroup (4 waves at 180 VGPRs: nothing to switch to while a frame's loads are in flight); the ddec / dW / dbias partial sums
+    // of the ranges are added in fixed order afterwards
+    const int nb = gridDim.z / TS, b = blockIdx.z / TS, ts = blockIdx.z - b * TS, ut = blockIdx.x, u0 = ut * 32, nut = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int nslots = gridDim.y * 4, wslot = blockIdx.y * 4 + wave;
     const int Tb = tlen ? min(max(tlen[b], 1), Tn) : Tn;
     const int Ub = ulen ? min(max(ulen[b], 0), U1 - 1) : U1 - 1;
-    const int t_end = (u0 <= Ub) ? Tb : 0;  // tile entirely outside the lattice -> dlogits are zero
+    const int t_chunk = (Tn + TS - 1) / TS, t_lo = ts * t_chunk, t_hi = min(Tn, t_lo + t_chunk);
+    const int t_end = (u0 <= Ub) ? min(Tb, t_hi) : t_lo;  // tile entirely outside the lattice -> dlogits are zero
 
     BwdFrags f;
     load_w_frags(f, W, J, V, wslot, nslots, r, h);
@@ -259,12 +264,12 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
     const float *dl0 = dlogits + (((size_t)b * Tn) * U1 + min(u0 + r, U1 - 1)) * 32;
     float afn[2][8];
     T en[KB];
-    if (pipe && t_end > 0) {
-        load_a_raw32(dl0, h, afn);
+    if (pipe && t_end > t_lo) {
+        load_a_raw32(dl0 + (size_t)t_lo * U1 * 32, h, afn);
 #pragma unroll
-        for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn) * J + kbc[i] * 32 + r];
+        for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + t_lo) * J + kbc[i] * 32 + r];
     }
-    for (int t = 0; t < t_end; ++t) {
+    for (int t = t_lo; t < t_end; ++t) {
         bf16x8 a[2];
         float af[2][8], ev[KB];
         if (pipe) {
@@ -325,17 +330,17 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
             }
             if (denc_part) {    // dh is in registers here anyway: the separate denc pass recomputed every one of these tiles
                 esum += other_half(esum);
-                if (h == 0) denc_part[(((size_t)ut * gridDim.z + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
+                if (h == 0) denc_part[(((size_t)ut * nb + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
             }
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], hb[0], wacc[i], 0, 0, 0);
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], hb[1], wacc[i], 0, 0, 0);
         }
     }
     if (denc_part && h == 0) {   // frames this tile never visited (beyond the utterance, or the tile lies outside the lattice)
-        for (int t = t_end; t < Tn; ++t)
+        for (int t = max(t_end, t_lo); t < t_hi; ++t)
 #pragma unroll
             for (int i = 0; i < KB; ++i)
-                if (f.kb[i] >= 0) denc_part[(((size_t)ut * gridDim.z + b) * Tn + t) * J + f.kb[i] * 32 + r] = 0.f;
+                if (f.kb[i] >= 0) denc_part[(((size_t)ut * nb + b) * Tn + t) * J + f.kb[i] * 32 + r] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
@@ -344,8 +349,11 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int u = u0 + acc_row(g, h);
-            if (u < U1) st1(ddec + ((size_t)b * U1 + u) * J + k, dacc[i][g]);
-            slab_w[((size_t)(b * nut + ut) * 32 + acc_row(g, h)) * J + k] = wacc[i][g];
+            if (u < U1) {
+                if (TS > 1) ddec_part[(((size_t)ts * nb + b) * U1 + u) * J + k] = dacc[i][g];
+                else st1(ddec + ((size_t)b * U1 + u) * J + k, dacc[i][g]);
+            }
+            slab_w[((size_t)((ts * nb + b) * nut + ut) * 32 + acc_row(g, h)) * J + k] = wacc[i][g];
         }
     }
     if (wslot == 0) {  // dbias partial: sum over the 32 lanes (u) that share h
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
                 float x = bsum[s][j];
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-                if (r == 0) slab_b[(size_t)(b * nut + ut) * 32 + 16 * s + 8 * h + j] = x;
+                if (r == 0) slab_b[(size_t)((ts * nb + b) * nut + ut) * 32 + 16 * s + 8 * h + j] = x;
             }
     }
 }
@@ -803,10 +811,34 @@ __global__ __launch_bounds__(256) void denc_sum_kernel(const float *__restrict__
 
 extern "C" {
 
+static int device_cu_count_rnnt() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// frame ranges per (utterance, u tile, k group). Measured on the benchmark step (B = 32, T' = 250, 256 workgroups = one per CU without
+// a split): 1 -> 0.66 ms, 2 -> 0.75, 3 -> 0.84, 4 -> 0.93 - a second resident workgroup per CU buys nothing (the kernel is bound by
+// what a CU issues per frame, not by latency) and every range repeats the fragment loads and the slab writes. So: split only when the
+// grid would leave CUs idle (B = 1 long-form: 120 workgroups), never below 32 frames per range; TSASR_JOINT_TSPLIT forces a value.
+static int joint_tsplit(int B, int T, int U1, int J) {
+    static const int forced = getenv("TSASR_JOINT_TSPLIT") ? atoi(getenv("TSASR_JOINT_TSPLIT")) : 0;
+    if (forced > 0) return std::min(forced, 4);
+    const long long wgs = (long long)B * cdiv(U1, 32) * cdiv(J / 32, 4 * KB);
+    int ts = (int)std::min<long long>(4, device_cu_count_rnnt() / std::max<long long>(wgs, 1));
+    while (ts > 1 && T / ts < 32) --ts;
+    return std::max(ts, 1);
+}
+
 size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J) {
-    const size_t nslab = (size_t)B * cdiv(U1, 32);
+    const size_t nslab = (size_t)B * cdiv(U1, 32) * 4;        // sized for the largest frame split
     return align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256) +
-           align_up(nslab * T * J * sizeof(float), 256);      // denc partial sums per u tile
+           align_up((size_t)B * cdiv(U1, 32) * T * J * sizeof(float), 256) +      // denc partial sums per u tile
+           align_up((size_t)4 * B * U1 * J * sizeof(float), 256);                 // ddec partial sums per frame range
 }
 
 int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, const float *W, void *denc, void *ddec,
@@ -819,22 +851,27 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_joint_bwd_workspace_bytes(B, T, U1, J), "tsasr_joint_bwd: workspace too small");
     const int nut = cdiv(U1, 32), nkb = J / 32;
     const int ksplit = cdiv(nkb, 4 * KB);
-    const size_t nslab = (size_t)B * nut;
+    const int TS = joint_tsplit(B, T, U1, J);
+    const size_t nslab = (size_t)B * nut * TS, nslab_max = (size_t)B * nut * 4;
     float *slab_w = (float *)workspace;
-    float *slab_b = (float *)((char *)workspace + align_up(nslab * 32 * J * sizeof(float), 256));
+    float *slab_b = (float *)((char *)workspace + align_up(nslab_max * 32 * J * sizeof(float), 256));
     hipStream_t st = (hipStream_t)stream;
-    dim3 gx(nut, ksplit, B), gy(cdiv(T, TG), ksplit, B);
+    dim3 gx(nut, ksplit, B * TS), gy(cdiv(T, TG), ksplit, B);
     // one pass: the kernel that forms dh tile by tile for ddec / dW also leaves each tile's column sums (its share of denc); a small
     // kernel adds the cdiv(U1, 32) shares. TSASR_JOINT_TWO_PASS=1 brings the separate denc kernel back (A/B: it recomputes every tile).
     static const bool two_pass = getenv("TSASR_JOINT_TWO_PASS") && atoi(getenv("TSASR_JOINT_TWO_PASS")) != 0;
-    float *part = two_pass ? nullptr : (float *)((char *)workspace + align_up(nslab * 32 * J * sizeof(float), 256) + align_up(nslab * 32 * sizeof(float), 256));
-    const long long n_enc = (long long)B * T * J;
+    char *after_slabs = (char *)workspace + align_up(nslab_max * 32 * J * sizeof(float), 256) + align_up(nslab_max * 32 * sizeof(float), 256);
+    float *part = two_pass ? nullptr : (float *)after_slabs;
+    float *ddec_part = (float *)(after_slabs + align_up((size_t)B * nut * T * J * sizeof(float), 256));
+    const long long n_enc = (long long)B * T * J, n_dec = (long long)B * U1 * J;
     if (io_dtype == TSASR_F32) {
-        joint_bwd_x_kernel<float><<<gx, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part);
+        joint_bwd_x_kernel<float><<<gx, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part, TS, ddec_part);
+        if (TS > 1) denc_sum_kernel<float><<<(unsigned)std::min<long long>(4096, (n_dec / 4 + 255) / 256), 256, 0, st>>>(ddec_part, (float *)ddec, n_dec, TS);
         if (two_pass) joint_bwd_y_kernel<float><<<gy, 256, 0, st>>>(dlogits, (const float *)enc, (const float *)dec, W, (float *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
         else denc_sum_kernel<float><<<(unsigned)std::min<long long>(4096, (n_enc / 4 + 255) / 256), 256, 0, st>>>(part, (float *)denc, n_enc, nut);
     } else if (io_dtype == TSASR_BF16) {
-        joint_bwd_x_kernel<bf16_t><<<gx, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part);
+        joint_bwd_x_kernel<bf16_t><<<gx, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)ddec, slab_w, slab_b, tlen, ulen, T, U1, J, V, ldl, slope, part, TS, ddec_part);
+        if (TS > 1) denc_sum_kernel<bf16_t><<<(unsigned)std::min<long long>(4096, (n_dec / 4 + 255) / 256), 256, 0, st>>>(ddec_part, (bf16_t *)ddec, n_dec, TS);
         if (two_pass) joint_bwd_y_kernel<bf16_t><<<gy, 256, 0, st>>>(dlogits, (const bf16_t *)enc, (const bf16_t *)dec, W, (bf16_t *)denc, tlen, ulen, T, U1, J, V, ldl, slope);
         else denc_sum_kernel<bf16_t><<<(unsigned)std::min<long long>(4096, (n_enc / 4 + 255) / 256), 256, 0, st>>>(part, (bf16_t *)denc, n_enc, nut);
     } else {

@@ -142,7 +142,10 @@ def mix_sources(sigs, delays, start, duration, target_speaker_idx, sample_rate=1
             sig = sig * gain
         out.append(torch.nn.functional.pad(sig, [math.ceil(delay * sample_rate), 0]))
     n = max(len(x) for x in out)
-    mixed = torch.stack([torch.nn.functional.pad(x, [0, n - len(x)]) for x in out]).sum(0)
+    out = [torch.nn.functional.pad(x, [0, n - len(x)]) for x in out]
+    mixed = out[0].clone()
+    for x in out[1:]:          # left to right, as the reference adds them (:375-377): fp32 sums of 3+ sources depend on the order
+        mixed += x
     a = math.ceil(start * sample_rate)
     return mixed[a:a + math.ceil(duration * sample_rate)]
 

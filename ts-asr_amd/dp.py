@@ -256,9 +256,12 @@ class GradArena:
         if b["left"] == 0:
             self.flush_wgrads()
 
-    def flush_wgrads(self, side=False):
+    def flush_wgrads(self, side=False, hold=False):
         """Run every queued weight gradient now, ordered after every stream of the step: on the current stream, or (side) on the
-        arena's weight-gradient stream, which finish_backward joins."""
+        arena's weight-gradient stream, which finish_backward joins. ``hold``: the launch happens while other streams of the step are
+        still running (the recipe's early flush under the speaker branch's backward): the operands - some were allocated on those
+        streams - stay referenced until the next flush from finish_backward, after the streams have joined; dropped here, the caching
+        allocator hands their memory to the other stream's next kernels while this launch still reads it."""
         from . import ops
         if ops.wgrad_pending() == 0:
             return
@@ -277,9 +280,13 @@ class GradArena:
             for st in [self._main_stream, self.wgrad_stream if self._wgrad_side_busy else None] + list(self.aux_streams):
                 if st is not None and st != cur:
                     cur.wait_stream(st)
-        ops.wgrad_flush()
-        if self._wgrad_side_busy:
-            self._wgrad_side_busy, self._wgrad_hold = False, []
+        if hold:
+            ops.wgrad_flush(hold=self._wgrad_hold)
+            self._wgrad_side_busy = True           # (no side stream involved: only marks the held operands for the next flush to release)
+        else:
+            ops.wgrad_flush()
+            if self._wgrad_side_busy:
+                self._wgrad_side_busy, self._wgrad_hold = False, []
         if self._sync_this_step and self._order_final:
             for b in self.buckets:
                 if b.get("queued", 0) and b["left"] == 0:
@@ -345,8 +352,9 @@ class GradArena:
         if self.device.type == "cuda":
             from . import ops
             self.flush_wgrads()         # every queued weight gradient, one grouped launch (accumulates into the arena)
-            if self._wgrad_side_busy:   # nothing was left to flush: still join the weight-gradient stream
-                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            if self._wgrad_side_busy:   # nothing was left to flush: still join the weight-gradient stream, release held operands
+                if self.wgrad_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
                 self._wgrad_side_busy, self._wgrad_hold = False, []
             ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()

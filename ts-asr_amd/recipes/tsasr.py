@@ -18,7 +18,31 @@ Stage = core.Stage
 
 
 _OVERLAP_MODE = os.environ.get("TSASR_OVERLAP", "1")
+# A/B knob, off: see _BranchBackwardNow. Measured on the captured step: 13.55 ms off, 14.15 ms on - hipGraph then places the LSTM backward
+# kernel in the hardware queue of the encoder's backward and serialises with it (profiles/r02_notes.md)
+_PREDICTOR_BWD_FIRST = os.environ.get("TSASR_PREDICTOR_BWD_FIRST", "0") != "0"
+_EARLY_WGRAD = os.environ.get("TSASR_WGRAD_EARLY", "1") != "0"   # A/B knob: main-encoder weight gradients launched under the speaker branch's backward
 _OVERLAP_DEFAULT = _OVERLAP_MODE != "0"   # A/B knob: speaker branch + predictor on a second stream
+
+class _BranchBackwardNow(torch.autograd.Function):
+    """Identity that cuts a forked branch (the predictor) out of the main autograd graph and runs that branch's backward the moment
+    its output gradient exists. Autograd runs ready nodes in reverse order of their creation; the predictor is created before the
+    encoder, so its backward - ready as soon as the joint's is done - was issued after the whole encoder's, and its 0.8 ms LSTM kernel
+    (16 CUs) then sat on the side stream in front of the speaker branch's backward, on the step's critical path. This node is created
+    right before the joint, runs right after it, and issues the branch's backward (re-entrant autograd, every node on the stream of its
+    forward) beside the encoder's. Parameter gradients reach the arena exactly as before; only the issue order changes."""
+
+    @staticmethod
+    def forward(ctx, y_leaf, holder):
+        ctx.holder = holder
+        return y_leaf.view_as(y_leaf)
+
+    @staticmethod
+    def backward(ctx, g):
+        y = ctx.holder.pop()
+        torch.autograd.backward(y, g)
+        return None, None
+
 
 class TSASR(core.Brain):
     """One class for the reference's three recipe scripts; ``variant`` says which speaker branch runs:
@@ -89,6 +113,23 @@ class TSASR(core.Brain):
             self._aux_streams.append(self._side)      # Brain joins it after backward
         return self._side
 
+    def _predictor_stream(self):
+        if getattr(self, "_side2", None) is None:
+            self._side2 = torch.cuda.Stream(device=self.device)
+            self._aux_streams.append(self._side2)
+        return self._side2
+
+    def _flush_main_wgrads(self, grad):
+        """Tensor hook on the speaker embedding: fires (on the side stream) when the speaker branch's backward is about to start, i.e.
+        when the mixture encoder's and front-end's backward have been enqueued on the main stream. Their queued weight gradients
+        (three quarters of the step's) are launched there now, as one grouped kernel that runs beside the speaker branch's small,
+        latency-bound backward kernels instead of after them; the rest follows in finish_backward. The gradient passes through."""
+        arena = getattr(self, "arena", None)
+        if arena is not None and arena.in_backward and getattr(arena, "_main_stream", None) is not None:
+            with torch.cuda.stream(arena._main_stream):
+                arena.flush_wgrads(hold=True)
+        return None
+
     def compute_forward(self, batch, stage):
         hp = self.hparams
         epoch = hp.epoch_counter.current if hasattr(hp, "epoch_counter") else 0
@@ -103,7 +144,7 @@ class TSASR(core.Brain):
         # branch's overlaps layer 0 / the front-end's. Works the same inside a captured hipGraph (fork / join become edges).
         overlap = (stage == Stage.TRAIN and self.variant != "none" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT)
                    and torch.device(self.device).type == "cuda")
-        dec_out = None
+        dec_out, side_pred = None, None
         if overlap:
             cur, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(cur)
@@ -111,8 +152,23 @@ class TSASR(core.Brain):
                 spk, enroll_lens = self._speaker_embedding(batch, epoch)
                 spk_ready = torch.cuda.Event()
                 spk_ready.record(side)
-                if _OVERLAP_MODE != "2":     # "2" (diagnostics): only the speaker branch forks, the predictor stays on the main stream
+                if _EARLY_WGRAD and spk is not None and spk.requires_grad:
+                    spk.register_hook(self._flush_main_wgrads)
+                # The predictor joins the fork only while the step is being captured into a hipGraph (mode "3": always). Eager steps
+                # with the predictor on a forked stream showed run-to-run deviations (~1e-4 of the loss, 1-2 % of 8-step runs when the
+                # host is not synchronised every step; tools/eager_repeat.py) whose cause was not found - ruled out: uninitialised
+                # memory, leftover LDS, the persistent LSTM kernels, hipMemsetAsync, the grouped weight gradients.
+                # With only the speaker branch forked 357 such runs were identical; replays of a captured step are bitwise reproducible
+                # across processes (tests/test_recipe_gpu.py). Eager steps are host-bound: the predictor's overlap buys nothing there.
+                if _OVERLAP_MODE == "3" or (_OVERLAP_MODE == "1" and torch.cuda.is_current_stream_capturing()):
                     dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+            if _OVERLAP_MODE == "4":
+                # "4" (A/B, measured equal: 13.43 vs 13.44 ms): the predictor on a stream of its own
+                pstream = self._predictor_stream()
+                pstream.wait_stream(cur)
+                with torch.cuda.stream(pstream):
+                    dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+                side_pred = pstream
 
             def speaker_embs():
                 cur.wait_event(spk_ready)
@@ -135,11 +191,18 @@ class TSASR(core.Brain):
         enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
         enc_out = self.modules.encoder_proj(enc_out)
 
+        if dec_out is None and overlap and _OVERLAP_MODE == "5":
+            # "5" (A/B, measured slower: 14.7 vs 13.45 ms): predictor issued AFTER the encoder so that autograd runs its backward first;
+            # hipGraph then schedules the forward's LSTM kernel in front of the encoder's kernels
+            with torch.cuda.stream(side):
+                dec_out = self._predictor(tokens_bos, tokens_bos_lens)
         if dec_out is None:
             dec_out = self._predictor(tokens_bos, tokens_bos_lens)
         else:
-            cur.wait_stream(side)
+            cur.wait_stream(side_pred if side_pred is not None else side)
             dec_out.record_stream(cur)
+            if _PREDICTOR_BWD_FIRST and dec_out.requires_grad:
+                dec_out = _BranchBackwardNow.apply(dec_out.detach().requires_grad_(), [dec_out])
 
         # joiner + transducer_head fused (train_librispeechmix_scratch.py:132-135)
         head = self.modules.transducer_head.w
