@@ -14,7 +14,7 @@ a = ap.parse_args()
 
 
 def norm(name):
-    n = re.sub(r"\(.*", "", name)
+    n = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     return re.sub(r"^void ", "", n)[:90]
 
 

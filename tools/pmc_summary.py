@@ -8,7 +8,7 @@ ap.add_argument("fetch_csv"); ap.add_argument("write_csv"); ap.add_argument("out
 a = ap.parse_args()
 
 def norm(name):
-    n = re.sub(r"\(.*", "", name)
+    n = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     n = re.sub(r"^void ", "", n)
     m = re.match(r"_Z\d+([A-Za-z0-9_]+?)I", n)
     if n.startswith("_Z") and m:

@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Per-hardware-queue timeline of ONE captured step from a rocprofv3 kernel trace (.db): which kernels ran where and when, and how
-much the queues overlapped (the step's branches run on separate HIP streams; hipGraph maps them to queues). Usage: stream_timeline.py db [step]"""
+much the queues overlapped (the step's branches run on separate HIP streams; hipGraph maps them to queues). Usage: stream_timeline.py db [step]
+[--grep substring]: also list every kernel of the step whose name contains the substring (start, end, queue, kernels of OTHER queues
+that ran during it)."""
 import collections, re, sqlite3, sys
+argv = [a for a in sys.argv[1:]]
+grep = None
+if "--grep" in argv:
+    i = argv.index("--grep"); grep = argv[i + 1].lower(); del argv[i:i + 2]
+sys.argv = [sys.argv[0]] + argv
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
 starts = [i for i, r in enumerate(rows) if "seed_advance" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 6
 step = rows[starts[k]:starts[k + 1]]
 t0 = step[0][1]
-short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:44]
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n.replace("(anonymous namespace)::", "")))[:44]
 print("step %d: %.2f ms, %d kernels" % (k, (step[-1][2] - t0) / 1e6, len(step)))
 segs, prevq = [], None
 for n, s, e, q in step:
@@ -27,3 +34,9 @@ both = act = 0; last = ev[0][0]; busy = collections.Counter()
 for t, d in ev:
     busy[min(act, 2)] += t - last; last = t; act += d
 print("  time with 0 / 1 / >=2 kernels in flight: %.2f / %.2f / %.2f ms" % (busy[0] / 1e6, busy[1] / 1e6, busy[2] / 1e6))
+if grep:
+    hits = [(n, s, e, q) for n, s, e, q in step if grep in n.lower()]
+    print("  %d kernels matching %r:" % (len(hits), grep))
+    for n, s, e, q in hits:
+        others = [short(n2) for n2, s2, e2, q2 in step if q2 != q and s2 < e and e2 > s]
+        print("    %7.3f-%7.3f ms q%d %-40s beside %d kernels of other queues%s" % ((s - t0) / 1e6, (e - t0) / 1e6, q, short(n), len(others), (": " + ", ".join(sorted(set(others))[:3])) if others else ""))

@@ -19,7 +19,7 @@ else:
         rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Grid_Size_X"]), r.get("LDS_Block_Size", ""), r.get("VGPR_Count", "")))
 st = collections.defaultdict(list)
 for name, s, e, gx, lds, vg in rows:
-    nm = re.sub(r"\(.*", "", name)
+    nm = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     nm = re.sub(r"^void ", "", nm)[:84]
     if a.match and a.match not in nm:
         continue

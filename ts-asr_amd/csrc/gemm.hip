@@ -911,6 +911,9 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
     TSASR_CHECK_ARG(!(accumulate && out_dtype != TSASR_F32), "tsasr_gemm_bf16: accumulate needs fp32 output");
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
     hipStream_t st = (hipStream_t)stream;
+    static const bool log_small = getenv("TSASR_GEMM_LOG_SMALL") != nullptr;   // debugging aid: long-K problems that fill few CUs
+    if (log_small && (long long)cdiv(M, tile_bm(p.tile)) * cdiv(N, p.tile == 0 ? 128 : 64) * p.splits <= 16)
+        fprintf(stderr, "[tsasr_gemm_bf16] few tiles: M=%d N=%d K=%d tA=%d tB=%d out=%d acc=%d tile=%d splits=%d\n", M, N, K, transA, transB, out_dtype, accumulate, p.tile, p.splits);
     if (p.splits > 1) {
         TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_gemm_bf16_workspace_bytes(M, N, K, out_dtype), "tsasr_gemm_bf16: workspace too small");
         TSASR_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "tsasr_gemm_bf16: split-K output needs N, ldc multiples of 4");
@@ -954,6 +957,9 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
     GemmPlan pl = plan(M, N, K, 0);
     hipStream_t st = (hipStream_t)stream;
+    static const bool log_small = getenv("TSASR_GEMM_LOG_SMALL") != nullptr;
+    if (log_small && (long long)cdiv(M, tile_bm(pl.tile)) * cdiv(N, pl.tile == 0 ? 128 : 64) <= 16)
+        fprintf(stderr, "[tsasr_gemm_bf16_fused] few tiles: M=%d N=%d K=%d tA=%d tB=%d mode=%d tile=%d\n", M, N, K, transA, transB, epi_mode, pl.tile);
     if (!transA && !transB && g_force_tile < 0) {
         const int bm = tsasr_gemm_big_bm(M, N, K);
         float *colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;

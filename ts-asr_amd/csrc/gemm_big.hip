@@ -4,7 +4,7 @@
 // (SB/nnet/attention.py:820-836 `PositionalwiseFeedForward.ffn`: Linear(D, 4D... d_ffn) -> activation -> Dropout -> Linear(d_ffn, D);
 // M = B*T' = 8000 rows, N = d_ffn = 2048, K = d_model = 256), the 128x128 / 4-wave tiles of csrc/gemm.hip. At K = 256 such a GEMM
 // is not MFMA-bound but bound by what a CU can take in per second (LDS-DMA from L2 / Infinity Cache: ~40 GB/s per CU with every CU
-// loading, profiles/r02_wgrad_notes.md): 1008 tiles of 128x128 move 129 MB through the CUs' load paths, 256 tiles of 256x256 move 67 MB.
+// loading, profiles/r02_notes.md): 1008 tiles of 128x128 move 129 MB through the CUs' load paths, 256 tiles of 256x256 move 67 MB.
 //   workgroup = 512 threads = 8 waves as 2 (M) x 4 (N); wave tile (BM/2) x 64 of v_mfma_f32_32x32x16_bf16 blocks
 //   k-tile = [BM + 256 rows][64 k] (128-byte rows) filled by LDS-DMA issued as inline asm (see csrc/wgrad.hip: through the builtin
 //   hipcc drains the DMA in front of the fragment reads), XOR swizzle on the SOURCE chunk, two slots, counted waits, raw s_barrier

@@ -109,7 +109,9 @@ class TSASR(core.Brain):
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # TSASR_SIDE_PRIORITY=-1: a high-priority stream for the forked branches (their kernels are small and sit on the critical path
+            # at the joins; the main stream's are large)
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("TSASR_SIDE_PRIORITY", "0")))
             self._aux_streams.append(self._side)      # Brain joins it after backward
         return self._side
 
