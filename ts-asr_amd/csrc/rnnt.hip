@@ -588,28 +588,44 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
     }
 }
 
-// (2) alpha / beta: one wave per (utterance, direction). blockIdx.x = 2b + dir.
-template <int K>
-__global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int32_t *__restrict__ tlen,
-                                                            const int32_t *__restrict__ ulen, float *__restrict__ costs,
-                                                            int Tn, int U1) {
-    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1, l = threadIdx.x;
+// (2) alpha / beta: one workgroup of NW waves per (utterance, direction), blockIdx.x = 2b + dir. Thread g = wave * 64 + lane owns the K
+// columns u = K*g .. K*g+K-1 and is skewed by g frames (alpha: t = s - g at step s), so a step needs only the value the neighbouring
+// thread produced in the step before: inside a wave by a DPP wave shift, across a wave boundary through one LDS word per wave
+// (double-buffered by step parity) behind the step's workgroup barrier. NW = 1 (short targets: the benchmark's U = 120 is K = 2) has
+// neither LDS nor barriers; long targets spread over up to 16 waves (U = 1920: 16 waves x 64 lanes x 2 columns) instead of 32
+// sequentially dependent columns per lane in ONE wave (49.7 ms of an 85 ms long-form step before).
+// end of a lattice step: the boundary words in LDS are visible to the other waves. NOT __syncthreads(): that also waits for every
+// outstanding global load (s_waitcnt vmcnt(0)) - here the operands of the next eight steps, requested on purpose - and made a step
+// cost a full memory round trip (1.5 - 3 us per step with 4 - 16 waves)
+__device__ __forceinline__ void ab_step_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const int32_t *__restrict__ tlen,
+                                                                 const int32_t *__restrict__ ulen, float *__restrict__ costs,
+                                                                 int Tn, int U1) {
+    constexpr int G = 64 * NW;
+    __shared__ float edge_lds[2][NW > 1 ? NW : 1];
+    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1, g = threadIdx.x, l = g & 63, wave = g >> 6;
     const int U1P = w.U1P;
     const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
-    const size_t base = (size_t)b * Tn * U1P + (size_t)K * l;
-    const int nsteps = Tb + 63;
+    const size_t base = (size_t)b * Tn * U1P + (size_t)K * g;
+    const int nsteps = Tb + G - 1;
     float prev[K], cur[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) prev[i] = NEG_INF;
-    float edge = NEG_INF;  // boundary value handed to the neighbour lane
-    // The per-step operands (log-probabilities of blank / label for this lane's K columns at its current frame) are requested PF
+    float edge = NEG_INF;  // boundary value handed to the neighbour thread
+    // The per-step operands (log-probabilities of blank / label for this thread's K columns at its current frame) are requested PF
     // steps ahead, unconditionally (frame index clamped): fetched inside the guarded step they cost one L2 round trip per step,
-    // and the Tb + 63 steps are strictly sequential (310 us for 313 steps before; the arithmetic of a step is ~50 cycles).
+    // and the steps are strictly sequential (310 us for 313 steps before; the arithmetic of a step is ~50 cycles).
     constexpr int PF = 8;
     float qb[PF][K], qe[PF][K];
     if (dir == 0) {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
-            const int t = min(max(ss - l, 0), Tb - 1);
+            const int t = min(max(ss - g, 0), Tb - 1);
             const float *pb = w.lpb + base + (size_t)(t > 0 ? t - 1 : 0) * U1P;
             const float *pe = w.lpe_in + base + (size_t)t * U1P;
 #pragma unroll
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
         };
 #pragma unroll
         for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
-        // a chunk of PF steps; GUARD = false when every lane has a valid frame in every step of the chunk (63 <= s < Tb): that
+        // a chunk of PF steps; GUARD = false when every thread has a valid frame in every step of the chunk (G-1 <= s < Tb): that
         // version is straight-line code, so the compiler can count the outstanding prefetches exactly instead of draining them
         // (s_waitcnt vmcnt(0)) behind every divergent guard
         auto chunk = [&](int s0, auto guard_tag) {
@@ -626,12 +642,13 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
                 if (GUARD && s >= nsteps) break;
-                const int t = s - l;
-                const float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                const int t = s - g;
+                float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                if (NW > 1 && l == 0 && wave > 0) left = edge_lds[(s + 1) & 1][wave - 1];          // written in step s-1
                 if (!GUARD || (t >= 0 && t < Tb)) {
 #pragma unroll
                     for (int i = 0; i < K; ++i) {
-                        const int u = K * l + i;
+                        const int u = K * g + i;
                         const float noemit = (t > 0) ? prev[i] + qb[d][i] : NEG_INF;
                         const float lft = (i == 0) ? left : cur[i > 0 ? i - 1 : 0];
                         const float emit = (u > 0) ? lft + qe[d][i] : NEG_INF;
@@ -643,10 +660,11 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
 #pragma unroll
                     for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
                     edge = cur[K - 1];
+                    if (NW > 1 && l == 63) edge_lds[s & 1][wave] = edge;
                     if (GUARD && t == Tb - 1) {
 #pragma unroll
                         for (int i = 0; i < K; ++i)
-                            if (K * l + i == Ub) {
+                            if (K * g + i == Ub) {
                                 const float lp = cur[i] + w.lpb[base + (size_t)t * U1P + i];
                                 w.logp[b] = lp;
                                 costs[b] = -lp;
@@ -654,15 +672,16 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
                     }
                 }
                 fetch(s + PF, qb[d], qe[d]);
+                if (NW > 1) ab_step_barrier();
             }
         };
         for (int s0 = 0; s0 < nsteps; s0 += PF) {
-            if (s0 >= 63 && s0 + PF < Tb) chunk(s0, std::false_type{});   // (t == Tb-1 only occurs in guarded chunks)
+            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});   // (t == Tb-1 only occurs in guarded chunks)
             else chunk(s0, std::true_type{});
         }
     } else {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
-            const int t = min(max(Tb - 1 - (ss - (63 - l)), 0), Tb - 1);
+            const int t = min(max(Tb - 1 - (ss - (G - 1 - g)), 0), Tb - 1);
             const float *pb = w.lpb + base + (size_t)t * U1P;
             const float *pe = w.lpe_out + base + (size_t)t * U1P;
 #pragma unroll
@@ -676,12 +695,13 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
                 if (GUARD && s >= nsteps) break;
-                const int t = Tb - 1 - (s - (63 - l));
-                const float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                const int t = Tb - 1 - (s - (G - 1 - g));
+                float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                if (NW > 1 && l == 63 && wave < NW - 1) right = edge_lds[(s + 1) & 1][wave + 1];
                 if (!GUARD || (t >= 0 && t < Tb)) {
 #pragma unroll
                     for (int i = K - 1; i >= 0; --i) {
-                        const int u = K * l + i;
+                        const int u = K * g + i;
                         const float lb = qb[d][i];
                         const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
                         const float rgt = (i == K - 1) ? right : cur[i < K - 1 ? i + 1 : K - 1];
@@ -694,12 +714,14 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(RnntWs w, const int3
 #pragma unroll
                     for (int i = 0; i < K; ++i) { pbeta[i] = cur[i]; prev[i] = cur[i]; }
                     edge = cur[0];
+                    if (NW > 1 && l == 0) edge_lds[s & 1][wave] = edge;
                 }
                 fetch(s + PF, qb[d], qe[d]);
+                if (NW > 1) ab_step_barrier();
             }
         };
         for (int s0 = 0; s0 < nsteps; s0 += PF) {
-            if (s0 >= 63 && s0 + PF < Tb) chunk(s0, std::false_type{});
+            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});
             else chunk(s0, std::true_type{});
         }
     }
@@ -753,9 +775,40 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict_
     }
 }
 
-template <int K>
+template <int K, int NW>
 static void launch_ab(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
-    rnnt_alphabeta_kernel<K><<<2 * B, 64, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    rnnt_alphabeta_kernel<K, NW><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+}
+
+// columns per lane of the one-wave layout -> (columns per thread, waves): TSASR_RNNT_WAVES caps the waves (1 = always one wave)
+static void launch_alphabeta(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
+    // measured at B = 1, T' = 4000, U = 1920 (32 columns per lane in one wave): 1 wave 50.5 ms, 2 waves 12.7, 4 waves 6.2, 8 waves 8.9,
+    // 16 waves 15.3 - with four waves the kernel streams its 100 MB of log-probabilities and alphas at what ONE CU pulls from HBM
+    // (~17 GB/s); more waves only add barrier arrivals per step. (Spreading one utterance over several CUs is the next step.)
+    static const int max_waves = getenv("TSASR_RNNT_WAVES") ? atoi(getenv("TSASR_RNNT_WAVES")) : 4;
+    const int waves = std::min(max_waves, w.K >= 8 ? w.K / 4 : 1);
+    switch (w.K) {
+        case 1: launch_ab<1, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 2: launch_ab<2, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 4: launch_ab<4, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
+        case 8:
+            if (waves >= 4) launch_ab<2, 4>(w, tlen, ulen, costs, B, T, U1, st);
+            else if (waves >= 2) launch_ab<4, 2>(w, tlen, ulen, costs, B, T, U1, st);
+            else launch_ab<8, 1>(w, tlen, ulen, costs, B, T, U1, st);
+            break;
+        case 16:
+            if (waves >= 8) launch_ab<2, 8>(w, tlen, ulen, costs, B, T, U1, st);
+            else if (waves >= 4) launch_ab<4, 4>(w, tlen, ulen, costs, B, T, U1, st);
+            else launch_ab<16, 1>(w, tlen, ulen, costs, B, T, U1, st);
+            break;
+        default:
+            if (waves >= 16) launch_ab<2, 16>(w, tlen, ulen, costs, B, T, U1, st);
+            else if (waves >= 8) launch_ab<4, 8>(w, tlen, ulen, costs, B, T, U1, st);
+            else if (waves >= 4) launch_ab<8, 4>(w, tlen, ulen, costs, B, T, U1, st);
+            else if (waves >= 2) launch_ab<16, 2>(w, tlen, ulen, costs, B, T, U1, st);
+            else launch_ab<32, 1>(w, tlen, ulen, costs, B, T, U1, st);
+            break;
+    }
 }
 
 // ============================================================================================
@@ -901,14 +954,7 @@ int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, co
     RnntWs w = rnnt_carve(workspace, B, T, U1);
     const long long rows = (long long)B * T * U1;
     rnnt_lp_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(logits, targets, ldt, tlen, ulen, w, B, T, U1, V, ldl, blank);
-    switch (w.K) {
-        case 1: launch_ab<1>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 2: launch_ab<2>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 4: launch_ab<4>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 8: launch_ab<8>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 16: launch_ab<16>(w, tlen, ulen, costs, B, T, U1, st); break;
-        default: launch_ab<32>(w, tlen, ulen, costs, B, T, U1, st); break;
-    }
+    launch_alphabeta(w, tlen, ulen, costs, B, T, U1, st);
     TSASR_CHECK_LAUNCH("tsasr_rnnt_loss_fwd");
     return 0;
 }
