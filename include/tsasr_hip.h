@@ -50,7 +50,8 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
                     int B, int T, int U1, int J, int V, int ldl, int io_dtype, float slope, void *stream);
 
 size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J);
-/* Backward of the above: denc[b,t,:], ddec[b,u,:] (io_dtype), dW[V,J], dbias[V] (fp32, OVERWRITTEN).
+/* Backward of the above: denc[b,t,:], ddec[b,u,:] (io_dtype), dW[V,J], dbias[V] (fp32, OVERWRITTEN; while tsasr_reduce_defer(1)
+ * is in force the two are parameter-gradient outputs like the others: written by tsasr_reduce_flush, workspace kept until then).
  * tlen/ulen (may be NULL = full) let the kernel skip the part of the lattice whose dlogits are zero. */
 int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, const float *W,
                     void *denc, void *ddec, float *dW, float *dbias,

@@ -15,17 +15,28 @@
 
 __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float *__restrict__ g, float *__restrict__ part, long long n) {
     __shared__ float red[4];
-    const long long per = (n + OPT_PARTS - 1) / OPT_PARTS;
-    const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
-    float s = 0.f;
-    for (long long i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
-        if (i + 4 <= hi && ((lo & 3) == 0)) {
-            const float4 v = *reinterpret_cast<const float4 *>(g + i);
-            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        } else {
-            for (long long k = i; k < min(hi, i + 4); ++k) s += g[k] * g[k];
-        }
+    // a part is a multiple of 4 elements, so every part starts 16-byte aligned (with n / 1024 rounded up to an odd number three parts
+    // out of four started misaligned and fell back to scalar loads: 82 us for 204 MB)
+    const long long per = (((n + OPT_PARTS - 1) / OPT_PARTS) + 3) & ~3ll;
+    const long long lo = min(n, (long long)blockIdx.x * per), hi = min(n, lo + per);
+    const long long hi4 = lo + ((hi - lo) & ~3ll);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long i = lo + threadIdx.x * 4;
+    for (; i + 3 * 1024 + 4 <= hi4; i += 4 * 1024) {     // four independent 16-byte loads in flight per thread
+        const float4 a = *reinterpret_cast<const float4 *>(g + i), b = *reinterpret_cast<const float4 *>(g + i + 1024);
+        const float4 c = *reinterpret_cast<const float4 *>(g + i + 2048), d = *reinterpret_cast<const float4 *>(g + i + 3072);
+        s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
     }
+    for (; i + 4 <= hi4; i += 1024) {
+        const float4 a = *reinterpret_cast<const float4 *>(g + i);
+        s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    if (threadIdx.x == 0)
+        for (long long k = hi4; k < hi; ++k) s0 += g[k] * g[k];
+    float s = (s0 + s1) + (s2 + s3);
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -184,7 +184,7 @@ extern "C" {
 /* 1: reductions of partial gradient rows / split-K slabs requested from now on are queued (their partial buffers and outputs
  * must stay alive and untouched until tsasr_reduce_flush); 0: launched immediately (default). Switching off with jobs still
  * queued is an error. Only calls that declare it take part: tsasr_gemm_bf16(accumulate = 2) and the *_bwd kernels' parameter
- * gradient outputs (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias). */
+ * gradient outputs (dgamma, dbeta, dbias, conv-module dparams, fused-GEMM dbias, front-end block dparams, the joint's dW / dbias). */
 int tsasr_reduce_defer(int on) {
     TSASR_CHECK_ARG(on || g_jobs.empty(), "tsasr_reduce_defer(0) with %d reductions still queued: call tsasr_reduce_flush first", (int)g_jobs.size());
     g_defer = on ? 1 : 0;

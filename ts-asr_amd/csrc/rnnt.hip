@@ -930,7 +930,13 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     } else {
         TSASR_CHECK_ARG(false, "tsasr_joint_bwd: bad io_dtype %d", io_dtype);
     }
-    joint_bwd_reduce_kernel<<<cdiv(V * J, 256), 256, 0, st>>>(slab_w, slab_b, dW, dbias, (int)nslab, J, V);
+    static const bool joint_defer = !(getenv("TSASR_JOINT_DEFER") && getenv("TSASR_JOINT_DEFER")[0] == '0');   // A/B knob
+    if (tsasr_reduce_deferring() && joint_defer) {   // head-weight slabs join the batched reduction at the end of backward (the loop kernel below walks
+        tsasr_reduce_submit(slab_w, dW, (long long)32 * J, (int)nslab, V * J, 0, st);   // 128 slabs serially per thread: 57 us on the main stream)
+        tsasr_reduce_submit(slab_b, dbias, 32, (int)nslab, V, 0, st);
+    } else {
+        joint_bwd_reduce_kernel<<<cdiv(V * J, 256), 256, 0, st>>>(slab_w, slab_b, dW, dbias, (int)nslab, J, V);
+    }
     TSASR_CHECK_LAUNCH("tsasr_joint_bwd");
     return 0;
 }

@@ -53,7 +53,8 @@ class _JointLogitsFn(torch.autograd.Function):
             C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
                                             C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), C.io_dtype(enc), ctx.slope,
                                             C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_bwd")
-        from .ops import _pgrad
+        from .ops import _keep, _pgrad
+        _keep(dW, db, ws)     # while reductions are deferred the two are filled from the slabs in `ws` by the batched launch at the end of backward
         return denc, ddec, _pgrad(ctx.params[0], dW), _pgrad(ctx.params[1], db), None, None, None
 
 
