@@ -25,6 +25,16 @@ def test_rccl_collectives_captured_in_graph_and_replayed():
     assert "RCCL single-rank path OK" in r.stdout
 
 
+def test_two_ranks_on_one_gpu_over_gloo_equal_single_process():
+    """Data parallel with device tensors: two ranks share the GPU, gloo carries the bucket all-reduces (tools/dp_gloo_gpu_check.py):
+    ranks end with identical weights, equal to one process on the whole batch up to bf16 rounding. RCCL / xGMI are not exercised."""
+    env = dict(os.environ, MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_gloo_gpu_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    sys.stdout.write(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "two-rank data parallel on one GPU (gloo) OK" in r.stdout
+
+
 def test_speed_perturbation_varies_under_hip_graph():
     """`augment: True` + enable_hip_graph(): the speed SpeedPerturb picks per batch (speech_augmentation.py:480-493) must keep varying -
     drawn on the host before each replay, one graph per (batch shape, speed) - and the run must equal the eager run step for step."""

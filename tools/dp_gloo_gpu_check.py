@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Data parallelism of the REAL model on the device with two ranks sharing ONE GPU (gloo carries the bucket all-reduces; RCCL refuses
+two ranks on one device): every rank runs the HIP path on its half of the configs[0] golden batch, the gradient arena averages the
+buckets, and after three SGD steps (no clipping: the weight change IS the averaged gradient times the step size) all ranks must hold the same weights,
+equal - to rounding - to ONE process training on the whole batch. Checks bucketing, averaging, parameter broadcast and stream joins of
+dp.GradArena with device tensors; it does NOT exercise RCCL or xGMI. usage: python tools/dp_gloo_gpu_check.py            (parent)"""
+import functools, importlib, os, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+STEPS, LR = 3, 3e-4
+
+
+def train(rank, world, out):
+    import torch
+    entry = importlib.import_module("__graft_entry__")
+    hp = importlib.import_module(entry.PKG + ".hparams")
+    tsasr = importlib.import_module(entry.PKG + ".recipes.tsasr")
+    dp = importlib.import_module(entry.PKG + ".dp")
+    bm = importlib.import_module(entry.PKG + ".batch")
+    from oracle.golden_recipe import CFG1, golden_inputs, load_det_weights
+    run_opts = {"device": "cuda:0", "compute_dtype": "bf16"}
+    if world > 1:
+        run_opts.update(distributed_launch=True, distributed_backend="gloo")
+        dp.ddp_init_group(run_opts)
+    c = CFG1
+    ov = dict(d_model=c["d_model"], nhead=c["nhead"], encoder_num_layers=c["encoder_num_layers"], speaker_num_layers=c["speaker_num_layers"],
+              d_ffn=c["d_ffn"], joint_dim=c["joint_dim"], decoder_neurons=c["decoder_neurons"], dropout=0.0, compute_dtype="bf16",
+              max_grad_norm=0.0, enable_scheduler=False)
+    with open(os.path.join(ROOT, "hparams", "conformer-t_scratch_mi355x.yaml")) as f:
+        h = hp.load_hyperpyyaml(f, ov)
+    for name, mod in h["modules"].items():
+        if isinstance(mod, torch.nn.Module):
+            load_det_weights(mod, name + ".")
+            if rank:                      # ranks start from different weights: the arena must adopt rank 0's
+                with torch.no_grad():
+                    for p in mod.parameters():
+                        if p.requires_grad:
+                            p.mul_(1.5)
+    brain = tsasr.TSASR(h["modules"], functools.partial(torch.optim.SGD, lr=LR), h, run_opts)
+    inp = golden_inputs()
+    idx = torch.arange(rank, 4, world)
+    T = lambda k: torch.from_numpy(inp[k])[idx]  # noqa: E731   (rows of the padded batch: widths, hence relative lengths, unchanged)
+    batch = bm.PaddedBatch({
+        "id": [str(int(i)) for i in idx],
+        "mixed_sig": bm.PaddedData(T("mixed_sig"), T("mixed_lens")), "enroll_sig": bm.PaddedData(T("enroll_sig"), T("enroll_lens")),
+        "tokens_bos": bm.PaddedData(T("tokens_bos"), T("tokens_bos_lens")), "tokens": bm.PaddedData(T("tokens"), T("tokens_lens")),
+    }).to("cuda:0")
+    brain.modules.train()
+    losses = [float(brain.fit_batch(batch)) for _ in range(STEPS)]
+    torch.cuda.synchronize()
+    sd = {f"{n}.{k}": v.detach().float().cpu() for n, m in brain.modules.items() if isinstance(m, torch.nn.Module) for k, v in m.state_dict().items()}
+    torch.save({"sd": sd, "losses": losses, "buckets": len(brain.arena.buckets), "sent": len(brain.arena.sent_log)}, out)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        train(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+        sys.exit(0)
+    import torch
+    d = tempfile.mkdtemp()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", TSASR_RCCL_DIRECT="0", TSASR_BUCKET_MB="4")   # 24 MB of gradients -> several buckets
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", os.path.join(d, f"r{r}.pt")],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [0, 0], rcs
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    assert subprocess.call([sys.executable, os.path.abspath(__file__), "--child", "0", "1", os.path.join(d, "single.pt")], env=env1) == 0
+    r0, r1, s = (torch.load(os.path.join(d, f)) for f in ("r0.pt", "r1.pt", "single.pt"))
+    print("losses: single", s["losses"], "rank0", r0["losses"], "rank1", r1["losses"], "| buckets", r0["buckets"], "collectives in the last step", r0["sent"])
+    worst = 0.0
+    for k in s["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"ranks diverged: {k}"
+        a, b = r0["sd"][k].double(), s["sd"][k].double()
+        if a.numel() and float(b.norm()) > 0:
+            worst = max(worst, float((a - b).norm() / b.norm()))
+    # mean of the two ranks' losses = the single process's loss on the whole batch (same utterances)
+    m = [(x + y) / 2 for x, y in zip(r0["losses"], r1["losses"])]
+    print("mean of rank losses", m, "worst relative-L2 weight difference DP vs single process: %.3e" % worst)
+    # (bf16 activations: the two halves of the batch round their weight-gradient sums differently from the whole batch - measured
+    #  4e-8 / 5e-5 / 8e-5 on the three losses, 3.4e-5 on the weights)
+    assert all(abs(x - y) <= 5e-4 * abs(y) for x, y in zip(m, s["losses"])), (m, s["losses"])
+    assert worst < 5e-4, worst
+    assert r0["buckets"] >= 3 and r0["sent"] == r0["buckets"]
+    print("two-rank data parallel on one GPU (gloo) OK")

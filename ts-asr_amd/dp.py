@@ -78,7 +78,9 @@ def direct_rccl_init(world, rank, device, force=False):
 
 
 class GradArena:
-    def __init__(self, modules, world_size=1, bucket_bytes=32 << 20, group=None):
+    def __init__(self, modules, world_size=1, bucket_bytes=None, group=None):
+        if bucket_bytes is None:    # 32 MiB buckets (6-7 per step at 51 M parameters); TSASR_BUCKET_MB for tests with small models
+            bucket_bytes = int(float(os.environ.get("TSASR_BUCKET_MB", "32")) * (1 << 20))
         seen, params = set(), []
         for p in modules.parameters():
             if p.requires_grad and id(p) not in seen:
@@ -106,6 +108,11 @@ class GradArena:
         self.sync_enabled = True
         self._sync_this_step = False
         self._order_seen, self._order_final = [], False
+        # gradient contributions per parameter and backward pass (a weight used by two GEMMs - the two halves of the `cat` injection's
+        # projection - reports twice): recorded on the unordered first pass; a bucket is complete when ALL of them are in. Counting
+        # parameters instead sent layer 0's bucket one contribution early and the late one landed on top of the averaged gradient -
+        # ranks drifted apart (tools/dp_gloo_gpu_check.py)
+        self._contrib, self._contrib_step = {}, {}
         self._handles, self.sent_log = [], []
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
@@ -245,6 +252,7 @@ class GradArena:
         rest of backward (a long kernel on fewer than 256 CUs next to many short, latency-bound ones) instead of after it."""
         if not self._order_final:
             self._order_seen.append(p)
+            self._contrib_step[id(p)] = self._contrib_step.get(id(p), 0) + 1
         from . import ops
         if not self._sync_this_step or not self._order_final:
             if _WGRAD_ASYNC_TILES and ops.wgrad_pending_tiles() >= _WGRAD_ASYNC_TILES:
@@ -302,12 +310,15 @@ class GradArena:
             from . import ops
             ops.reduce_defer_begin(self.device)
         for b in self.buckets:
-            b["left"], b["sent"], b["queued"] = len(b["ids"]), False, 0
+            b["left"], b["sent"], b["queued"] = sum(self._contrib.get(i, 1) for i in b["ids"]), False, 0
+        if not self._order_final:
+            self._contrib_step = {}
         self._handles, self.sent_log = [], []
 
     def _on_grad(self, p):
         if not self._order_final:
             self._order_seen.append(p)
+            self._contrib_step[id(p)] = self._contrib_step.get(id(p), 0) + 1
         if not self._sync_this_step or not self._order_final:
             return
         b = self.bucket_of[id(p)]
@@ -394,6 +405,7 @@ class GradArena:
             order = self._agree_order(order)
             self._layout(order)
             self._order_final, self._reorder_pending, self._order_seen = True, False, []
+            self._contrib = dict(self._contrib_step)
 
     def _agree_order(self, order):
         """Every rank must cut the SAME buckets: rank 0's recorded backward order is broadcast (as indices into the construction
