@@ -25,11 +25,15 @@ def test_rccl_collectives_captured_in_graph_and_replayed():
     assert "RCCL single-rank path OK" in r.stdout
 
 
-def test_two_ranks_on_one_gpu_over_gloo_equal_single_process():
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_on_one_gpu_over_gloo_equal_single_process(graph):
     """Data parallel with device tensors: two ranks share the GPU, gloo carries the bucket all-reduces (tools/dp_gloo_gpu_check.py):
-    ranks end with identical weights, equal to one process on the whole batch up to bf16 rounding. RCCL / xGMI are not exercised."""
-    env = dict(os.environ, MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_gloo_gpu_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    ranks end with identical weights, equal to one process on the whole batch up to bf16 rounding - eagerly (bucket collectives from the
+    gradient hooks, overlapped with backward) and with the step captured (one all-reduce between replay and optimizer: gloo cannot be
+    captured). RCCL / xGMI are not exercised."""
+    env = dict(os.environ, MASTER_PORT=str(29900 + os.getpid() % 90 + (7 if graph else 0)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_gloo_gpu_check.py")] + (["--graph"] if graph else []), env=env,
+                       capture_output=True, text=True, timeout=900)
     sys.stdout.write(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "two-rank data parallel on one GPU (gloo) OK" in r.stdout

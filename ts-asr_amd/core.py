@@ -318,12 +318,18 @@ class Brain:
             self._copy_batch(batch, key)
         self._graphs[flavour].replay()
         if should_step:
-            if self.distributed and not _GRAPH_COMM:   # A/B form: one big averaged all-reduce between the two halves of the step
+            if self.distributed and not self._graph_comm():   # one big averaged all-reduce between the two halves of the step
                 self.arena.allreduce_all()
                 self.optimizer.launch()
                 self.arena.zero_()
             self.optimizer_step += 1
         return self._static_loss[flavour]
+
+    def _graph_comm(self):
+        """Collectives inside the captured step: only through the direct RCCL C-ABI (csrc/comm.hip), whose launches are plain stream work.
+        torch.distributed's gloo (and ProcessGroupNCCL's watchdog) cannot be captured: then the arena is all-reduced in one piece between
+        the replayed graph and the optimizer (TSASR_GRAPH_COMM=0 forces that form for A/B runs)."""
+        return bool(self.distributed and _GRAPH_COMM and getattr(self.arena, "direct", False))
 
     def _capture(self, batch, should_step, key):
         if key not in self._static_batches:
@@ -336,7 +342,7 @@ class Brain:
         # invalidating the capture (single rank keeps the strict default)
         mode = "thread_local" if self.distributed else "global"
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
-            loss, _ = self._device_step(self._static_batches[key], should_step, comm=self.distributed and _GRAPH_COMM)
+            loss, _ = self._device_step(self._static_batches[key], should_step, comm=self._graph_comm())
         from . import ops as _ops
         _ops.upload_captured_tables()             # job tables of the captured flushes: uploaded once, now (replays carry no memcpy node)
         self.arena.upload_captured_tables()
