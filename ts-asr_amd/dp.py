@@ -264,7 +264,7 @@ class GradArena:
         if b["left"] == 0:
             self.flush_wgrads()
 
-    def flush_wgrads(self, side=False, hold=False):
+    def flush_wgrads(self, side=False, hold=False, release=False):
         """Run every queued weight gradient now, ordered after every stream of the step: on the current stream, or (side) on the
         arena's weight-gradient stream, which finish_backward joins. ``hold``: the launch happens while other streams of the step are
         still running (the recipe's early flush under the speaker branch's backward): the operands - some were allocated on those
@@ -272,6 +272,7 @@ class GradArena:
         allocator hands their memory to the other stream's next kernels while this launch still reads it."""
         from . import ops
         if ops.wgrad_pending() == 0:
+            self._send_completed()      # (an earlier flush may have finished a bucket's queued gradients before its last plain gradient came in)
             return
         if side and self.device.type == "cuda":
             if self.wgrad_stream is None:
@@ -293,8 +294,12 @@ class GradArena:
             self._wgrad_side_busy = True           # (no side stream involved: only marks the held operands for the next flush to release)
         else:
             ops.wgrad_flush()
-            if self._wgrad_side_busy:
+            if self._wgrad_side_busy and release:    # held operands go only once every stream of the step has joined (finish_backward)
                 self._wgrad_side_busy, self._wgrad_hold = False, []
+        self._send_completed()
+
+    def _send_completed(self):
+        """Buckets whose every contribution is in and whose queued weight gradients have been launched: all-reduce them now."""
         if self._sync_this_step and self._order_final:
             for b in self.buckets:
                 if b.get("queued", 0) and b["left"] == 0:
@@ -362,7 +367,7 @@ class GradArena:
     def finish_backward(self):
         if self.device.type == "cuda":
             from . import ops
-            self.flush_wgrads()         # every queued weight gradient, one grouped launch (accumulates into the arena)
+            self.flush_wgrads(release=True)   # every queued weight gradient, one grouped launch (accumulates into the arena)
             if self._wgrad_side_busy:   # nothing was left to flush: still join the weight-gradient stream, release held operands
                 if self.wgrad_stream is not None:
                     torch.cuda.current_stream().wait_stream(self.wgrad_stream)
