@@ -49,6 +49,9 @@ def train(rank, world, out):
     }).to("cuda:0")
     brain.modules.train()
     steps = STEPS
+    if os.environ.get("TSASR_DP_CHECK_ACCUM"):           # gradient accumulation: no_sync micro-steps, collectives on the stepping one only
+        brain.grad_accumulation_factor = int(os.environ["TSASR_DP_CHECK_ACCUM"])
+        steps = STEPS * brain.grad_accumulation_factor
     if os.environ.get("TSASR_DP_CHECK_GRAPH") == "1":     # captured step: the collectives run between the replayed graph and the optimizer
         brain.enable_hip_graph(warmup_steps=2)
         steps = STEPS + 3
@@ -69,6 +72,10 @@ if __name__ == "__main__":
     import torch
     if "--graph" in sys.argv:
         os.environ["TSASR_DP_CHECK_GRAPH"] = "1"
+    if "--accum" in sys.argv:
+        os.environ["TSASR_DP_CHECK_ACCUM"] = "2"
+    if "--bf16-payload" in sys.argv:
+        os.environ["TSASR_ALLREDUCE_DTYPE"] = "bf16"
     d = tempfile.mkdtemp()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), WORLD_SIZE="2",
                HSA_ENABLE_IPC_MODE_LEGACY="0", TSASR_RCCL_DIRECT="0", TSASR_BUCKET_MB="4")   # 24 MB of gradients -> several buckets
@@ -91,8 +98,9 @@ if __name__ == "__main__":
     print("mean of rank losses", m, "worst relative-L2 weight difference DP vs single process: %.3e" % worst)
     # (bf16 activations: the two halves of the batch round their weight-gradient sums differently from the whole batch - measured
     #  4e-8 / 5e-5 / 8e-5 on the three losses, 3.4e-5 on the weights)
-    assert all(abs(x - y) <= 5e-4 * abs(y) for x, y in zip(m, s["losses"])), (m, s["losses"])
-    assert worst < 5e-4, worst
+    tol = 2e-2 if os.environ.get("TSASR_ALLREDUCE_DTYPE") == "bf16" else 5e-4     # bf16 payload: the averaged gradient is rounded to 8 bits
+    assert all(abs(x - y) <= tol * abs(y) for x, y in zip(m, s["losses"])), (m, s["losses"])
+    assert worst < tol, worst
     assert r0["buckets"] >= 3
     if os.environ.get("TSASR_DP_CHECK_GRAPH") != "1":
         assert r0["sent"] == r0["buckets"]      # (captured step over gloo: one all-reduce of the whole arena after the replay instead)
