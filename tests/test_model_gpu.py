@@ -191,6 +191,38 @@ def test_hip_graph_replay_equals_eager(accum):
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("accum", [1, 2])
+def test_hip_graph_replay_equals_eager_with_a_torch_optimizer(accum):
+    """Same, with an optimizer that is not the fused AdamW kernel (torch SGD, no clipping - so that, unlike Adam, the update is
+    sensitive to the gradient's scale and to stale operands): the bf16 shadow of the weights has to be rewritten inside the captured
+    step (dp.GradArena.sync_shadow); a replay otherwise keeps multiplying with the weights of the capture step."""
+    import functools
+    hp = importlib.import_module("ts-asr_amd.hparams")
+    tsasr = importlib.import_module("ts-asr_amd.recipes.tsasr")
+    from oracle.golden_recipe import load_det_weights
+    inp = golden_inputs()
+    c = CFG1
+    losses = {}
+    for mode in ("eager", "graph"):
+        ov = dict(d_model=c["d_model"], nhead=c["nhead"], encoder_num_layers=c["encoder_num_layers"], speaker_num_layers=c["speaker_num_layers"],
+                  d_ffn=c["d_ffn"], joint_dim=c["joint_dim"], decoder_neurons=c["decoder_neurons"], dropout=0.0, compute_dtype="bf16",
+                  max_grad_norm=0.0, enable_scheduler=False)
+        with open(os.path.join(entry.ROOT, "hparams", "conformer-t_scratch_mi355x.yaml")) as f:
+            h = hp.load_hyperpyyaml(f, ov)
+        for name, mod in h["modules"].items():
+            if isinstance(mod, torch.nn.Module):
+                load_det_weights(mod, name + ".")
+        brain = tsasr.TSASR(h["modules"], functools.partial(torch.optim.SGD, lr=3e-4), h, {"device": DEV, "compute_dtype": "bf16"})
+        brain.grad_accumulation_factor = accum
+        brain.modules.train()
+        if mode == "graph":
+            brain.enable_hip_graph(warmup_steps=2)
+        batch = make_batch(inp).to(DEV)
+        losses[mode] = [float(brain.fit_batch(batch)) for _ in range(8)]
+    assert losses["eager"][0] > losses["eager"][-1]
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("beam", [4, 15])
 def test_beam_search_fp32_vs_reference_golden(brain32, golden, beam):
     """decoders.TransducerBeamSearcher (beam > 1) on the golden encoder output against the reference's own hypotheses

@@ -192,6 +192,18 @@ class GradArena:
         self._tr_jobs = torch.tensor(jobs, dtype=torch.int32).reshape(-1).to(self.device) if jobs else None
         self.refresh_transposed()
 
+    def sync_shadow(self):
+        """After an optimizer that updates the fp32 parameters through torch (anything but the fused AdamW kernel, which writes the
+        shadow itself): rewrite the bf16 shadow and the transposed copies - two launches, graph-capturable. Without it an eager step
+        notices the stale shadow through the parameters' version counters and casts on the fly, but a captured step has that
+        decision frozen at capture time and kept multiplying with the weights of the capture step (found with SGD under hipGraph)."""
+        if self.flat_params16 is None:
+            return
+        self.flat_params16.copy_(self.flat_params)
+        for p in self.params_ordered:
+            p._bf16_ver = p._version
+        self.refresh_transposed()
+
     def refresh_transposed(self):
         """Rewrite the transposed weight copies from the bf16 shadow: one launch, issued after every optimizer step (graph-capturable)."""
         if getattr(self, "_tr_jobs", None) is None:

@@ -117,6 +117,7 @@ class _WrappedTorchOptimizer:
         if self.max_grad_norm > 0:
             self.arena.grads.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
         self.opt.step()
+        self.arena.sync_shadow()
 
     def step(self):
         self.launch()
