@@ -328,6 +328,18 @@ void tsasr_wgrad_discard(void);
 int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_mean_pool_bwd(const void *dout, const float *rel, void *dx, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_abs_lengths(const float *const *rel, int *const *out, const int *dim, const int *mode, int n, int B, void *stream);
+/* ------------------------------------------------------------------------------------------
+ * Greedy transducer search on the device (SB/decoders/transducer.py:138-218, transducer_greedy_decode): one launch decodes the batch,
+ * one persistent workgroup per utterance; predictor = embedding table -> one-layer LSTM -> Linear, joiner = LeakyReLU(enc + pn) -> Linear
+ * head; at most one symbol per frame, the predictor advances only on a non-blank. enc [B,T,J] (io_dtype); emb fp32 [n_emb, E], E <= 64;
+ * LSTM weights in torch layout (w_ih [4H,E], w_hh [4H,H], gate order i,f,g,o); w_proj [J,H]; w_head [V,J], V <= 63; matrices in `wdtype`
+ * (TSASR_F32 | TSASR_BF16), biases fp32 or NULL; H, J multiples of 4. preds int32 [B,T]: symbol emitted at frame t or -1;
+ * logp_sum fp32 [B]: sum of the emitted symbols' log-probabilities.
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_greedy_decode(const void *enc, const float *emb, const void *w_ih, const void *w_hh, const float *b_ih, const float *b_hh,
+                        const void *w_proj, const float *b_proj, const void *w_head, const float *b_head, int *preds, float *logp_sum,
+                        int B, int T, int J, int H, int E, int V, int blank, float slope, int io_dtype, int wdtype, void *stream);
+
 /* TEST AID (tests / tools only): overwrite the whole LDS of every CU with a 32-bit pattern, so that a kernel reading LDS it never wrote
  * sees the pattern instead of whatever the previous kernel left there. */
 int tsasr_debug_fill_lds(unsigned pattern, void *stream);

@@ -7,6 +7,8 @@ beam_size > 1 -> the reference's per-utterance beam search with state_beam / exp
 no LM fusion): host-side hypothesis bookkeeping exactly as specified there, device-side predictor /
 joint / head steps. Pinned to the reference's own hypotheses by tests/golden/c1_beam.npz.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -31,8 +33,54 @@ class TransducerBeamSearcher(torch.nn.Module):
         out, hidden = dec(emb(tok), hx=hidden)
         return proj(out), hidden
 
+    def _device_greedy_ok(self, tn_output):
+        """The one-launch device decoder (csrc/search.hip) covers the recipes' networks: one-hot or learned embedding (<= 64 columns),
+        one-layer unidirectional LSTM, Linear projection, joint = LeakyReLU(sum), one Linear classifier."""
+        from . import nnet, rnnt
+        if os.environ.get("TSASR_GREEDY_KERNEL", "1") == "0" or not tn_output.is_cuda or tn_output.dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if len(self.decode_network_lst) != 3 or len(self.classifier_network) != 1:
+            return False
+        emb, dec, proj = self.decode_network_lst
+        head = self.classifier_network[0]
+        ok = (isinstance(emb, nnet.Embedding) and isinstance(dec, nnet.LSTM) and isinstance(proj, nnet.Linear) and isinstance(head, nnet.Linear)
+              and isinstance(self.tjoint, rnnt.Transducer_joint) and isinstance(self.tjoint.nonlinearity, torch.nn.LeakyReLU)
+              and dec.rnn.num_layers == 1 and not dec.rnn.bidirectional and emb.embedding_dim <= 64 and head.w.out_features <= 63
+              and dec.rnn.hidden_size % 4 == 0 and proj.w.out_features % 4 == 0 and proj.w.out_features == tn_output.shape[-1])
+        return bool(ok)
+
+    @torch.no_grad()
+    def _greedy_on_device(self, tn_output):
+        from . import _capi as C
+        emb, dec, proj = self.decode_network_lst
+        head = self.classifier_network[0]
+        B, T, J = tn_output.shape
+        enc = tn_output.contiguous()
+        f = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+        rnn = dec.rnn
+        mats = [rnn.weight_ih_l0, rnn.weight_hh_l0, proj.w.weight, head.w.weight]
+        if enc.dtype == torch.bfloat16:       # the training step's bf16 shadows (or a cast) - half the bytes per predictor step
+            from .ops import _bf16_weight
+            mats, wdt = [_bf16_weight(m).contiguous() for m in mats], C.BF16
+        else:
+            mats, wdt = [f(m) for m in mats], C.F32
+        table = f(emb.Embedding.weight)
+        b_ih, b_hh = (f(rnn.bias_ih_l0), f(rnn.bias_hh_l0)) if rnn.bias else (None, None)
+        b_proj, b_head = f(proj.w.bias), f(head.w.bias)
+        preds = torch.empty(B, T, dtype=torch.int32, device=enc.device)
+        logp = torch.empty(B, dtype=torch.float32, device=enc.device)
+        C.check(C.lib().tsasr_greedy_decode(C.ptr(enc), C.ptr(table), C.ptr(mats[0]), C.ptr(mats[1]), C.ptr(b_ih), C.ptr(b_hh), C.ptr(mats[2]),
+                                            C.ptr(b_proj), C.ptr(mats[3]), C.ptr(b_head), C.ptr(preds), C.ptr(logp), B, T, J, rnn.hidden_size,
+                                            table.shape[1], mats[3].shape[0], int(self.blank_id), float(self.tjoint.nonlinearity.negative_slope),
+                                            C.io_dtype(enc), wdt, C.stream_ptr()), "tsasr_greedy_decode")
+        rows = preds.cpu()
+        hyps = [[int(v) for v in row[row >= 0]] for row in rows]
+        return hyps, logp.exp().mean(), None, None
+
     @torch.no_grad()
     def transducer_greedy_decode(self, tn_output):
+        if self._device_greedy_ok(tn_output):
+            return self._greedy_on_device(tn_output)
         B, T, _ = tn_output.shape
         dev = tn_output.device
         tok = torch.full((B, 1), self.blank_id, dtype=torch.long, device=dev)
