@@ -231,6 +231,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_group_kernel(const WgradJ
 }
 
 static std::vector<WgradJob> g_wjobs;
+static int g_next_slots = 0;
 
 extern "C" {
 
@@ -285,9 +286,15 @@ int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, voi
      dbg == 3 ? ((variant & 2) ? wgrad_group_kernel<BK_, NST_, 3, true> : wgrad_group_kernel<BK_, NST_, 3, false>) : \
                 ((variant & 2) ? wgrad_group_kernel<BK_, NST_, 0, true> : wgrad_group_kernel<BK_, NST_, 0, false>))
     kern = (variant & 1) ? WG_PICK(32, 4) : WG_PICK(64, 2);
+    int lds_bytes = 128 * 1024;
+    if (g_next_slots == 2 && dbg == 0) {    // a launch meant to run BESIDE other kernels: 64 KB of LDS (two 32-row slots) leaves room on the CU
+        kern = wgrad_group_kernel<32, 2, 0, false>;
+        lds_bytes = 64 * 1024;
+    }
+    g_next_slots = 0;
 #undef WG_PICK
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    kern<<<tiles, WG_THREADS, 128 * 1024, st>>>((const WgradJob *)table_dev, (int)g_wjobs.size(), tiles);
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    kern<<<tiles, WG_THREADS, lds_bytes, st>>>((const WgradJob *)table_dev, (int)g_wjobs.size(), tiles);
     g_wjobs.clear();
     TSASR_CHECK_LAUNCH("tsasr_wgrad_flush");
     return 0;
@@ -297,6 +304,10 @@ int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, voi
 int tsasr_wgrad_debug_read(unsigned long long *host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_stamp), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : TSASR_E_LAUNCH;
 }
+
+/* The NEXT tsasr_wgrad_flush uses `slots` LDS-DMA slots of 32 rows (2 = 64 KB of LDS per workgroup instead of 128 KB: slower alone, but
+ * other kernels' workgroups fit beside it on a CU); 0 = default. One-shot. */
+void tsasr_wgrad_next_flush_slots(int slots) { g_next_slots = slots; }
 
 /* Drop the queue without running it (error paths / tests). */
 void tsasr_wgrad_discard(void) { g_wjobs.clear(); }

@@ -176,6 +176,7 @@ def reduce_defer_end():
 _WG = {"keep": [], "ids": set(), "ring": None, "params": []}
 _WG_MAX_JOBS = 1024
 _WG_ENABLED = os.environ.get("TSASR_WGRAD_GROUP", "1") != "0"
+_WG_EARLY_SLOTS = int(os.environ.get("TSASR_WGRAD_EARLY_SLOTS", "0"))   # 2: the launch made beside another stream's kernels uses 64 KB of LDS
 
 
 def wgrad_queue(weight, grad2d, dy2, x2):
@@ -214,6 +215,8 @@ def wgrad_flush(hold=None):
     if done:
         ring = _WG["ring"]
         k, host, dev, _ = ring.acquire()
+        if hold is not None and _WG_EARLY_SLOTS:
+            C.lib().tsasr_wgrad_next_flush_slots(_WG_EARLY_SLOTS)
         with prof.region("wgrad_group", _WG.get("flops", 0.0), _WG.get("bytes", 0.0)):
             C.check(C.lib().tsasr_wgrad_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_wgrad_flush")
         ring.launched(k)
