@@ -303,9 +303,18 @@ class Brain:
             # eager until the allocator is warm AND one optimizer step has run: the arena re-lays itself out in backward order when
             # the gradients are first cleared, which must not happen inside a capture
             self._eager_steps += 1
+            # Ranks decide eager-vs-replay from their OWN shape history, so both paths must issue the same collectives: with the direct
+            # RCCL communicator both send the bucket all-reduces during backward; otherwise (gloo, TSASR_GRAPH_COMM=0) the replay is
+            # followed by ONE all-reduce of the whole arena - and so is this eager step
+            same_as_replay = self.distributed and not self._graph_comm()
             with self.no_sync(not should_step):
-                loss, _ = self._device_step(batch, should_step, comm=True)
+                loss, _ = self._device_step(batch, should_step, comm=not same_as_replay)
             if should_step:
+                if same_as_replay:
+                    self.arena.allreduce_all()
+                    self.optimizer.prepare()
+                    self.optimizer.launch()
+                    self.arena.zero_()
                 self.optimizer_step += 1
                 self._eager_stepped = True
             return loss
