@@ -322,6 +322,8 @@ void tsasr_wgrad_discard(void);
 /* The NEXT tsasr_wgrad_flush runs with `slots` LDS-DMA slots (2: 64 KB of LDS per workgroup, for a launch that should share the CUs
  * with another stream's kernels; 0: default 128 KB). One-shot. */
 void tsasr_wgrad_next_flush_slots(int slots);
+/* The NEXT tsasr_wgrad_flush launches at most `wgs` workgroups that walk the tiles persistently (0: one workgroup per tile). One-shot. */
+void tsasr_wgrad_next_flush_wgs(int wgs);
 
 /* Recipe glue on the device (csrc/misc.hip), each ONE launch instead of a chain of tiny library kernels:
  * tsasr_mean_pool_*: masked mean over time of the speaker encoder's output (train_librispeechmix_scratch.py:52-64);

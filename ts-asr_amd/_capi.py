@@ -116,6 +116,7 @@ _PROTOS = {
     "tsasr_wgrad_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_wgrad_discard": (None, []),
     "tsasr_wgrad_next_flush_slots": (None, [c_int]),
+    "tsasr_wgrad_next_flush_wgs": (None, [c_int]),
     "tsasr_specaug_params_words": (c_size_t, [c_int] * 3),
     "tsasr_specaug_draw": (c_int, [c_void_p] + [c_int] * 10 + [c_ull, c_void_p, c_void_p]),
     "tsasr_specaug_workspace_bytes": (c_size_t, []),

@@ -100,10 +100,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_group_kernel(const WgradJ
     constexpr int TILE_BYTES = BK * WG_ROW_BYTES, SLOT_BYTES = 2 * TILE_BYTES, LPT = 2 * (BK / 16);   // LPT: DMA instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+    // A launch with fewer workgroups than tiles walks the tiles persistently (vb, vb + gridDim.x, ...): the early launch that runs beside
+    // another stream's kernels occupies only that many CUs (a workgroup holds 64-128 KB of LDS: nothing else fits beside it on a CU).
+    for (int vb = blockIdx.x; vb < total_tiles; vb += gridDim.x) {
     // XCD-contiguous tile ids: consecutive tiles (same job, same row panel) share one XCD's L2
     int id;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, q = total_tiles >> 3, rem = total_tiles & 7;
+        const int bid = vb, xcd = bid & 7, q = total_tiles >> 3, rem = total_tiles & 7;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     }
     int lo = 0, n = njobs;
@@ -228,10 +231,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_group_kernel(const WgradJ
             }
         }
     }
+    if (vb + (int)gridDim.x < total_tiles) {     // another tile follows: its DMA reuses the slots and counts on an empty vmcnt
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    }   // tile loop
 }
 
 static std::vector<WgradJob> g_wjobs;
-static int g_next_slots = 0;
+static int g_next_slots = 0, g_next_wgs = 0;
 
 extern "C" {
 
@@ -292,9 +301,11 @@ int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, voi
         lds_bytes = 64 * 1024;
     }
     g_next_slots = 0;
+    const int wgs = (g_next_wgs > 0 && g_next_wgs < tiles && dbg == 0) ? g_next_wgs : tiles;
+    g_next_wgs = 0;
 #undef WG_PICK
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    kern<<<tiles, WG_THREADS, lds_bytes, st>>>((const WgradJob *)table_dev, (int)g_wjobs.size(), tiles);
+    kern<<<wgs, WG_THREADS, lds_bytes, st>>>((const WgradJob *)table_dev, (int)g_wjobs.size(), tiles);
     g_wjobs.clear();
     TSASR_CHECK_LAUNCH("tsasr_wgrad_flush");
     return 0;
@@ -308,6 +319,10 @@ int tsasr_wgrad_debug_read(unsigned long long *host_out) {
 /* The NEXT tsasr_wgrad_flush uses `slots` LDS-DMA slots of 32 rows (2 = 64 KB of LDS per workgroup instead of 128 KB: slower alone, but
  * other kernels' workgroups fit beside it on a CU); 0 = default. One-shot. */
 void tsasr_wgrad_next_flush_slots(int slots) { g_next_slots = slots; }
+
+/* The NEXT tsasr_wgrad_flush launches at most `wgs` workgroups, which walk the tiles persistently (0 = one workgroup per tile):
+ * a launch that should leave the other CUs to another stream's kernels. One-shot. */
+void tsasr_wgrad_next_flush_wgs(int wgs) { g_next_wgs = wgs; }
 
 /* Drop the queue without running it (error paths / tests). */
 void tsasr_wgrad_discard(void) { g_wjobs.clear(); }

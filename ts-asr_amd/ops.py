@@ -176,6 +176,11 @@ def reduce_defer_end():
 _WG = {"keep": [], "ids": set(), "ring": None, "params": []}
 _WG_MAX_JOBS = 1024
 _WG_ENABLED = os.environ.get("TSASR_WGRAD_GROUP", "1") != "0"
+# The weight-gradient launch made beside another stream's kernels (the recipe's early flush) walks its tiles persistently on at most this
+# many CUs: -1 = half the device. A 256x256-tile workgroup holds 128 KB of LDS, so nothing shares a CU with it; with one per tile the
+# speaker branch's small kernels waited for whole CUs to drain (13.39-13.46 ms per step; 96 CUs 13.16, 112: 13.12, 128: 13.09, 144: 13.28,
+# 192: 13.20). 0 = one workgroup per tile.
+_WG_EARLY_WGS = int(os.environ.get("TSASR_WGRAD_EARLY_WGS", "-1"))
 _WG_EARLY_SLOTS = int(os.environ.get("TSASR_WGRAD_EARLY_SLOTS", "0"))   # 2: the launch made beside another stream's kernels uses 64 KB of LDS
 
 
@@ -217,6 +222,8 @@ def wgrad_flush(hold=None):
         k, host, dev, _ = ring.acquire()
         if hold is not None and _WG_EARLY_SLOTS:
             C.lib().tsasr_wgrad_next_flush_slots(_WG_EARLY_SLOTS)
+        if hold is not None and _WG_EARLY_WGS:
+            C.lib().tsasr_wgrad_next_flush_wgs(_WG_EARLY_WGS if _WG_EARLY_WGS > 0 else max(1, torch.cuda.get_device_properties(dev.device).multi_processor_count // 2))
         with prof.region("wgrad_group", _WG.get("flops", 0.0), _WG.get("bytes", 0.0)):
             C.check(C.lib().tsasr_wgrad_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_wgrad_flush")
         ring.launched(k)
