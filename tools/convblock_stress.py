@@ -18,7 +18,6 @@ def params(cin, fo, co=128):
 def run(x, P, p):
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     xg = x.clone().requires_grad_(x.shape[-1] > 1)
-    out = ops.frontend_block.__wrapped__(xg, Pg) if False else None
     conv_params, ln_params = (Pg["w1"], Pg["b1"], Pg["w2"], Pg["b2"]), (Pg["g1"], Pg["be1"], Pg["g2"], Pg["be2"])
     if x.shape[-1] == 1:
         out = ops._FrontendBlockFn.apply(xg.squeeze(-1), None, None, conv_params, ln_params, 0, 0, False, 0.01, 1e-5, p, 11, p, 12, *conv_params, *ln_params)
