@@ -203,6 +203,13 @@ size_t tsasr_relpos_attn_lds_bytes(void);
 int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream);
+/* Same with a caller-owned workspace: long sequences in small batches (B * H * T/128 < 512 workgroups, T > 1024) are split along the keys
+ * across workgroups and merged by a second launch. workspace may be NULL (no split). */
+size_t tsasr_relpos_attn_fwd_workspace_bytes(int B, int T, int H);
+int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                             void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                             unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace,
+                             size_t workspace_bytes, void *stream);
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H);
 /* Backward: dqkv [B,T,H,3*Dh] fully written; d_bias_u/d_bias_v fp32 [H*Dh] ([H,Dh] reading of the parameter storage); dpk [2T-1, H*Dh]
  * (io_dtype, fully written) = gradient of pk = linear_pos(pos_embs). The workspace holds P_d and scale*dS as [B,H,T,ceil64(T)] tensors

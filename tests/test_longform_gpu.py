@@ -177,3 +177,36 @@ def test_longform_model_loss_vs_oracle(chunk):
     print(f"long-form loss chunk={chunk}: hip {float(loss):.4f} oracle {ref:.4f}")
     assert float(loss) == pytest.approx(ref, rel=3e-2)
     assert brain.optimizer_step == 1 and brain.flush_nonfinite() == 0
+
+
+# ---------------------------------------------------------------------------------------------- key-split forward == unsplit forward
+@pytest.mark.parametrize("B,Tn,H,Dh,causal,pdrop", [(1, 4000, 4, 64, 1, 0.0), (2, 1500, 4, 64, 0, 0.1), (1, 2077, 2, 36, 40, 0.1),
+                                                    (3, 1100, 2, 64, 1, 0.0)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_forward_key_split_equals_unsplit(B, Tn, H, Dh, causal, pdrop, dtype):
+    """tsasr_relpos_attn_fwd_ws with a workspace splits the keys of long sequences over workgroups and merges the partial softmaxes;
+    with workspace = NULL the same entry runs one workgroup per query block. Same inputs, same dropout seed (the mask is a function of
+    (seed, b, h, i, j)): outputs agree to fp32 re-association, log-sum-exp rows too; ragged key lengths, padded head dim, block-causal."""
+    C = importlib.import_module("ts-asr_amd._capi")
+    D = H * Dh
+    g = torch.Generator().manual_seed(Tn + Dh)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(dtype).to(DEV)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(dtype).to(DEV)
+    u, v = (torch.randn(H * Dh, generator=g) * 0.3).to(DEV), (torch.randn(H * Dh, generator=g) * 0.3).to(DEV)
+    lens = torch.tensor([Tn, max(1, Tn // 3), max(1, Tn - 7)][:B], dtype=torch.int32, device=DEV)
+    nbytes = C.lib().tsasr_relpos_attn_fwd_workspace_bytes(B, Tn, H)
+    assert nbytes > 0, "these shapes are meant to take the split path"
+    res = []
+    for ws in (None, torch.empty(nbytes, dtype=torch.uint8, device=DEV)):
+        out = torch.full((B, Tn, D), float("nan"), dtype=dtype, device=DEV)
+        lse = torch.full((B, H, Tn), float("nan"), dtype=torch.float32, device=DEV)
+        C.check(C.lib().tsasr_relpos_attn_fwd_ws(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, Tn, H, Dh,
+                                                 1.0 / D ** 0.5, causal, pdrop, 1234, None, C.io_dtype(qkv), C.ptr(ws),
+                                                 nbytes if ws is not None else 0, C.stream_ptr()), "attn")
+        torch.cuda.synchronize()
+        res.append((out.float().cpu(), lse.cpu()))
+    (o0, l0), (o1, l1) = res
+    assert torch.isfinite(o1).all() and torch.isfinite(l1).all()
+    # probabilities enter the P.V MFMA as bf16(exp(s - running max)): the running max differs between the two walks, so the roundings do
+    assert float((o1 - o0).norm() / o0.norm()) < 3e-3
+    assert float((l1 - l0).abs().max()) < 1e-4

@@ -67,6 +67,8 @@ _PROTOS = {
     "tsasr_frontend_block_bwd": (c_int, [c_void_p] * 15 + [c_int] * 5 + [c_float, c_float, c_ull, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_relpos_attn_lds_bytes": (c_size_t, []),
     "tsasr_relpos_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p]),
+    "tsasr_relpos_attn_fwd_workspace_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_relpos_attn_fwd_ws": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_relpos_attn_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
     "tsasr_relpos_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_accumulate_many": (c_int, [c_void_p, c_int, c_void_p]),

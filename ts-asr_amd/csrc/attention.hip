@@ -178,14 +178,19 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
                                                               const int32_t *__restrict__ key_lens, T *__restrict__ out,
                                                               float *__restrict__ lse, int Tn, int H, int Dh, float scale,
                                                               int causal, float pdrop, unsigned long long seed,
-                                                              const unsigned long long *__restrict__ seed_dev) {
+                                                              const unsigned long long *__restrict__ seed_dev,
+                                                              int nparts, int part_keys, float *__restrict__ part_o, float *__restrict__ part_ml) {
+    // nparts > 1 (long sequences, few utterances): blockIdx.x = query block * nparts + part; a part covers part_keys keys and leaves its
+    // un-normalised (O, m, l) in part_o / part_ml for relpos_attn_merge_kernel - the query blocks of a causal T' = 4000 utterance need
+    // 2 .. 63 key tiles each and there are only 128 of them per utterance: the longest set the time and half the CUs stood idle
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (seed_dev) seed += *seed_dev;
     bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);             // [AT_KT][AT_LD]
     bf16_t *v_lds = k_lds + AT_KT * AT_LD;                        // [AT_KT][AT_LD]
     bf16_t *p_lds = v_lds + AT_KT * AT_LD;                        // [AT_BAND][AT_LD]
     float *g_all = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);  // [4 waves][64][32]
-    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QB;
+    const int part = nparts > 1 ? (int)(blockIdx.x % nparts) : 0;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = (nparts > 1 ? (int)(blockIdx.x / nparts) : (int)blockIdx.x) * AT_QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     float *g_lds = g_all + wave * 64 * 32;
     const int D = H * Dh;
@@ -225,6 +230,11 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
 
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);  // keys beyond the last query's limit are never attended
+    const int j_begin = part * part_keys;
+    if (nparts > 1) {
+        j_end = min(j_end, j_begin + part_keys);
+        if (j_begin >= j_end) return;                                          // this part has no keys for this query block (workgroup-uniform)
+    }
     const bool pipe = (Dh % 8) == 0;   // 16-byte aligned row pieces: tiles are requested one iteration ahead (StagePieces)
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
@@ -235,12 +245,12 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
 #define ATF_STAMP(i)
 #endif
     if (pipe && j_end > 0) {
-        sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
-        sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
-        sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
+        sk.request(q_base + Dh, row_stride, j_begin, 0, Tn, Dh);
+        sv.request(q_base + 2 * Dh, row_stride, j_begin, 0, Tn, Dh);
+        sp.request(pk + (long long)h * Dh, D, j_begin - i0 - (AT_QB - 1) + Tn - 1, 0, 2 * Tn - 1, Dh);
     }
     ATF_STAMP(0);   // prologue
-    for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
+    for (int j0 = j_begin; j0 < j_end; j0 += AT_KT) {
         __syncthreads();  // previous tile fully consumed
         if (pipe) {
             sk.commit(k_lds, Dh);
@@ -346,6 +356,20 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
         }
     }
     ATF_STAMP(4);       // (P.V of the last sub-block; earlier ones are folded into phase 2 of the next)
+    if (nparts > 1) {   // un-normalised partial result of this key range: merged by relpos_attn_merge_kernel
+        if (iq < Tn) {
+            const size_t row = (((size_t)b * H + h) * Tn + iq) * nparts + part;
+            float *po = part_o + row * AT_DP;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(po + 32 * db + 8 * q + 4 * hh) =
+                        make_float4(o_acc[db][4 * q], o_acc[db][4 * q + 1], o_acc[db][4 * q + 2], o_acc[db][4 * q + 3]);
+            if (hh == 0) *reinterpret_cast<float2 *>(part_ml + row * 2) = make_float2(m_run, l_run);
+        }
+        return;
+    }
     // ---- epilogue: out[b, iq, h*Dh + d] = O / l ; lse = m + log l
     if (iq < Tn) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -373,6 +397,43 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
 }
 
 
+
+// out[b, i, h, :] = sum_p e^(m_p - M) O_p / sum_p e^(m_p - M) l_p over the key parts that exist for query i (part p starts at key
+// p * part_keys; a query reaches keys < min(len, causal limit + 1)), lse = M + log(sum). 16 threads per (b, h, i): four head dims each.
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                                const int32_t *__restrict__ key_lens, T *__restrict__ out,
+                                                                float *__restrict__ lse, int B, int Tn, int H, int Dh, int causal,
+                                                                int nparts, int part_keys) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid >> 4;
+    const int d = (int)(gid & 15) * 4;
+    if (row >= (long long)B * H * Tn) return;
+    const int i = (int)(row % Tn), h = (int)((row / Tn) % H), b = (int)(row / ((long long)Tn * H));
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    // parts are launched per query BLOCK: a part exists for this row iff it has keys for the block's last query
+    const int i_last = min((i / AT_QB) * AT_QB + AT_QB - 1, Tn - 1 + AT_QB);
+    int j_end = len;
+    if (causal) j_end = min(j_end, causal_limit(i_last, causal) + 1);
+    const int np = min(nparts, (j_end + part_keys - 1) / part_keys);
+    const float *ml = part_ml + row * nparts * 2;
+    float M = -INFINITY;
+    for (int p = 0; p < np; ++p) M = fmaxf(M, ml[2 * p]);
+    float L = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < np; ++p) {
+        const float m = ml[2 * p], w = (m == -INFINITY) ? 0.f : __expf(m - M);
+        L += w * ml[2 * p + 1];
+        const float4 v = *reinterpret_cast<const float4 *>(part_o + (row * nparts + p) * AT_DP + d);
+        o[0] += w * v.x; o[1] += w * v.y; o[2] += w * v.z; o[3] += w * v.w;
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    T *orow = out + ((long long)b * Tn + i) * (H * Dh) + (long long)h * Dh;
+    if (d + 4 <= Dh && (Dh % 4) == 0) st4(orow + d, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    else
+        for (int e = 0; e < 4; ++e)
+            if (d + e < Dh) st1(orow + d + e, o[e] * inv);
+    if (d == 0 && lse) lse[row] = M + __logf(L);
+}
 
 // =====================================================================================================================
 // Forward for short sequences (T <= 256: the mixture encoder's T' = 250 and the speaker encoder's 125 at BASELINE configs[1]),
@@ -1115,11 +1176,37 @@ size_t tsasr_relpos_attn_lds_bytes(void) {
     return (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)AT_NW * 64 * 32 * sizeof(float);
 }
 
+// key split of the streaming forward: parts of 16 key tiles when one workgroup per query block would leave the chip under-filled
+static int attn_fwd_parts(int B, int T, int H, int *part_keys) {
+    static const int forced = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;   // 0: never; n: n key tiles per part
+    const int tiles = cdiv(T, AT_KT);
+    int per = forced > 0 ? forced : 16;
+    if (forced == 0 || tiles <= per || (long long)B * H * cdiv(T, AT_QB) >= 512) return 1;
+    *part_keys = per * AT_KT;
+    return cdiv(tiles, per);
+}
+
+size_t tsasr_relpos_attn_fwd_workspace_bytes(int B, int T, int H) {
+    int pk = 0;
+    const int np = attn_fwd_parts(B, T, H, &pk);
+    return np > 1 ? align_up((size_t)B * H * T * np * (AT_DP + 2) * sizeof(float), 256) : 0;
+}
+
 /* out [B,T,H*Dh] = fused rel-pos attention; lse [B,H,T] fp32 (may be NULL) is kept for the backward.
  * Dh <= 64; dropout mask is a pure function of (seed, b, h, i, j). */
 int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
                           void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream) {
+    return tsasr_relpos_attn_fwd_ws(qkv, pk, bias_u, bias_v, key_lens, out, lse, B, T, H, Dh, scale, causal, pdrop, seed, seed_dev, io_dtype,
+                                    nullptr, 0, stream);
+}
+
+/* Same with a workspace of tsasr_relpos_attn_fwd_workspace_bytes(B, T, H) bytes: long sequences in small batches are then split along
+ * the keys across workgroups (partial results merged by a second launch); without a workspace (NULL) nothing is split. */
+int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens,
+                             void *out, float *lse, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
+                             unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace,
+                             size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(qkv && pk && bias_u && bias_v && out, "tsasr_relpos_attn_fwd: null pointer");
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_fwd: head dim %d not supported (1..%d)", Dh, AT_DP);
     TSASR_CHECK_ARG(pdrop >= 0.f && pdrop < 1.f, "tsasr_relpos_attn_fwd: bad dropout %f", pdrop);
@@ -1142,12 +1229,20 @@ int tsasr_relpos_attn_fwd(const void *qkv, const void *pk, const float *bias_u, 
         TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
         return 0;
     }
+    int part_keys = 0;
+    int nparts = workspace ? attn_fwd_parts(B, T, H, &part_keys) : 1;
+    if (nparts > 1 && workspace_bytes < tsasr_relpos_attn_fwd_workspace_bytes(B, T, H)) nparts = 1;
+    float *part_o = (float *)workspace, *part_ml = nparts > 1 ? part_o + (size_t)B * H * T * nparts * AT_DP : nullptr;
+    if (nparts > 1) grid.x *= nparts;
+    const unsigned mgrid = (unsigned)(((long long)B * H * T * 16 + 255) / 256);
     if (io_dtype == TSASR_F32) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<float><<<grid, AT_TH, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_fwd_kernel<float><<<grid, AT_TH, lds, st>>>((const float *)qkv, (const float *)pk, bias_u, bias_v, key_lens, (float *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev, nparts, part_keys, part_o, part_ml);
+        if (nparts > 1) relpos_attn_merge_kernel<float><<<mgrid, 256, 0, st>>>(part_o, part_ml, key_lens, (float *)out, lse, B, T, H, Dh, causal, nparts, part_keys);
     } else if (io_dtype == TSASR_BF16) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        relpos_attn_fwd_kernel<bf16_t><<<grid, AT_TH, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev);
+        relpos_attn_fwd_kernel<bf16_t><<<grid, AT_TH, lds, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, (bf16_t *)out, lse, T, H, Dh, scale, causal, pdrop, seed, seed_dev, nparts, part_keys, part_o, part_ml);
+        if (nparts > 1) relpos_attn_merge_kernel<bf16_t><<<mgrid, 256, 0, st>>>(part_o, part_ml, key_lens, (bf16_t *)out, lse, B, T, H, Dh, causal, nparts, part_keys);
     } else {
         TSASR_CHECK_ARG(false, "tsasr_relpos_attn_fwd: bad io_dtype %d", io_dtype);
     }

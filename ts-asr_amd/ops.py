@@ -1188,11 +1188,13 @@ class _RelPosAttnFn(torch.autograd.Function):
         v = _f32(pos_bias_v).reshape(-1).contiguous()
         out = torch.empty(B, T, D, dtype=qkvc.dtype, device=qkvc.device)
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkvc.device)
+        ws_bytes = C.lib().tsasr_relpos_attn_fwd_workspace_bytes(B, T, H)   # > 0: long sequence, small batch - keys split across workgroups
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkvc.device) if ws_bytes else None   # consumed in stream order by the merge launch
         with prof.region("relpos_attn_fwd"):
-            C.check(C.lib().tsasr_relpos_attn_fwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(lse),
-                                                  B, T, H, Dh, float(scale), int(causal), float(pdrop), seed,
-                                                  C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc),
-                                                  C.stream_ptr()), "tsasr_relpos_attn_fwd")
+            C.check(C.lib().tsasr_relpos_attn_fwd_ws(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(lse),
+                                                     B, T, H, Dh, float(scale), int(causal), float(pdrop), seed,
+                                                     C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc),
+                                                     C.ptr(ws), ws_bytes, C.stream_ptr()), "tsasr_relpos_attn_fwd")
         ctx.save_for_backward(qkvc, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
         ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed)
         return out
