@@ -329,12 +329,14 @@ def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
     close(out, ref, 4e-2, 4e-2)
 
 
-@pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 70, 4, 36), (1, 200, 2, 64)])
+@pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 70, 4, 36), (1, 200, 2, 64), (1, 1100, 2, 36), (2, 1500, 1, 64)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
     """HIP backward (dQ/dK/dV, d pos_bias_u/v, d pk) vs autograd through the ORACLE's attention (oracle/tsasr_ref.py relpos_core, the
-    function the reference-generated golden vectors pin through relpos_mha) - not through product code."""
+    function the reference-generated golden vectors pin through relpos_mha) - not through product code. The two T > 1000 shapes take
+    the long-sequence paths: keys split over workgroups in the forward and in the query-major backward (fp32 dQ shares + merge), query
+    ranges split in the d(pk) pass."""
     D = H * Dh
     g = torch.Generator().manual_seed(Tn * 3 + Dh)
     qkv = torch.randn(B, Tn, 3 * D, generator=g).to(dtype)

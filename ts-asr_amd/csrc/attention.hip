@@ -694,14 +694,18 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
                                                                 T *__restrict__ dqkv, T *__restrict__ pd_out, T *__restrict__ ds_out,
                                                                 float *__restrict__ slab_uv, int Tp,
                                                                 int Bn, int Tn, int H, int Dh, float scale, int causal, float pdrop,
-                                                                unsigned long long seed, const unsigned long long *__restrict__ seed_dev) {
+                                                                unsigned long long seed, const unsigned long long *__restrict__ seed_dev,
+                                                                int nparts, int part_keys, float *__restrict__ dq_part) {
+    // nparts > 1: blockIdx.x = query block * nparts + key part (see relpos_attn_fwd_kernel); a part leaves its share of dQ in fp32 in
+    // dq_part (summed by relpos_attn_dq_merge_kernel) and its own row of pos_bias partial sums; P_d / dS columns are disjoint anyway
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (seed_dev) seed += *seed_dev;
     bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);
     bf16_t *v_lds = k_lds + AT_KT * AT_LD;
     bf16_t *p_lds = v_lds + AT_KT * AT_LD;
     float *g_all = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);
-    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QB;
+    const int part = nparts > 1 ? (int)(blockIdx.x % nparts) : 0;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = (nparts > 1 ? (int)(blockIdx.x / nparts) : (int)blockIdx.x) * AT_QB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     float *g_lds = g_all + wave * 64 * 32;
     const int D = H * Dh, R = 2 * Tn - 1;
@@ -749,6 +753,8 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);
+    const int j_begin = part * part_keys;
+    if (nparts > 1) j_end = min(j_end, j_begin + part_keys);   // an empty part (j_begin >= j_end) skips the loop and writes zero sums below
     const bool pipe = (Dh % 8) == 0;
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
@@ -758,13 +764,13 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 #else
 #define AT_STAMP(i)
 #endif
-    if (pipe && j_end > 0) {
-        sk.request(q_base + Dh, row_stride, 0, 0, Tn, Dh);
-        sv.request(q_base + 2 * Dh, row_stride, 0, 0, Tn, Dh);
-        sp.request(pk + (long long)h * Dh, D, -i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
+    if (pipe && j_end > j_begin) {
+        sk.request(q_base + Dh, row_stride, j_begin, 0, Tn, Dh);
+        sv.request(q_base + 2 * Dh, row_stride, j_begin, 0, Tn, Dh);
+        sp.request(pk + (long long)h * Dh, D, j_begin - i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
     }
     AT_STAMP(0);   // prologue (q, do, o loads; first tile requests)
-    for (int j0 = 0; j0 < j_end; j0 += AT_KT) {
+    for (int j0 = j_begin; j0 < j_end; j0 += AT_KT) {
         __syncthreads();
         const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
         if (pipe) {
@@ -899,7 +905,11 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
-            if ((g & 3) == 0 && q_ok) {   // four consecutive head dims per store
+            if ((g & 3) == 0 && q_ok && nparts > 1) {
+                if (j_end > j_begin)
+                    *reinterpret_cast<float4 *>(dq_part + ((((size_t)b * H + h) * Tn + iq) * nparts + part) * AT_DP + d) =
+                        make_float4(dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
+            } else if ((g & 3) == 0 && q_ok) {   // four consecutive head dims per store
                 if (d + 4 <= Dh && (Dh % 4) == 0)
                     st4(dq + d, dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
                 else
@@ -914,6 +924,32 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64)
         for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(slab_uv)[i] = acc_t[i];
 #endif
+}
+
+// dQ[b, i, h, :] = sum over the key parts that exist for query i's block (fixed order) of the fp32 shares bwd_q left; 16 threads per row
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_dq_merge_kernel(const float *__restrict__ dq_part, const int32_t *__restrict__ key_lens,
+                                                                   T *__restrict__ dqkv, int B, int Tn, int H, int Dh, int causal, int nparts,
+                                                                   int part_keys) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid >> 4;
+    const int d = (int)(gid & 15) * 4;
+    if (row >= (long long)B * H * Tn) return;
+    const int i = (int)(row % Tn), h = (int)((row / Tn) % H), b = (int)(row / ((long long)Tn * H));
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    int j_end = len;
+    if (causal) j_end = min(j_end, causal_limit((i / AT_QB) * AT_QB + AT_QB - 1, causal) + 1);
+    const int np = min(nparts, (j_end + part_keys - 1) / part_keys);
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < np; ++p) {
+        const float4 v = *reinterpret_cast<const float4 *>(dq_part + (row * nparts + p) * AT_DP + d);
+        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+    }
+    T *dq = dqkv + ((long long)b * Tn + i) * (3LL * H * Dh) + (long long)h * 3 * Dh;
+    if (d + 4 <= Dh && (Dh % 4) == 0) st4(dq + d, o[0], o[1], o[2], o[3]);
+    else
+        for (int e = 0; e < 4; ++e)
+            if (d + e < Dh) st1(dq + d + e, o[e]);
 }
 
 // Key-major pass on the MATERIALISED probabilities: bwd_q leaves P_d (dropout applied) and scale*dS as [B,H,T,Tp] tensors (16 MB each
@@ -1041,10 +1077,13 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ ds, const T *__restrict__ qv /*[H][B*T][Dh]*/,
                                                          const int32_t *__restrict__ key_lens, float *__restrict__ part /*[G][R][H*64]*/,
-                                                         int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup) {
+                                                         int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup, int isplit,
+                                                         int i_span) {
+    // isplit > 1 (long sequences, few utterances): blockIdx.z = utterance group * isplit + query range; a workgroup walks the query
+    // blocks of [ipart * i_span, (ipart + 1) * i_span) only - the band rows around r = T-1 are reached by every query block
     __shared__ __attribute__((aligned(16))) T raw[64 * SH_LD];
     __shared__ __attribute__((aligned(16))) bf16_t a_tile[64 * DPK_LD], b_tile[64 * DPK_LD];
-    const int r0 = blockIdx.x * 64, h = blockIdx.y, grp = blockIdx.z;
+    const int r0 = blockIdx.x * 64, h = blockIdx.y, grp = blockIdx.z / isplit, ipart = blockIdx.z % isplit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int rblk = wave & 1, dblk = wave >> 1;
     const int R = 2 * Tn - 1;
@@ -1052,13 +1091,16 @@ __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ d
     constexpr int VE = 16 / (int)sizeof(T), NG = SH_LD / VE;
     f32x16 acc = {0};
     const int b_end = min(Bn, (grp + 1) * bgroup);
+    const int i_lo = ipart * i_span, i_hi = min(Tn, i_lo + i_span);
+    // band rows whose every (query, key) pair lies beyond the causal limit (j - i = r - (T-1) > chunk - 1) only ever see zeros
+    const bool dead = causal && r0 - (Tn - 1) > max(causal, 1) - 1;
     // (a version that requested the next pair's global loads before building this pair's tiles - LDS-only barriers in between -
     // measured 5 % slower than this plain loop: two to four workgroups share a CU and cover each other's round trips)
-    for (int b = grp * bgroup; b < b_end; ++b) {
+    for (int b = grp * bgroup; b < b_end && !dead; ++b) {
         const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
         const T *src = ds + (((long long)b * H + h) * Tn) * Tp;
         const T *qrow = qv + ((long long)h * Bn + b) * Tn * Dh;
-        for (int i0 = 0; i0 < Tn; i0 += 64) {
+        for (int i0 = i_lo; i0 < i_hi; i0 += 64) {
             const int jlo = r0 + i0 - (Tn - 1);                  // key of (rl = 0, il = 0); keys jlo .. jlo + 126 are touched
             if (jlo + 126 < 0 || jlo >= len) continue;           // no query of this block reaches these band rows (workgroup-uniform)
             const int jal = (jlo >= 0 ? jlo : jlo - 7) / 8 * 8, off = jlo - jal;
@@ -1106,7 +1148,7 @@ __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ d
         }
     }
     // accumulator: rows = band rows 32*rblk + (g&3) + 8(g>>2) + 4hh, column = head dim 32*dblk + r
-    float *pw = part + ((long long)grp * R) * (H * 64) + h * 64 + 32 * dblk + r;
+    float *pw = part + ((long long)blockIdx.z * R) * (H * 64) + h * 64 + 32 * dblk + r;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int rg = r0 + 32 * rblk + (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -1130,15 +1172,57 @@ __global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict
 
 extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 
-static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * H * AT_NW * 128 * sizeof(float), 256); }
+// ---- key parts for long sequences in small batches (forward and query-major backward) -------------------------------------------
+// One workgroup per (utterance, head, 128 queries) leaves the chip under-filled when B * H * T/128 < CUs, and under a causal mask the
+// blocks need 2 .. T/64 key tiles each: the keys are then cut into parts of `per` tiles, `per` the smallest value (>= 8) for which the
+// non-empty workgroups still fit one per CU (two per CU share its LDS / VALU throughput: T' = 4000, B = 1 measured 131 us per layer
+// with 24-tile parts = 240 workgroups, 136 - 193 us with 4 .. 16-tile parts, 297 us unsplit).
+constexpr int AT_MIN_PART = 8;
+static int host_causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
+static int attn_max_parts(int T) { return std::max(1, cdiv(cdiv(T, AT_KT), AT_MIN_PART)); }
+static int attn_key_parts(int B, int T, int H, int causal, int *part_keys) {
+    static const int forced = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;   // 0: never; n: n key tiles per part
+    static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const int tiles = cdiv(T, AT_KT), nqb = cdiv(T, AT_QB);
+    *part_keys = 0;
+    if (forced == 0 || tiles <= AT_MIN_PART || (long long)B * H * nqb >= cus) return 1;
+    int per = std::max(forced, AT_MIN_PART);
+    if (forced <= 0)
+        for (; per < tiles; ++per) {
+            long long n = 0;
+            for (int qb = 0; qb < nqb; ++qb) {
+                const int je = causal ? std::min(T, host_causal_limit(qb * AT_QB + AT_QB - 1, causal) + 1) : T;
+                n += cdiv(cdiv(je, AT_KT), per);
+            }
+            if (n * B * H <= cus) break;
+        }
+    if (per >= tiles) return 1;
+    *part_keys = per * AT_KT;
+    return cdiv(tiles, per);
+}
+
+static size_t attn_slab_bytes(int B, int T, int H) { return align_up((size_t)B * cdiv(T, AT_QB) * attn_max_parts(T) * H * AT_NW * 128 * sizeof(float), 256); }
+static size_t attn_dq_part_bytes(int B, int T, int H) { return attn_max_parts(T) > 1 ? align_up((size_t)B * H * T * attn_max_parts(T) * AT_DP * sizeof(float), 256) : 0; }
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
+// d(pk): query ranges per workgroup when (band-row blocks x heads x utterance groups) alone would be few, long walks
+static int attn_dpk_isplit(int B, int T, int H, int causal, int G) {
+    static const int forced = getenv("TSASR_DPK_ISPLIT") ? atoi(getenv("TSASR_DPK_ISPLIT")) : 0;
+    const int nib = cdiv(T, 64);
+    if (forced > 0) return std::min(forced, nib);
+    const long long live = (long long)cdiv(causal ? T + std::max(causal, 1) : 2 * T - 1, 64) * H * G;   // causal: band rows beyond T-1+chunk are dead
+    if (live >= 1024 || nib < 16) return 1;
+    return (int)std::min<long long>(cdiv(1024, (int)live), nib / 8);
+}
+static int attn_dpk_max_isplit(int T) { return std::max(1, std::min(cdiv(T, 64) / 8, 16)); }
 static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
     static const int dpk_wgs = getenv("TSASR_DPK_WGS") ? atoi(getenv("TSASR_DPK_WGS")) : 1024;
     const int want = std::max(1, dpk_wgs / (4 * cdiv(2 * T - 1, 64)));
     return std::max(1, cdiv(B, std::min(B, want)));
 }
 static size_t attn_qv_bytes(int B, int T, int H) { return align_up((size_t)B * T * H * AT_DP * sizeof(float), 256); }
-static size_t attn_part_bytes(int B, int T, int H) { return align_up((size_t)cdiv(B, attn_bgroup(B, T)) * (2 * T - 1) * H * 64 * sizeof(float), 256); }
+static size_t attn_part_bytes(int B, int T, int H) {
+    return align_up((size_t)cdiv(B, attn_bgroup(B, T)) * attn_dpk_max_isplit(T) * (2 * T - 1) * H * 64 * sizeof(float), 256);
+}
 
 __global__ void attn_zero_kernel(uint4 *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1154,20 +1238,29 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     T *pd = (T *)(workspace + attn_slab_bytes(B, Tn, H)), *ds = (T *)(workspace + attn_slab_bytes(B, Tn, H) + mat);
     T *qv = (T *)(workspace + attn_slab_bytes(B, Tn, H) + 2 * mat);
     float *part = (float *)(workspace + attn_slab_bytes(B, Tn, H) + 2 * mat + attn_qv_bytes(B, Tn, H));
+    float *dq_part = (float *)(workspace + attn_slab_bytes(B, Tn, H) + 2 * mat + attn_qv_bytes(B, Tn, H) + attn_part_bytes(B, Tn, H));
     const int bg = attn_bgroup(B, Tn), G = cdiv(B, bg), R = 2 * Tn - 1;
+    int part_keys = 0;
+    const int nparts = attn_key_parts(B, Tn, H, causal, &part_keys);
+    const int isplit = std::min(attn_dpk_isplit(B, Tn, H, causal, G), attn_dpk_max_isplit(Tn)), i_span = cdiv(cdiv(Tn, 64), isplit) * 64;
     if (causal) {   // key blocks in the future of a whole query wave are skipped by bwd_q: their entries must read as zero
-        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)pd, mat / 16);
-        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, mat / 16);
+        const size_t used = align_up((size_t)B * H * Tn * Tp * sizeof(T), 16) / 16;   // `mat` is sized for fp32 io
+        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)pd, used);
+        attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, used);
     }
     const size_t lds_q = tsasr_relpos_attn_lds_bytes();
     (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB), H, B), AT_TH, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out,
-                                                                              (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
-                                                                              causal, pdrop, seed, seed_dev);
+    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), AT_TH, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens,
+                                                                                       (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B,
+                                                                                       Tn, H, Dh, scale, causal, pdrop, seed, seed_dev, nparts, part_keys,
+                                                                                       dq_part);
+    if (nparts > 1)
+        relpos_attn_dq_merge_kernel<T><<<(unsigned)(((long long)B * H * Tn * 16 + 255) / 256), 256, 0, st>>>(dq_part, key_lens, (T *)dqkv, B, Tn, H, Dh, causal,
+                                                                                                          nparts, part_keys);
     relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
                                                                           qv, Tn, Tp, H, Dh, causal);
-    relpos_dpk_kernel<T><<<dim3(cdiv(R, 64), H, G), 256, 0, st>>>(ds, qv, key_lens, part, B, Tn, Tp, H, Dh, causal, bg);
-    dpk_reduce_kernel<T><<<std::min(1024, cdiv(R * H * 64, 256)), 256, 0, st>>>(part, (T *)dpk, R, H, Dh, G);
+    relpos_dpk_kernel<T><<<dim3(cdiv(R, 64), H, G * isplit), 256, 0, st>>>(ds, qv, key_lens, part, B, Tn, Tp, H, Dh, causal, bg, isplit, i_span);
+    dpk_reduce_kernel<T><<<std::min(1024, cdiv(R * H * 64, 256)), 256, 0, st>>>(part, (T *)dpk, R, H, Dh, G * isplit);
 }
 
 extern "C" {
@@ -1176,19 +1269,9 @@ size_t tsasr_relpos_attn_lds_bytes(void) {
     return (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)AT_NW * 64 * 32 * sizeof(float);
 }
 
-// key split of the streaming forward: parts of 16 key tiles when one workgroup per query block would leave the chip under-filled
-static int attn_fwd_parts(int B, int T, int H, int *part_keys) {
-    static const int forced = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;   // 0: never; n: n key tiles per part
-    const int tiles = cdiv(T, AT_KT);
-    int per = forced > 0 ? forced : 16;
-    if (forced == 0 || tiles <= per || (long long)B * H * cdiv(T, AT_QB) >= 512) return 1;
-    *part_keys = per * AT_KT;
-    return cdiv(tiles, per);
-}
-
-size_t tsasr_relpos_attn_fwd_workspace_bytes(int B, int T, int H) {
+size_t tsasr_relpos_attn_fwd_workspace_bytes(int B, int T, int H) {   // sized for the finest split any mask may choose
     int pk = 0;
-    const int np = attn_fwd_parts(B, T, H, &pk);
+    const int np = std::max(attn_key_parts(B, T, H, 0, &pk), attn_key_parts(B, T, H, 1, &pk)) > 1 ? attn_max_parts(T) : 1;
     return np > 1 ? align_up((size_t)B * H * T * np * (AT_DP + 2) * sizeof(float), 256) : 0;
 }
 
@@ -1230,7 +1313,7 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
         return 0;
     }
     int part_keys = 0;
-    int nparts = workspace ? attn_fwd_parts(B, T, H, &part_keys) : 1;
+    int nparts = workspace ? attn_key_parts(B, T, H, causal, &part_keys) : 1;
     if (nparts > 1 && workspace_bytes < tsasr_relpos_attn_fwd_workspace_bytes(B, T, H)) nparts = 1;
     float *part_o = (float *)workspace, *part_ml = nparts > 1 ? part_o + (size_t)B * H * T * nparts * AT_DP : nullptr;
     if (nparts > 1) grid.x *= nparts;
@@ -1252,8 +1335,9 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
 
 size_t tsasr_relpos_attn_bwd_workspace_bytes(int B, int T, int H) {
     // pos_bias partial sums + the two materialised [B,H,T,Tp] tensors (P_d, scale*dS; sized for fp32 io) + (q + v) rows + d(pk) partials
+    // + fp32 dQ shares of the key parts (long sequences in small batches only)
     return attn_slab_bytes(B, T, H) + 2 * align_up((size_t)B * H * T * attn_tp(T) * sizeof(float), 256) + attn_qv_bytes(B, T, H) +
-           attn_part_bytes(B, T, H);
+           attn_part_bytes(B, T, H) + attn_dq_part_bytes(B, T, H);
 }
 
 /* Backward of tsasr_relpos_attn_fwd. dqkv [B,T,H,3*Dh] (fully written), d_bias_u / d_bias_v fp32 [H*Dh] in the [H,Dh] reading of the
@@ -1271,7 +1355,8 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
     TSASR_CHECK_ARG(B > 0 && T > 0 && H > 0 && Dh > 0 && Dh <= AT_DP, "tsasr_relpos_attn_bwd: head dim %d not supported", Dh);
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), "tsasr_relpos_attn_bwd: workspace too small");
     TSASR_CHECK_ARG((long long)B * H <= 65535, "tsasr_relpos_attn_bwd: B*H too large");
-    const int nqt = cdiv(T, AT_QB);
+    int part_keys_ = 0;
+    const int nqt = cdiv(T, AT_QB) * attn_key_parts(B, T, H, causal, &part_keys_);   // rows of pos_bias partial sums per utterance and wave
     hipStream_t st = (hipStream_t)stream;
     float *slab = (float *)workspace;
     if (io_dtype == TSASR_F32)
