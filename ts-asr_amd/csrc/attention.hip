@@ -1179,14 +1179,26 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 // with 24-tile parts = 240 workgroups, 136 - 193 us with 4 .. 16-tile parts, 297 us unsplit).
 constexpr int AT_MIN_PART = 8;
 static int host_causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
-static int attn_max_parts(int T) { return std::max(1, cdiv(cdiv(T, AT_KT), AT_MIN_PART)); }
+static int attn_ksplit_env() {   // TSASR_ATTN_KSPLIT = 0: never split; n > 0: parts of n key tiles whatever the shape (A/B)
+    static const int v = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;
+    return v;
+}
+static int attn_max_parts(int T) {
+    const int f = attn_ksplit_env();
+    return std::max(1, cdiv(cdiv(T, AT_KT), f > 0 ? std::min(f, AT_MIN_PART) : AT_MIN_PART));
+}
 static int attn_key_parts(int B, int T, int H, int causal, int *part_keys) {
-    static const int forced = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;   // 0: never; n: n key tiles per part
+    const int forced = attn_ksplit_env();
     static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     const int tiles = cdiv(T, AT_KT), nqb = cdiv(T, AT_QB);
     *part_keys = 0;
+    if (forced > 0) {
+        if (forced >= tiles) return 1;
+        *part_keys = forced * AT_KT;
+        return cdiv(tiles, forced);
+    }
     if (forced == 0 || tiles <= AT_MIN_PART || (long long)B * H * nqb >= cus) return 1;
-    int per = std::max(forced, AT_MIN_PART);
+    int per = AT_MIN_PART;
     if (forced <= 0)
         for (; per < tiles; ++per) {
             long long n = 0;
