@@ -156,6 +156,7 @@ class Brain:
         self.arena = None
         self._graph_mode, self._graph, self._graph_warmup, self._eager_steps = False, None, 3, 0
         self._static_batches, self._static_loss, self._graphs, self._graph_pool, self._eager_stepped = {}, {}, {}, None, False
+        self._graph_comm_ok = None                # multi-rank: may collectives be captured with the step? (probed once, see _graph_comm)
         self._graph_max_shapes, self._seen_shapes = 24, set()
         self._aux_streams = []
         self.rank = int(os.environ.get("RANK", 0))
@@ -338,7 +339,15 @@ class Brain:
         """Collectives inside the captured step: only through the direct RCCL C-ABI (csrc/comm.hip), whose launches are plain stream work.
         torch.distributed's gloo (and ProcessGroupNCCL's watchdog) cannot be captured: then the arena is all-reduced in one piece between
         the replayed graph and the optimizer (TSASR_GRAPH_COMM=0 forces that form for A/B runs)."""
-        return bool(self.distributed and _GRAPH_COMM and getattr(self.arena, "direct", False))
+        if not (self.distributed and _GRAPH_COMM and getattr(self.arena, "direct", False)):
+            return False
+        if self._graph_comm_ok is None:   # first question of a multi-rank run (asked by every rank before its first step): probe once
+            from . import dp as _dp
+            self._graph_comm_ok = _dp.direct_capture_probe(self.device, self.arena.world_size, self.rank, self.arena.group)
+            if not self._graph_comm_ok and self.rank == 0:
+                import sys
+                print("[ts-asr_amd] collectives stay outside the captured step (one all-reduce between replay and optimizer)", file=sys.stderr)
+        return self._graph_comm_ok
 
     def _capture(self, batch, should_step, key):
         if key not in self._static_batches:

@@ -77,6 +77,40 @@ def direct_rccl_init(world, rank, device, force=False):
     return world
 
 
+def direct_capture_probe(device, world, rank, group=None):
+    """True when an all-reduce of the direct communicator, captured into a hipGraph on a forked stream and replayed, averages correctly
+    on EVERY rank. Called once before the first multi-rank capture of a step: a capture that fails half-way through a training step
+    would leave the arena's queues in an unknown state, a failed probe leaves nothing behind - the step is then captured without
+    collectives (one all-reduce between replay and optimizer: round 1's form). The verdict is agreed over the process group (MIN)."""
+    import sys
+    from . import _capi as C
+    ok = 1
+    try:
+        buf = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=device)
+        comm = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream()
+            comm.wait_stream(cur)
+            C.check(C.lib().tsasr_allreduce_bucket(C.ptr(buf), buf.numel(), C.F32, 1, ctypes.c_void_p(comm.cuda_stream)), "tsasr_allreduce_bucket")
+            cur.wait_stream(comm)
+        g.replay()
+        torch.cuda.synchronize()
+        n = _DIRECT["ranks"] or world    # ranks of the direct communicator (the one-rank GPU test tells the arena there are two)
+        ok = int(bool(torch.allclose(buf, torch.full_like(buf, (n + 1) / 2.0), rtol=1e-6)))
+        if not ok:
+            print(f"[ts-asr_amd] rank {rank}: captured all-reduce replayed a wrong average ({float(buf[0])})", file=sys.stderr, flush=True)
+    except Exception as e:   # noqa: BLE001 - any failure means "do not capture collectives"
+        print(f"[ts-asr_amd] rank {rank}: capturing an RCCL all-reduce failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        ok = 0
+    if is_initialized() and world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    return bool(ok)
+
+
 class GradArena:
     def __init__(self, modules, world_size=1, bucket_bytes=None, group=None):
         if bucket_bytes is None:    # 32 MiB buckets (6-7 per step at 51 M parameters); TSASR_BUCKET_MB for tests with small models
