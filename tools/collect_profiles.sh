@@ -37,9 +37,9 @@ if [ -s $O/rccl_timeline.txt ]; then
     echo "the hipGraph with the rest of the step and replayed. On a one-rank communicator RCCL's all-reduce kernel is \`oneRankReduce\`. This"
     echo "shows capture + replay + placement beside backward; it does NOT validate N > 1 (no multi-GPU box in the development loop)."
     echo
-    echo "Output of the check (losses of the plain / RCCL fp32 payload / RCCL bf16 payload runs, bucket collectives in the captured step):"
+    echo "Output of the check (losses of the plain / RCCL fp32 payload / RCCL bf16 payload / collectives-outside-the-graph runs, bucket collectives in the captured step):"
     echo '```'
-    grep -E "^(plain|rccl|rccl_bf16) |RCCL single-rank" $O/rccl_check.log | cut -c1-260
+    grep -E "^(plain|rccl|rccl_bf16|rccl_uncaptured) |RCCL single-rank" $O/rccl_check.log | cut -c1-260
     echo '```'
     echo
     echo "RCCL kernels in the whole trace (3 runs x 8 steps):"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-hardware-queue timeline of ONE captured step from a rocprofv3 kernel trace (.db): which kernels ran where and when, and how
 much the queues overlapped (the step's branches run on separate HIP streams; hipGraph maps them to queues). Usage: stream_timeline.py db [step]
-[--grep substring]: also list every kernel of the step whose name contains the substring (start, end, queue, kernels of OTHER queues
+[--grep substring] [--dump t0 t1]: also list every kernel of the step whose name contains the substring (start, end, queue, kernels of OTHER queues
 that ran during it)."""
 import collections, re, sqlite3, sys
 argv = [a for a in sys.argv[1:]]
@@ -9,6 +9,10 @@ grep = None
 if "--grep" in argv:
     i = argv.index("--grep"); grep = argv[i + 1].lower(); del argv[i:i + 2]
 sys.argv = [sys.argv[0]] + argv
+dump = None
+if "--dump" in argv:   # --dump t0_ms t1_ms: every kernel of the step starting in that window (start, duration, gap to the previous kernel of its queue)
+    i = argv.index("--dump"); dump = (float(argv[i + 1]), float(argv[i + 2])); del argv[i:i + 3]
+    sys.argv = [sys.argv[0]] + argv
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
 starts = [i for i, r in enumerate(rows) if "seed_advance" in r[0]]
@@ -40,3 +44,12 @@ if grep:
     for n, s, e, q in hits:
         others = [short(n2) for n2, s2, e2, q2 in step if q2 != q and s2 < e and e2 > s]
         print("    %7.3f-%7.3f ms q%d %-40s beside %d kernels of other queues%s" % ((s - t0) / 1e6, (e - t0) / 1e6, q, short(n), len(others), (": " + ", ".join(sorted(set(others))[:3])) if others else ""))
+if dump:
+    last_end = {}
+    print("  kernels starting in %.2f .. %.2f ms:" % dump)
+    for n, s, e, q in step:
+        t = (s - t0) / 1e6
+        if dump[0] <= t < dump[1]:
+            gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+            print("    %7.3f ms q%d dur %7.1f us gap %6.1f us  %s" % (t, q, (e - s) / 1e3, gap, short(n)))
+        last_end[q] = e
