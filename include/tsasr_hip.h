@@ -298,6 +298,19 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
                             void *dres, void *dx, float *dgamma, float *dbeta, float *dbias, long long M, int D, float alpha, float p,
                             unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
                             int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* Two LayerNorms in a row with the residual tail in front - norm2 of a Conformer layer and the next layer's first LayerNorm (or the
+ * encoder's final norm): Conformer.py:194-217,259, models/conformer.py:223-233. (s, y, z) bit-identical to tsasr_add_layernorm_fwd +
+ * tsasr_layernorm_fwd; the backward takes dz and (optionally) the gradients reaching y and s along other paths. */
+int tsasr_add_layernorm2_fwd(const void *x, const float *bias, const void *res, void *s, void *y, void *z, float *mean, float *rstd,
+                             float *mean2, float *rstd2, const float *gamma, const float *beta, const float *gamma2, const float *beta2,
+                             long long M, int D, float alpha, float p, unsigned long long seed, const unsigned long long *seed_dev,
+                             const int32_t *valid_lens, int Trows, float eps, float eps2, int io_dtype, void *stream);
+size_t tsasr_add_layernorm2_bwd_workspace_bytes(long long M, int D);
+int tsasr_add_layernorm2_bwd(const void *dz, const void *dy, const void *dout, const void *s, const float *gamma, const float *beta,
+                             const float *gamma2, const float *mean, const float *rstd, const float *mean2, const float *rstd2, void *dres,
+                             void *dx, float *dgamma, float *dbeta, float *dbias, float *dgamma2, float *dbeta2, long long M, int D,
+                             float alpha, float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens,
+                             int Trows, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Whole-sequence LSTM recurrences (all U steps of tsasr_lstm_step_fwd / _bwd). bf16, H in {256, 512}, B <= 256: one persistent
  * launch per direction (workgroups exchange h_t / dG_t through write-through stores and an arrival counter); otherwise a loop of

@@ -743,3 +743,46 @@ def test_layer_norm_res_sums_both_gradients(ops, dtype):
     y, xa = ops.layer_norm_res(xg, w.to(DEV), b.to(DEV), 1e-5)
     xa.backward(dr.to(DEV))
     assert torch.equal(xg.grad, dr.to(DEV))
+
+
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 256), (torch.bfloat16, 144), (torch.float32, 144), (torch.float32, 256), (torch.bfloat16, 512)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("with_dy", [True, False])
+def test_add_layer_norm2_equals_the_two_launches_it_replaces(ops, dtype, D, p, with_dy):
+    """The layer seam norm2 -> next layer's first LayerNorm (Conformer.py:194-217,259; after the last layer the encoder's final norm,
+    eps 1e-6: models/conformer.py:223-233) in ONE launch each way (tsasr_add_layernorm2_fwd/bwd) against the two launches it replaces
+    (tsasr_add_layernorm_* then tsasr_layernorm_*, themselves pinned to the oracle by the block tests above): y, z and the data
+    gradients to the last bits of the row sums (same dropout seed, ragged valid lengths; bf16: < 0.2 % of the elements differ, by one
+    ulp), parameter gradients to summation order. with_dy=False: y has no
+    other reader (the last layer)."""
+    B, Tn = 3, 50
+    g = torch.Generator().manual_seed(D + int(p * 10))
+    mk = lambda *shape: torch.randn(*shape, generator=g)  # noqa: E731
+    x0, r0 = mk(B, Tn, D).to(dtype), mk(B, Tn, D).to(dtype)
+    par0 = [mk(D) * 0.1, 1 + 0.1 * mk(D), 0.1 * mk(D), 1 + 0.1 * mk(D), 0.1 * mk(D)]   # bias, g1, b1, g2, b2
+    wz, wy = mk(B, Tn, D).to(DEV), mk(B, Tn, D).to(DEV)
+    valid = torch.tensor([Tn, 31, 7], dtype=torch.int32, device=DEV)
+    out = []
+    for fused in (False, True):
+        x, r = x0.clone().to(DEV).requires_grad_(), r0.clone().to(DEV).requires_grad_()
+        par = [t.clone().to(DEV).requires_grad_() for t in par0]
+        if fused:
+            y, z = ops._AddLayerNorm2Fn.apply(x, par[0], r, par[1], par[2], par[3], par[4], 0.5, p, 4321, valid, Tn, 1e-5, 1e-6)
+        else:
+            _, y0 = ops._AddLayerNormFn.apply(x, par[0], r, par[1], par[2], 0.5, p, 4321, valid, Tn, 1e-5)
+            z, y = ops._LayerNormResFn.apply(y0, par[3], par[4], 1e-6)
+        loss = (z.float() * wz).sum() + ((y.float() * wy).sum() if with_dy else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((y.detach(), z.detach(), x.grad, r.grad, [t.grad for t in par]))
+    (y_a, z_a, dx_a, dr_a, pg_a), (y_b, z_b, dx_b, dr_b, pg_b) = out
+    assert torch.equal(y_a, y_b) and torch.equal(z_a, z_b)
+    # backward: the row sums of the kernels associate differently (last fp32 bits; in bf16 that flips the odd rounding: one ulp)
+    rt, at = (1e-5, 1e-6) if dtype == torch.float32 else (2 ** -7, 2 ** -9)
+    torch.testing.assert_close(dx_b.float(), dx_a.float(), rtol=rt, atol=at)
+    torch.testing.assert_close(dr_b.float(), dr_a.float(), rtol=rt, atol=at)
+    if dtype == torch.bfloat16:
+        frac = max(float((dx_b != dx_a).float().mean()), float((dr_b != dr_a).float().mean()))
+        assert frac < 2e-3, frac
+    for a, b_, name in zip(pg_a, pg_b, ("bias", "gamma", "beta", "gamma2", "beta2")):
+        np.testing.assert_allclose(b_.float().cpu().numpy(), a.float().cpu().numpy(), rtol=2e-4, atol=2e-4 * float(a.abs().max()), err_msg=name)

@@ -44,6 +44,13 @@ if grep:
     for n, s, e, q in hits:
         others = [short(n2) for n2, s2, e2, q2 in step if q2 != q and s2 < e and e2 > s]
         print("    %7.3f-%7.3f ms q%d %-40s beside %d kernels of other queues%s" % ((s - t0) / 1e6, (e - t0) / 1e6, q, short(n), len(others), (": " + ", ".join(sorted(set(others))[:3])) if others else ""))
+if "--names" in sys.argv or dump:   # launches and summed duration per kernel name in this one step
+    cnt = collections.defaultdict(lambda: [0, 0.0])
+    for n, s_, e, q in step:
+        c = cnt[short(n)]; c[0] += 1; c[1] += (e - s_) / 1e3
+    print("  per kernel name in this step (launches, summed us):")
+    for n, (c, us) in sorted(cnt.items(), key=lambda kv: -kv[1][1]):
+        print("    %4d  %8.1f us  %s" % (c, us, n))
 if dump:
     last_end = {}
     print("  kernels starting in %.2f .. %.2f ms:" % dump)

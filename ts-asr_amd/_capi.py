@@ -90,6 +90,9 @@ _PROTOS = {
     "tsasr_add_layernorm_fwd": (c_int, [c_void_p] * 9 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
     "tsasr_add_layernorm_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
     "tsasr_add_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_add_layernorm2_fwd": (c_int, [c_void_p] * 14 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
+    "tsasr_add_layernorm2_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
+    "tsasr_add_layernorm2_bwd": (c_int, [c_void_p] * 18 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_lstm_seq_persistent": (c_int, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),

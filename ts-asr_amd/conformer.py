@@ -99,16 +99,22 @@ class ConformerEncoder(nn.Module):
             x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
         pos = self.positional_encoding(x)
         attns = []
+        pre, n = None, len(self.layers)
         for i, layer in enumerate(self.layers):
-            x, attn = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn)
+            inject = i in self.injection_after and speaker_embs is not None
+            # a layer's norm2 is followed by another LayerNorm of the same rows - the next layer's first macaron LayerNorm, or the final
+            # norm (models/conformer.py:223-233) - unless the speaker embedding is injected in between: one launch for the pair
+            nxt = None if inject else (self.norm.norm if i == n - 1 else self.layers[i + 1].ffn_module1[0])
+            x, attn, pre = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre, next_ln=nxt) if nxt is not None \
+                else layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre) + (None,)
             if return_attn:
                 attns.append(attn.detach())
-            if i in self.injection_after and speaker_embs is not None:
+            if inject:
                 # a callable = "not needed before this point": the recipe computes the speaker branch on a second HIP stream and
                 # joins it here, so it overlaps the mixture's front-end and the layers before the injection
                 speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
                 x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
-        x = self.norm(x)
+        x = self.norm(x) if pre is None else pre
         return (x, attns) if return_attn else x
 
     def _inject_speaker_emb(self, src, spk, spk_len):

@@ -876,6 +876,265 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The seam between two Conformer LAYERS is two LayerNorms in a row: norm2 of layer i (Conformer.py:259) and the first macaron FFN's
+// LayerNorm of layer i+1 (Conformer.py:194-217; after the last layer: the encoder's final norm, models/conformer.py:233). One pass:
+//   s = res + alpha * timemask(dropout_p(x + bias)) ;  y = LN(s) * gamma + beta ;  z = LN(y) * gamma2 + beta2
+// with the statistics of z taken from the STORED (rounded) y, so (y, z) are bit-identical to add_layernorm + layernorm.
+// Backward:  dy_total = LN_bwd2(dz) + dy (gradient that reaches y along the residual path; may be NULL), rounded to the io dtype as
+// the tensor it replaces was; then exactly add_layernorm_bwd. y is recomputed from s (beta needed), never read.
+// part rows per workgroup: [dgamma D | dbeta D | dbias D | dgamma2 D | dbeta2 D]
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int ITERS, bool HW>
+__global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(const T *__restrict__ x, const float *__restrict__ bias,
+                                                                 const T *__restrict__ res, T *__restrict__ s_out, T *__restrict__ y,
+                                                                 T *__restrict__ z, float *__restrict__ mean, float *__restrict__ rstd,
+                                                                 float *__restrict__ mean2, float *__restrict__ rstd2,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 const float *__restrict__ gamma2, const float *__restrict__ beta2,
+                                                                 long long M, int D, float alpha, float p, unsigned long long seed,
+                                                                 const unsigned long long *__restrict__ seed_dev,
+                                                                 const int32_t *__restrict__ valid_lens, int Trows, float eps, float eps2) {
+    constexpr int N = Vec<T>::N, LPR = HW ? 32 : 64;
+    long long row = HW ? ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x >> 5) & 1) : (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & (LPR - 1);
+    if (!HW && row >= M) return;
+    const bool row_valid = row < M;                    // HW: no early exit (the reductions are wave-wide instructions); stores guarded
+    if (HW && !row_valid) row = M - 1;
+    if (seed_dev) seed += *seed_dev;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
+    const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+    float v[ITERS][N], gv[ITERS][N], bt[ITERS][N], gv2[ITERS][N], bt2[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = min((it * LPR + l) * N, D - N);
+        ldv<float, N>(gamma + c, gv[it]);
+        ldv<float, N>(beta + c, bt[it]);
+        ldv<float, N>(gamma2 + c, gv2[it]);
+        ldv<float, N>(beta2 + c, bt2[it]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+            float xv[N], rv[N], bv[N];
+            ldv<T, N>(x + row * D + c, xv);
+            ldv<T, N>(res + row * D + c, rv);
+            if (bias) ldv<float, N>(bias + c, bv);
+            const unsigned long long idx = (unsigned long long)row * D + c;
+            const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t = xv[j] + (bias ? bv[j] : 0.f);
+                if (p > 0.f) t = ((km >> j) & 1u) ? t * ks : 0.f;
+                t = live ? t * alpha : 0.f;
+                t += rv[j];
+                if (sizeof(T) == 2) t = (float)(bf16_t)t;
+                v[it][j] = t;
+                sum += t;
+            }
+            if (row_valid) stv<T, N>(s_out + row * D + c, v[it]);
+        }
+    }
+    const float mu = (HW ? half_wave_sum(sum) : wave_sum(sum)) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const float d = v[it][j] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf((HW ? half_wave_sum(q) : wave_sum(q)) / D + eps);
+    float sum2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t = (v[it][j] - mu) * rs * gv[it][j] + bt[it][j];
+                if (sizeof(T) == 2) t = (float)(bf16_t)t;       // the second LayerNorm sees the stored row
+                v[it][j] = t;
+                sum2 += t;
+            }
+            if (row_valid) stv<T, N>(y + row * D + c, v[it]);
+        }
+    }
+    const float mu2 = (HW ? half_wave_sum(sum2) : wave_sum(sum2)) / D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const float d = v[it][j] - mu2; q2 += d * d; }
+        }
+    }
+    const float rs2 = rsqrtf((HW ? half_wave_sum(q2) : wave_sum(q2)) / D + eps2);
+    if (!row_valid) return;
+    if (l == 0) { mean[row] = mu; rstd[row] = rs; mean2[row] = mu2; rstd2[row] = rs2; }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = (v[it][j] - mu2) * rs2 * gv2[it][j] + bt2[it][j];
+            stv<T, N>(z + row * D + c, o);
+        }
+    }
+}
+
+template <typename T, int ITERS, bool HW>
+__global__ __launch_bounds__(256) void add_layernorm2_bwd_kernel(const T *__restrict__ dz, const T *__restrict__ dy, const T *__restrict__ dout,
+                                                                 const T *__restrict__ s_in, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, const float *__restrict__ gamma2,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                 const float *__restrict__ mean2, const float *__restrict__ rstd2,
+                                                                 T *__restrict__ dres, T *__restrict__ dx, float *__restrict__ part,
+                                                                 long long M, int D, float alpha, float p, unsigned long long seed,
+                                                                 const unsigned long long *__restrict__ seed_dev,
+                                                                 const int32_t *__restrict__ valid_lens, int Trows, int rows_per_wg) {
+    constexpr int N = Vec<T>::N, LPR = HW ? 32 : 64, RPP = HW ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) float colbuf[];  // [RPP row slots][5][D]
+    if (seed_dev) seed += *seed_dev;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
+    const int slot = threadIdx.x / LPR, l = threadIdx.x & (LPR - 1);
+    float ag[ITERS][N], abt[ITERS][N], abx[ITERS][N], ag2[ITERS][N], abt2[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int j = 0; j < N; ++j) ag[it][j] = abt[it][j] = abx[it][j] = ag2[it][j] = abt2[it][j] = 0.f;
+    int cc[ITERS];
+    bool ok[ITERS];
+    float gm[ITERS][N], bm[ITERS][N], gm2[ITERS][N];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        ok[it] = c < D;
+        cc[it] = ok[it] ? c : 0;
+        ldv<float, N>(gamma + cc[it], gm[it]);
+        ldv<float, N>(beta + cc[it], bm[it]);
+        ldv<float, N>(gamma2 + cc[it], gm2[it]);
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+    float sn[ITERS][N], zn[ITERS][N], dn[ITERS][N], on[ITERS][N], mu_n = 0.f, rs_n = 0.f, mu2_n = 0.f, rs2_n = 0.f;
+    auto request = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            ldv<T, N>(s_in + row * D + cc[it], sn[it]);
+            ldv<T, N>(dz + row * D + cc[it], zn[it]);
+            if (dy) ldv<T, N>(dy + row * D + cc[it], dn[it]);
+            if (dout) ldv<T, N>(dout + row * D + cc[it], on[it]);
+        }
+        mu_n = mean[row];
+        rs_n = rstd[row];
+        mu2_n = mean2[row];
+        rs2_n = rstd2[row];
+    };
+    if (HW ? r0 + (slot & ~1) < r1 : r0 + slot < r1) request(min(r0 + slot, r1 - 1));
+    for (long long row_w = r0 + (HW ? (slot & ~1) : slot); row_w < r1; row_w += RPP) {
+        const long long row_u = HW ? row_w + (slot & 1) : row_w;
+        const bool row_valid = row_u < r1;
+        const long long row = row_valid ? row_u : r1 - 1;
+        const float mu = mu_n, rs = rs_n, mu2 = mu2_n, rs2 = rs2_n;
+        const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+        float xh[ITERS][N], xh2[ITERS][N], gd[ITERS][N], dov[ITERS][N], dyr[ITERS][N];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const bool use = HW ? (ok[it] && row_valid) : ok[it];
+                const float h = use ? (sn[it][j] - mu) * rs : 0.f;
+                float yv = h * gm[it][j] + bm[it][j];
+                if (sizeof(T) == 2) yv = (float)(bf16_t)yv;                    // the stored y of the forward
+                const float h2 = use ? (yv - mu2) * rs2 : 0.f, dzv = use ? zn[it][j] : 0.f;
+                xh[it][j] = h;
+                xh2[it][j] = h2;
+                ag2[it][j] += dzv * h2;
+                abt2[it][j] += dzv;
+                const float g2 = dzv * gm2[it][j];
+                gd[it][j] = g2;
+                t1 += g2;
+                t2 += g2 * h2;
+                dov[it][j] = dout ? on[it][j] : 0.f;
+                dyr[it][j] = (dy && use) ? dn[it][j] : 0.f;
+            }
+        }
+        if (row_w + RPP < r1) request(min(row_u + RPP, r1 - 1));
+        const float n1 = (HW ? half_wave_sum(t1) : wave_sum(t1)) / D, n2 = (HW ? half_wave_sum(t2) : wave_sum(t2)) / D;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const bool use = HW ? (ok[it] && row_valid) : ok[it];
+                float dv = rs2 * (gd[it][j] - n1 - xh2[it][j] * n2) + dyr[it][j];   // gradient of y: through the second LayerNorm + the residual path
+                if (sizeof(T) == 2) dv = (float)(bf16_t)dv;
+                dv = use ? dv : 0.f;
+                const float h = xh[it][j];
+                ag[it][j] += dv * h;
+                abt[it][j] += dv;
+                const float g = dv * gm[it][j];
+                gd[it][j] = g;
+                s1 += g;
+                s2 += g * h;
+            }
+        }
+        const float m1 = (HW ? half_wave_sum(s1) : wave_sum(s1)) / D, m2 = (HW ? half_wave_sum(s2) : wave_sum(s2)) / D;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (HW ? (ok[it] && row_valid) : ok[it]) {
+                const int c = cc[it];
+                float ds[N], dxv[N];
+                const unsigned long long idx = (unsigned long long)row * D + c;
+                const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float d = rs * (gd[it][j] - m1 - xh[it][j] * m2) + dov[it][j];
+                    ds[j] = d;
+                    float g = live ? d * alpha : 0.f;
+                    if (p > 0.f) g = ((km >> j) & 1u) ? g * ks : 0.f;
+                    dxv[j] = g;
+                    abx[it][j] += g;
+                }
+                stv<T, N>(dres + row * D + c, ds);
+                stv<T, N>(dx + row * D + c, dxv);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * LPR + l) * N;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                colbuf[(slot * 5 + 0) * D + c + j] = ag[it][j];
+                colbuf[(slot * 5 + 1) * D + c + j] = abt[it][j];
+                colbuf[(slot * 5 + 2) * D + c + j] = abx[it][j];
+                colbuf[(slot * 5 + 3) * D + c + j] = ag2[it][j];
+                colbuf[(slot * 5 + 4) * D + c + j] = abt2[it][j];
+            }
+        }
+    }
+    __syncthreads();
+    float *pw = part + (size_t)blockIdx.x * 5 * D;
+    for (int i = threadIdx.x; i < 5 * D; i += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < RPP; ++q) a += colbuf[q * 5 * D + i];
+        pw[i] = a;
+    }
+}
+
 // out3[k][c] = sum_parts part[n][k*D + c], k = 0..2 (dgamma, dbeta, dbias) ; any out pointer may be NULL
 __global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ part, float *__restrict__ o0, float *__restrict__ o1,
                                                       float *__restrict__ o2, int nparts, int D) {
@@ -1232,6 +1491,69 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
         tsasr_reduce_submit(part + 2 * D, dbias, 3 * D, nwg, D, 0, st);
     } else colsum3_kernel<<<cdiv(3 * D, 16), 256, 0, st>>>(part, dgamma, dbeta, dbias, nwg, D);
     TSASR_CHECK_LAUNCH("tsasr_add_layernorm_bwd");
+    return 0;
+}
+
+/* (s, y, z) = (res + alpha*timemask(dropout(x + bias)), LN(s; gamma, beta), LN(y; gamma2, beta2)): tsasr_add_layernorm_fwd followed by
+ * tsasr_layernorm_fwd in one launch, bit-identical outputs (models/conformer.py:223-233 + Conformer.py:194-259: norm2 of a layer and
+ * the next layer's first LayerNorm, or the encoder's final norm, whose eps differs: eps2). mean2 / rstd2 [M] are the statistics of y. */
+int tsasr_add_layernorm2_fwd(const void *x, const float *bias, const void *res, void *s, void *y, void *z, float *mean, float *rstd,
+                             float *mean2, float *rstd2, const float *gamma, const float *beta, const float *gamma2, const float *beta2,
+                             long long M, int D, float alpha, float p, unsigned long long seed, const unsigned long long *seed_dev,
+                             const int32_t *valid_lens, int Trows, float eps, float eps2, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(x && res && s && y && z && mean && rstd && mean2 && rstd2 && gamma && beta && gamma2 && beta2, "tsasr_add_layernorm2_fwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && p >= 0.f && p < 1.f, "tsasr_add_layernorm2_fwd: bad shape/p");
+    TSASR_CHECK_ARG(!valid_lens || (Trows > 0 && M % Trows == 0), "tsasr_add_layernorm2_fwd: rows not a multiple of T");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((M + 3) / 4);
+#define ALN2_F(TT, IT, HWV, GR) add_layernorm2_fwd_kernel<TT, IT, HWV><<<GR, 256, 0, st>>>((const TT *)x, bias, (const TT *)res, (TT *)s, (TT *)y, (TT *)z, mean, rstd, mean2, rstd2, gamma, beta, gamma2, beta2, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps, eps2)
+    if (io_dtype == TSASR_BF16) {
+        if (D <= 256) ALN2_F(bf16_t, 1, true, (unsigned)((M + 7) / 8));
+        else if (D <= 512) ALN2_F(bf16_t, 1, false, grid); else if (D <= 1024) ALN2_F(bf16_t, 2, false, grid);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm2_fwd: D=%d too large", D);
+    } else if (io_dtype == TSASR_F32) {
+        if (D <= 256) ALN2_F(float, 1, false, grid); else if (D <= 512) ALN2_F(float, 2, false, grid); else if (D <= 1024) ALN2_F(float, 4, false, grid);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm2_fwd: D=%d too large", D);
+    } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+#undef ALN2_F
+    TSASR_CHECK_LAUNCH("tsasr_add_layernorm2_fwd");
+    return 0;
+}
+
+size_t tsasr_add_layernorm2_bwd_workspace_bytes(long long M, int D) {
+    const int rpw = pick_rows_per_wg(M, 8);
+    return align_up((size_t)((M + rpw - 1) / rpw) * 5 * D * sizeof(float), 256);
+}
+
+/* Backward of tsasr_add_layernorm2_fwd: dz = gradient of z, dy = gradient reaching y along other paths (NULL: none), dout = gradient
+ * reaching s along other paths (NULL: none). dres / dx as tsasr_add_layernorm_bwd; dgamma2 / dbeta2 belong to the second LayerNorm. */
+int tsasr_add_layernorm2_bwd(const void *dz, const void *dy, const void *dout, const void *s, const float *gamma, const float *beta,
+                             const float *gamma2, const float *mean, const float *rstd, const float *mean2, const float *rstd2, void *dres,
+                             void *dx, float *dgamma, float *dbeta, float *dbias, float *dgamma2, float *dbeta2, long long M, int D,
+                             float alpha, float p, unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens,
+                             int Trows, int io_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dz && s && gamma && beta && gamma2 && mean && rstd && mean2 && rstd2 && dres && dx && workspace, "tsasr_add_layernorm2_bwd: null pointer");
+    TSASR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "tsasr_add_layernorm2_bwd: bad shape");
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_add_layernorm2_bwd_workspace_bytes(M, D), "tsasr_add_layernorm2_bwd: workspace too small");
+    const int rpw = pick_rows_per_wg(M, 8);
+    const int nwg = (int)((M + rpw - 1) / rpw);
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+#define ALN2_B(TT, IT, HWV) add_layernorm2_bwd_kernel<TT, IT, HWV><<<nwg, 256, (size_t)(HWV ? 8 : 4) * 5 * D * sizeof(float), st>>>((const TT *)dz, (const TT *)dy, (const TT *)dout, (const TT *)s, gamma, beta, gamma2, mean, rstd, mean2, rstd2, (TT *)dres, (TT *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw)
+    if (io_dtype == TSASR_BF16) {
+        if (D <= 256) ALN2_B(bf16_t, 1, true); else if (D <= 512) ALN2_B(bf16_t, 1, false); else if (D <= 1024) ALN2_B(bf16_t, 2, false);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm2_bwd: D=%d too large", D);
+    } else if (io_dtype == TSASR_F32) {
+        if (D <= 256) ALN2_B(float, 1, false); else if (D <= 512) ALN2_B(float, 2, false); else if (D <= 1024) ALN2_B(float, 4, false);
+        else TSASR_CHECK_ARG(false, "tsasr_add_layernorm2_bwd: D=%d too large", D);
+    } else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
+#undef ALN2_B
+    tsasr_reduce_submit(part, dgamma, 5 * D, nwg, D, 0, st);
+    tsasr_reduce_submit(part + D, dbeta, 5 * D, nwg, D, 0, st);
+    tsasr_reduce_submit(part + 2 * D, dbias, 5 * D, nwg, D, 0, st);
+    tsasr_reduce_submit(part + 3 * D, dgamma2, 5 * D, nwg, D, 0, st);
+    tsasr_reduce_submit(part + 4 * D, dbeta2, 5 * D, nwg, D, 0, st);
+    TSASR_CHECK_LAUNCH("tsasr_add_layernorm2_bwd");
     return 0;
 }
 

@@ -539,17 +539,24 @@ class ConformerEncoderLayer(nn.Module):
         y = ops.ffn_core(y, pff[0].weight, pff[0].bias, pff[3].weight, self.slope, self.dropout, self.training)   # two GEMMs, fused epilogues
         return ops.dropout_add(y, pff[3].bias, x, 0.5, self.dropout, self.training)
 
-    def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True):
+    def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True, prenorm=None,
+                next_ln=None):
         """Returns (x, attention weights [B,H,T,T] or None). The reference always materialises the weights
         (Conformer.py:247-254); the encoder passes need_attn=False unless return_attn is requested.
-        Every ``residual + branch`` of Conformer.py:243-259 is fused with the LayerNorm that reads it (ops.add_layer_norm)."""
+        Every ``residual + branch`` of Conformer.py:243-259 is fused with the LayerNorm that reads it (ops.add_layer_norm).
+        The seam between two LAYERS is two LayerNorms in a row (this layer's norm2, then the next layer's first macaron LayerNorm or the
+        encoder's final norm): the encoder may pass that next ``nn.LayerNorm`` as ``next_ln`` - a third value, next_ln(x), is then
+        returned (same launch as norm2, same bits) - and hand it to the next layer as ``prenorm``."""
         if valid_lens is None and src_key_padding_mask is not None:
             valid_lens = (~src_key_padding_mask).sum(-1).to(torch.int32)
         tr, p, conv, mha = self.training, self.dropout, self.convolution_module, self.mha_layer
         ln1, pff1 = self.ffn_module1[0], self.ffn_module1[1].ffn
         ln2, pff2 = self.ffn_module2[0], self.ffn_module2[1].ffn
         x = _cd(x)
-        y, x = ops.layer_norm_res(x, ln1.weight, ln1.bias, 1e-5)     # x is read twice (here and as the residual): one backward kernel sums both gradients
+        if prenorm is None:
+            y, x = ops.layer_norm_res(x, ln1.weight, ln1.bias, 1e-5)     # x is read twice (here and as the residual): one backward kernel sums both gradients
+        else:
+            y = prenorm                                                  # ln1(x), computed by the previous layer's last launch
         h = ops.ffn_core(y, pff1[0].weight, pff1[0].bias, pff1[3].weight, self.slope, p, tr)
         x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
         causal = self.causal or src_mask is not None
@@ -558,5 +565,8 @@ class ConformerEncoderLayer(nn.Module):
         c = conv.core(y)
         x, y = ops.add_layer_norm(c, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)          # + conv ; ffn2 LN
         h = ops.ffn_core(y, pff2[0].weight, pff2[0].bias, pff2[3].weight, self.slope, p, tr)
+        if next_ln is not None and ops.add_layer_norm2_supported(h):
+            x, z = ops.add_layer_norm2(h, pff2[3].bias, x, self.norm2.norm, next_ln, 0.5, p, tr, eps2=next_ln.eps)
+            return x, attn, z
         _, x = ops.add_layer_norm(h, pff2[3].bias, x, self.norm2.norm, 0.5, p, tr)                  # norm2(x + .5*drop(ffn2))
-        return x, attn
+        return (x, attn) if next_ln is None else (x, attn, None)

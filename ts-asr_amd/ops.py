@@ -830,6 +830,70 @@ def add_layer_norm(x, bias, res, ln, alpha=1.0, p=0.0, training=False, valid_len
     return _AddLayerNormFn.apply(x, bias, res, ln.weight, ln.bias, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, eps)
 
 
+class _AddLayerNorm2Fn(torch.autograd.Function):
+    """(y, z) = (LN(s; g1, b1), LN(y; g2, b2)), s = res + alpha*timemask(dropout(x + bias)): _AddLayerNormFn followed by _LayerNormResFn
+    in one launch each way (norm2 of a Conformer layer + the next layer's first LayerNorm, or the encoder's final norm), same bits."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, g1, b1, g2, b2, alpha, p, seed, valid_lens, trows, eps, eps2):
+        C.require_gpu(x, res, g1, b1, g2, b2)
+        ctx.set_materialize_grads(False)
+        xc, r = x.contiguous(), res.contiguous()
+        D = xc.shape[-1]
+        M = xc.numel() // D
+        b = None if bias is None else _f32(bias).contiguous()
+        ga, ba, gb, bb = (_f32(t).reshape(-1).contiguous() for t in (g1, b1, g2, b2))
+        s_out, y, z = torch.empty_like(xc), torch.empty_like(xc), torch.empty_like(xc)
+        stats = torch.empty(4, M, dtype=torch.float32, device=x.device)     # mean, rstd of s ; mean, rstd of y
+        with prof.region("add_layernorm2_fwd"):
+            C.check(C.lib().tsasr_add_layernorm2_fwd(C.ptr(xc), C.ptr(b), C.ptr(r), C.ptr(s_out), C.ptr(y), C.ptr(z), C.ptr(stats[0]),
+                                                     C.ptr(stats[1]), C.ptr(stats[2]), C.ptr(stats[3]), C.ptr(ga), C.ptr(ba), C.ptr(gb), C.ptr(bb),
+                                                     M, D, float(alpha), float(p), seed, C.ptr(seed_state(xc.device)), C.ptr(valid_lens),
+                                                     int(trows), float(eps), float(eps2), C.io_dtype(xc), C.stream_ptr()), "tsasr_add_layernorm2_fwd")
+        ctx.save_for_backward(s_out, ga, ba, gb, stats, valid_lens)
+        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias, g1, b1, g2, b2)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, dy, dz):
+        s_out, ga, ba, gb, stats, valid_lens = ctx.saved_tensors
+        alpha, p, seed, trows, bias_param, g1, b1, g2, b2 = ctx.cfg
+        D = s_out.shape[-1]
+        M = s_out.numel() // D
+        if dz is None:
+            dz = torch.zeros_like(s_out)
+        dz = dz.contiguous()
+        dy = None if dy is None else dy.contiguous()
+        dres, dx = torch.empty_like(s_out), torch.empty_like(s_out)
+        dg1, dbt1, dg2, dbt2 = (torch.empty(D, dtype=torch.float32, device=s_out.device) for _ in range(4))
+        db = torch.empty(D, dtype=torch.float32, device=s_out.device) if bias_param is not None else None
+        _keep(dg1, dbt1, dg2, dbt2, db)
+        ws = _ws(C.lib().tsasr_add_layernorm2_bwd_workspace_bytes(M, D), s_out.device)
+        with prof.region("add_layernorm2_bwd"):
+            C.check(C.lib().tsasr_add_layernorm2_bwd(C.ptr(dz), C.ptr(dy), None, C.ptr(s_out), C.ptr(ga), C.ptr(ba), C.ptr(gb), C.ptr(stats[0]),
+                                                     C.ptr(stats[1]), C.ptr(stats[2]), C.ptr(stats[3]), C.ptr(dres), C.ptr(dx), C.ptr(dg1),
+                                                     C.ptr(dbt1), C.ptr(db), C.ptr(dg2), C.ptr(dbt2), M, D, alpha, p, seed,
+                                                     C.ptr(seed_state(s_out.device)), C.ptr(valid_lens), trows, C.io_dtype(s_out),
+                                                     C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_add_layernorm2_bwd")
+        return (dx, (_pgrad(bias_param, db) if bias_param is not None else None), dres, _pgrad(g1, dg1), _pgrad(b1, dbt1),
+                _pgrad(g2, dg2), _pgrad(b2, dbt2), None, None, None, None, None, None, None)
+
+
+_FUSED_LN_PAIR = os.environ.get("TSASR_FUSED_LN_PAIR", "1") != "0"   # A/B knob
+
+
+def add_layer_norm2_supported(x):
+    return _FUSED_LN_PAIR and x.is_cuda and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
+
+
+def add_layer_norm2(x, bias, res, ln, ln_next, alpha=1.0, p=0.0, training=False, valid_lens=None, eps=1e-5, eps2=1e-5):
+    """Returns (y, z) = (ln(s), ln_next(ln(s))) with s = res + alpha * timemask(dropout_p(x + bias))."""
+    p = float(p) if training else 0.0
+    trows = x.shape[-2] if valid_lens is not None else 0
+    return _AddLayerNorm2Fn.apply(x, bias, res, ln.weight, ln.bias, ln_next.weight, ln_next.bias, alpha, p, next_seed() if p > 0 else 0,
+                                  valid_lens, trows, eps, eps2)
+
+
 class _MeanPoolFn(torch.autograd.Function):
     """Masked mean over time of [B,T,D] -> [B,1,D] (train_librispeechmix_scratch.py:52-64), one HIP launch each way."""
 
