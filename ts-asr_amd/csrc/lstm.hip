@@ -412,6 +412,12 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 }
 
 #define LQ_BR 16   // batch rows per exchange group
+// B <= 8 (long-form, one utterance per GPU): groups of 8 rows - the exchange tile a workgroup pulls per step halves (backward: 64 -> 32 KB)
+static int lq_br(int B) {
+    static const int forced = getenv("TSASR_LSTM_BR") ? atoi(getenv("TSASR_LSTM_BR")) : 0;
+    if (forced == 8 || forced == 16) return forced;
+    return B <= 8 ? 8 : LQ_BR;
+}
 
 // Zero-fill by a kernel, NOT hipMemsetAsync: a memset node captured into a hipGraph wrote stale host bytes instead of zeros from
 // the second replay on (ROCm 7.2, 256-byte fill: the arrival counters then started at garbage and the waits passed early).
@@ -423,21 +429,31 @@ static void zero_async(void *p, size_t bytes, hipStream_t st) {   // bytes % 4 =
     zero_words_kernel<<<(unsigned)std::min<size_t>(1024, (n + 255) / 256), 256, 0, st>>>((unsigned *)p, n);
 }
 
-template <int H>
-static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
-    auto kern = lstm_seq_fwd_kernel<H, LQ_BR>;
+template <int H, int BR>
+static void launch_seq_fwd_br(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
+    auto kern = lstm_seq_fwd_kernel<H, BR>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     zero_async(ws, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    kern<<<dim3(H / LQ_UN, cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+}
+template <int H>
+static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
+    if (lq_br(B) == 8) launch_seq_fwd_br<H, 8>(gates, c, h, whh, B, U, ws, st);
+    else launch_seq_fwd_br<H, LQ_BR>(gates, c, h, whh, B, U, ws, st);
+}
+template <int H, int BR>
+static void launch_seq_bwd_br(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, char *ws, hipStream_t st) {
+    auto kern = lstm_seq_bwd_kernel<H, BR>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    zero_async(ws, 256, st);
+    kern<<<dim3(H / LQ_UN, cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
 }
 template <int H>
 static void launch_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, char *ws, hipStream_t st) {
-    auto kern = lstm_seq_bwd_kernel<H, LQ_BR>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
-    zero_async(ws, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, LQ_BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    if (lq_br(B) == 8) launch_seq_bwd_br<H, 8>(gates, c, dout, dgates, whhT, B, U, ws, st);
+    else launch_seq_bwd_br<H, LQ_BR>(gates, c, dout, dgates, whhT, B, U, ws, st);
 }
 
 
@@ -511,8 +527,8 @@ static int device_cu_count() {
 // (96 KB of dynamic LDS, launch bound 1), so the grid may not exceed the CUs THIS device exposes; otherwise the per-step kernels run.
 static bool seq_persistent_ok(int B, int H, int io_dtype) {   // sync words: 2 per batch group in a 256-byte block
     static const int force_off = getenv("TSASR_LSTM_PERSISTENT") ? (atoi(getenv("TSASR_LSTM_PERSISTENT")) == 0) : 0;
-    return !force_off && io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, LQ_BR) <= 16 &&
-           cdiv(B, LQ_BR) * (H / LQ_UN) <= device_cu_count();
+    return !force_off && io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, lq_br(B)) <= 16 &&
+           cdiv(B, lq_br(B)) * (H / LQ_UN) <= device_cu_count();
 }
 
 /* 1 when tsasr_lstm_seq_fwd/bwd run as ONE persistent launch for this shape on the current device (the workspace's first 256 bytes
