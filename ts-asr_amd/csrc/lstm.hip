@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
                 *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
         __syncthreads();
+        float4 gact[PP];
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = b0 + bl;
@@ -293,24 +294,34 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
             const float cn = gf * cprev[j] + gi * gg;
             cprev[j] = cn;
             const float hv = go * tanh_fast(cn);
-            if (b < B) {
-                *reinterpret_cast<float4 *>(gates + (((long long)b * U + t) * H + u0 + ul) * 4) = make_float4(gi, gf, gg, go);
-                c[((long long)b * U + t) * H + u0 + ul] = cn;
-            }
+            gact[j] = make_float4(gi, gf, gg, go);     // stored AFTER the arrival below: nobody waits for them, the drain in front of it must not
             hs[bl][ul] = (bf16_t)(b < B ? hv : 0.f);
         }
         __syncthreads();
         LQ_STAMP(2);   // cell math
+        u32x4 hv16 = {0u, 0u, 0u, 0u};
         if (tid < BR * 4) {   // BR*64-byte tile: whole 128-byte lines per wave-instruction, write-through
             const int ch = tid, bl = ch >> 2, part = ch & 3;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(&hs[bl][part * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
-            if (b0 + bl < B) *reinterpret_cast<u32x4 *>(h + ((long long)(b0 + bl) * U + t) * H + u0 + part * 8) = v;
+            hv16 = *reinterpret_cast<const u32x4 *>(&hs[bl][part * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(hv16, rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only the exchange tile is in flight here
         __syncthreads();
         LQ_STAMP(3);   // publish + drain
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the step's outputs for the backward / the caller: written while the other workgroups are already being waited for
+        if (tid < BR * 4) {
+            const int bl = tid >> 2, part = tid & 3;
+            if (b0 + bl < B) *reinterpret_cast<u32x4 *>(h + ((long long)(b0 + bl) * U + t) * H + u0 + part * 8) = hv16;
+        }
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int p = tid + 256 * j, bl = p >> 5, ul = p & 31, b = b0 + bl;
+            if (b < B) {
+                *reinterpret_cast<float4 *>(gates + (((long long)b * U + t) * H + u0 + ul) * 4) = gact[j];
+                c[((long long)b * U + t) * H + u0 + ul] = cprev[j];
+            }
+        }
         LQ_STAMP(4);
     }
 #ifdef LQ_PROFILE
@@ -395,18 +406,27 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             dcar[j] = dc * gf;
         }
         __syncthreads();
+        constexpr int NST = (BR * 16 + 255) / 256;
+        u32x4 dv16[NST];
 #pragma unroll
-        for (int k = 0; k < (BR * 16 + 255) / 256; ++k) {   // BR*256-byte tile: wave-instructions of 1 KiB, write-through
-            const int ch = tid + 256 * k, bl = ch >> 4, part = ch & 15;
+        for (int k = 0; k < NST; ++k) {   // BR*256-byte tile: wave-instructions of 1 KiB, write-through
+            const int ch = tid + 256 * k;
+            dv16[k] = (u32x4){0u, 0u, 0u, 0u};
             if (ch < BR * 16) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(&dgt[bl][part * 8]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
-                if (b0 + bl < B) *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = v;
+                dv16[k] = *reinterpret_cast<const u32x4 *>(&dgt[ch >> 4][(ch & 15) * 8]);
+                __builtin_amdgcn_raw_buffer_store_b128(dv16[k], rs, ((t * NWG + wg) * TILE + ch * 8) * 2, 0, 16);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only the exchange tile (and this step's input loads) are in flight here
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the gate gradients for the input-side GEMMs: nobody in this kernel reads them, so they go out after the arrival
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int ch = tid + 256 * k, bl = ch >> 4, part = ch & 15;
+            if (ch < BR * 16 && b0 + bl < B)
+                *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = dv16[k];
+        }
     }
     if (failed && tid == 0) dgates[((long long)min(b0, B - 1) * U) * K4 + u0] = (bf16_t)__builtin_nanf("");
 }
