@@ -102,16 +102,16 @@ __device__ __forceinline__ void stage_rows(bf16_t *lds, const T *__restrict__ sr
     constexpr int NIT = ROWS * (AT_DP / 8) / AT_TH;
     static_assert(ROWS * (AT_DP / 8) % AT_TH == 0, "whole passes of the workgroup");
     const bool fast = (Dh % 8) == 0;
-    const int c = (threadIdx.x % (AT_DP / 8)) * 8;      // 256 % (AT_DP / 8) == 0: one column group per thread
+    const int c = ((threadIdx.x & (AT_TH - 1)) % (AT_DP / 8)) * 8;      // 256 % (AT_DP / 8) == 0: one column group per thread
     float v[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int rr = (threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
+        const int rr = ((threadIdx.x & (AT_TH - 1)) + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
         load8_clamped<T>(src + (long long)min(max(r, lo), hi - 1) * src_stride, c, Dh, fast, v[it]);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int rr = (threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
+        const int rr = ((threadIdx.x & (AT_TH - 1)) + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
         if (r < lo || r >= hi) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[it][j] = 0.f;
@@ -131,20 +131,20 @@ struct StagePieces {
     int first_row, lo, hi;
     __device__ __forceinline__ void request(const T *__restrict__ src, long long src_stride, int first, int lo_, int hi_, int Dh) {
         first_row = first; lo = lo_; hi = hi_;
-        const int c = (threadIdx.x % (AT_DP / 8)) * 8, cc = min(c, ((Dh + 7) & ~7) - 8);
+        const int c = ((threadIdx.x & (AT_TH - 1)) % (AT_DP / 8)) * 8, cc = min(c, ((Dh + 7) & ~7) - 8);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int r = first + (int)(threadIdx.x + it * AT_TH) / (AT_DP / 8);
+            const int r = first + (int)((threadIdx.x & (AT_TH - 1)) + it * AT_TH) / (AT_DP / 8);
             const uint4 *p = reinterpret_cast<const uint4 *>(src + (long long)min(max(r, lo_), hi_ - 1) * src_stride + cc);
 #pragma unroll
             for (int w = 0; w < W; ++w) raw[it][w] = p[w];
         }
     }
     __device__ __forceinline__ void commit(bf16_t *lds, int Dh) const {
-        const int c = (threadIdx.x % (AT_DP / 8)) * 8;
+        const int c = ((threadIdx.x & (AT_TH - 1)) % (AT_DP / 8)) * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int rr = (int)(threadIdx.x + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
+            const int rr = (int)((threadIdx.x & (AT_TH - 1)) + it * AT_TH) / (AT_DP / 8), r = first_row + rr;
             if (sizeof(T) == 2 && (Dh % 8) == 0) {   // bf16 source, whole 16-byte pieces: straight to LDS, no fp32 round trip
                 const bool ok = r >= lo && r < hi && c < Dh;
                 uint4 w = raw[it][0];
@@ -686,8 +686,11 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
 //   bwd_kv (key-major: a lane owns one KEY, accumulators hold dK^T / dV^T): dK, dV.
 // dS = P * (dP - delta), delta_i = dO_i . O_i ; with dropout P_d = P*m/(1-p): dP = (dO.V^T)*m/(1-p), same counter-based mask.
 // =====================================================================================================================
-template <typename T>
-__global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
+// KG = 2: 8 waves - two groups of four share the workgroup's 128 queries and walk one half of its key tiles each (own K / V / band
+// tiles and G scratch in LDS), the second group hands its dQ shares to the first through LDS at the end. At B*H*T'/128 <= CUs there is
+// one workgroup per CU and with KG = 1 one wave per SIMD: nothing covers the softmax VALU work, the LDS round trips or the staging.
+template <typename T, int KG>
+__global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *__restrict__ qkv, const T *__restrict__ pk,
                                                                 const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                 const int32_t *__restrict__ key_lens, const T *__restrict__ out,
                                                                 const T *__restrict__ dout, const float *__restrict__ lse,
@@ -700,13 +703,15 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
     // dq_part (summed by relpos_attn_dq_merge_kernel) and its own row of pos_bias partial sums; P_d / dS columns are disjoint anyway
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (seed_dev) seed += *seed_dev;
-    bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem);
+    constexpr size_t GROUP_BYTES = (size_t)(2 * AT_KT + AT_BAND) * AT_LD * sizeof(bf16_t) + (size_t)AT_NW * 64 * 32 * sizeof(float);
+    const int kgrp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;       // wave-uniform
+    bf16_t *k_lds = reinterpret_cast<bf16_t *>(smem + kgrp * GROUP_BYTES);
     bf16_t *v_lds = k_lds + AT_KT * AT_LD;
     bf16_t *p_lds = v_lds + AT_KT * AT_LD;
     float *g_all = reinterpret_cast<float *>(p_lds + AT_BAND * AT_LD);
     const int part = nparts > 1 ? (int)(blockIdx.x % nparts) : 0;
     const int b = blockIdx.z, h = blockIdx.y, i0 = (nparts > 1 ? (int)(blockIdx.x / nparts) : (int)blockIdx.x) * AT_QB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x & (AT_TH - 1), lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     float *g_lds = g_all + wave * 64 * 32;
     const int D = H * Dh, R = 2 * Tn - 1;
     const long long row_stride = 3LL * D;
@@ -753,9 +758,16 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
 
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);
-    const int j_begin = part * part_keys;
+    int j_begin = part * part_keys;
     if (nparts > 1) j_end = min(j_end, j_begin + part_keys);   // an empty part (j_begin >= j_end) skips the loop and writes zero sums below
-    const bool pipe = (Dh % 8) == 0;
+    // trips of the key loop: the same for every wave of the workgroup (the loop holds workgroup barriers); KG = 2: each group takes
+    // `trips` tiles of the range, a group that runs out of keys idles through the remaining barriers
+    const int ntile = max(0, (j_end - j_begin + AT_KT - 1) / AT_KT), trips = (ntile + KG - 1) / KG;
+    if (KG > 1) {
+        j_begin += kgrp * trips * AT_KT;
+        j_end = min(j_end, j_begin + trips * AT_KT);
+    }
+    const bool pipe = KG == 1 && (Dh % 8) == 0;   // KG = 2: the other group's waves cover the round trips; the prefetch registers would spill
     StagePieces<T, AT_KT> sk, sv;
     StagePieces<T, AT_BAND> sp;
 #ifdef AT_PROFILE
@@ -770,8 +782,11 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
         sp.request(pk + (long long)h * Dh, D, j_begin - i0 - (AT_QB - 1) + Tn - 1, 0, R, Dh);
     }
     AT_STAMP(0);   // prologue (q, do, o loads; first tile requests)
-    for (int j0 = j_begin; j0 < j_end; j0 += AT_KT) {
+    for (int trip = 0; trip < trips; ++trip) {
+        const int j0 = j_begin + trip * AT_KT;
+        const bool idle = j0 >= j_end;             // group-uniform (KG = 2 only): no keys left for this group
         __syncthreads();
+        if (idle) { __syncthreads(); continue; }
         const int r_first = j0 - i0 - (AT_QB - 1) + Tn - 1;
         if (pipe) {
             sk.commit(k_lds, Dh);
@@ -897,6 +912,28 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
             AT_STAMP(5);
         }
     }
+    if (KG > 1) {   // the second group's shares of dQ_ac / dQ_bd reach the first through LDS ([wave][register][lane]: conflict-free)
+        __syncthreads();                                            // every tile consumed: the second group's area is free
+        float *xch = reinterpret_cast<float *>(smem + GROUP_BYTES) + wave * 64 * 64;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    xch[(db * 16 + g) * 64 + lane] = dqu[db][g];
+                    xch[(32 + db * 16 + g) * 64 + lane] = dqv[db][g];
+                }
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                dqu[db][g] += xch[(db * 16 + g) * 64 + lane];
+                dqv[db][g] += xch[(32 + db * 16 + g) * 64 + lane];
+            }
+    }
     // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
     T *dq = dqkv + ((long long)b * Tn + iqc) * row_stride + (long long)h * 3 * Dh;
     float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * AT_NW + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
@@ -906,7 +943,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_bwd_q_kernel(const T *__res
         for (int g = 0; g < 16; ++g) {
             const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
             if ((g & 3) == 0 && q_ok && nparts > 1) {
-                if (j_end > j_begin)
+                if (ntile > 0)
                     *reinterpret_cast<float4 *>(dq_part + ((((size_t)b * H + h) * Tn + iq) * nparts + part) * AT_DP + d) =
                         make_float4(dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
             } else if ((g & 3) == 0 && q_ok) {   // four consecutive head dims per store
@@ -1261,11 +1298,22 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, used);
     }
     const size_t lds_q = tsasr_relpos_attn_lds_bytes();
-    (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    relpos_attn_bwd_q_kernel<T><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), AT_TH, lds_q, st>>>((const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens,
-                                                                                       (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B,
-                                                                                       Tn, H, Dh, scale, causal, pdrop, seed, seed_dev, nparts, part_keys,
-                                                                                       dq_part);
+    // A/B knob TSASR_ATTN_BWD_KG=2: two key groups per workgroup (8 waves, two per SIMD). Measured at T' = 250, B = 32 (one workgroup per
+    // CU): 13.07 vs 13.06 ms per step with the tile prefetch dropped to fit 256 registers, 13.61 with it (76 spilled VGPRs) - the kernel
+    // is bound by the CU's VALU / LDS instruction throughput, not by latency a second wave could cover. Off.
+    static const int kg_env = getenv("TSASR_ATTN_BWD_KG") ? atoi(getenv("TSASR_ATTN_BWD_KG")) : 1;
+    const bool two = kg_env == 2 && Tn > AT_KT;
+    if (two) {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_q));
+        relpos_attn_bwd_q_kernel<T, 2><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), 2 * AT_TH, 2 * lds_q, st>>>(
+            (const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
+            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part);
+    } else {
+        (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        relpos_attn_bwd_q_kernel<T, 1><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), AT_TH, lds_q, st>>>(
+            (const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
+            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part);
+    }
     if (nparts > 1)
         relpos_attn_dq_merge_kernel<T><<<(unsigned)(((long long)B * H * Tn * 16 + 255) / 256), 256, 0, st>>>(dq_part, key_lens, (T *)dqkv, B, Tn, H, Dh, causal,
                                                                                                           nparts, part_keys);
