@@ -318,15 +318,17 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
             float psum = 0.f;
             bf16x8 pb[2];
+            unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
+            if (pdrop > 0.f) {
+                const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 float p = (m_new == -INFINITY) ? 0.f : __expf(sc[g] - m_new);
                 psum += p;
-                if (pdrop > 0.f) {
-                    const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                    p = drop_keep1(idx, dkey, thr) ? p * keep_scale : 0.f;
-                }
+                if (pdrop > 0.f) p = ((km[g >> 2] >> (g & 3)) & 1u) ? p * keep_scale : 0.f;
                 pb[g >> 3][g & 7] = (bf16_t)p;
             }
             psum += other_half(psum);
@@ -593,15 +595,17 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
         const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
         float psum = 0.f;
         bf16x8 pb[2];
+        unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
+        if (pdrop > 0.f) {
+            const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+        }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             float p = (m_new == -INFINITY) ? 0.f : __expf(sc[g] - m_new);
             psum += p;
-            if (pdrop > 0.f) {
-                const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                p = drop_keep1(idx, dkey, thr) ? p * keep_scale : 0.f;
-            }
+            if (pdrop > 0.f) p = ((km[g >> 2] >> (g & 3)) & 1u) ? p * keep_scale : 0.f;
             pb[g >> 3][g & 7] = (bf16_t)p;
         }
         psum += other_half(psum);
@@ -835,6 +839,12 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
             float ds[16], pdv[16], bdv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
+            unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
+            if (pdrop > 0.f) {
+                const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -843,10 +853,7 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                 const bool masked = (j >= len) || (causal && j > causal_limit(iq, causal));
                 const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
                 float keep = 1.f;
-                if (pdrop > 0.f) {
-                    const unsigned long long idx = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + j;
-                    keep = drop_keep1(idx, dkey, thr) ? keep_scale : 0.f;
-                }
+                if (pdrop > 0.f) keep = ((km[g >> 2] >> (g & 3)) & 1u) ? keep_scale : 0.f;
                 pdv[g] = q_ok ? p * keep : 0.f;
                 ds[g] = q_ok ? p * (dpd[g] * keep - delta) * scale : 0.f;
             }
