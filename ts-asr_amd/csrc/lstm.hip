@@ -336,6 +336,10 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
                                                               const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][BR][128]*/,
                                                               unsigned *sync, int B, int U) {
     constexpr int K4 = 4 * H, KSW = K4 / 16 / 4, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 128;   // KSW k-steps per wave
+    constexpr int XLD = 136;                                               // staged row: 128 bf16 + 8 pad (16-byte slots rotate per row)
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];         // 96 KB (also what keeps one workgroup per CU)
+    bf16_t *xl = reinterpret_cast<bf16_t *>(dyn_lds);                      // dgates_{t+1}: [H/32 workgroups x BR rows][XLD]
+    static_assert((H / LQ_UN) * BR * XLD * 2 <= 96 * 1024, "staged exchange tile must fit the dynamic LDS");
     __shared__ float red[4][32][33];                                       // [wave][batch][unit]
     __shared__ __attribute__((aligned(16))) bf16_t dgt[BR][4 * LQ_UN];     // [batch][gate*32 + unit]: the published tile
     __shared__ int ok_flag;
@@ -358,6 +362,12 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 #pragma unroll
     for (int j = 0; j < PP; ++j) dcar[j] = 0.f;
     bool failed = false;
+#ifdef LQ_PROFILE
+    long long bacc_t[6] = {0, 0, 0, 0, 0, 0}, bt_prev = clock64();
+#define LQB_STAMP(i) do { const long long n_ = clock64(); bacc_t[i] += n_ - bt_prev; bt_prev = n_; } while (0)
+#else
+#define LQB_STAMP(i)
+#endif
 #pragma unroll 1
     for (int t = U - 1; t >= 0; --t) {
         float gv[PP][4], cn[PP], cpv[PP], dov[PP];
@@ -377,19 +387,33 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * (U - 1 - t)), err) ? 1 : 0;
             __syncthreads();
             if (!ok_flag) { failed = true; break; }
-            u32x4 raw[KSW];
+            LQB_STAMP(0);   // input loads issued + wait for dgates_{t+1}
+            // dgates_{t+1} [BR x 4H] enters the workgroup ONCE, as coalesced 16-byte loads of distinct addresses, and feeds the waves'
+            // B fragments from LDS. (First version: every lane fetched its own fragment - 32 loads per lane whose addresses repeat
+            // across lanes and across the 16 workgroups: 128 KB per workgroup and step out of the same 64 KB of L2, 8.8k of the
+            // step's 12.6k cycles; the forward kernel has staged h_{t-1} this way since round 1: 3.1k.)
+            constexpr int NCH = NWG * BR * 16, NLD = (NCH + 255) / 256;       // 16-byte chunks of one published step
+            u32x4 raw[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((t + 1) * NWG * TILE + min(tid + 256 * i, NCH - 1) * 8) * 2, 0, 16);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int ch = tid + 256 * i;                                   // chunk = ((workgroup, batch row), 16-byte piece)
+                if (ch < NCH) *reinterpret_cast<u32x4 *>(&xl[(ch >> 4) * XLD + (ch & 15) * 8]) = raw[i];
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < KSW; ++i) {
                 const int cp = 16 * (KSW * wave + i) + 8 * hh;
-                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((t + 1) * NWG + (cp >> 7)) * BR + nr) * 128 + (cp & 127)) * 2, 0, 16);
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&xl[((cp >> 7) * BR + nr) * XLD + (cp & 127)]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfrag, acc, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
         }
+        LQB_STAMP(1);   // exchange loads + MFMA (issue)
 #pragma unroll
         for (int g = 0; g < 16; ++g) red[wave][r][(g & 3) + 8 * (g >> 2) + 4 * hh] = acc[g];
         __syncthreads();
+        LQB_STAMP(2);   // accumulators to LDS (waits for the MFMAs and their operands) + barrier
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const int p = tid + 256 * j, bl = p >> 5, ul = p & 31;
@@ -406,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             dcar[j] = dc * gf;
         }
         __syncthreads();
+        LQB_STAMP(3);   // cell backward (waits for this step's gates / c / dout) + barrier
         constexpr int NST = (BR * 16 + 255) / 256;
         u32x4 dv16[NST];
 #pragma unroll
@@ -419,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only the exchange tile (and this step's input loads) are in flight here
         __syncthreads();
+        LQB_STAMP(4);   // publish + drain
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the gate gradients for the input-side GEMMs: nobody in this kernel reads them, so they go out after the arrival
 #pragma unroll
@@ -428,6 +454,9 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
                 *reinterpret_cast<u32x4 *>(dgates + ((long long)(b0 + bl) * U + t) * K4 + (part >> 2) * H + u0 + (part & 3) * 8) = dv16[k];
         }
     }
+#ifdef LQ_PROFILE
+    if (tid == 0 && wg == 3 && bg == 0) for (int i = 0; i < 5; ++i) reinterpret_cast<long long *>(sync + 32)[i] = bacc_t[i];
+#endif
     if (failed && tid == 0) dgates[((long long)min(b0, B - 1) * U) * K4 + u0] = (bf16_t)__builtin_nanf("");
 }
 
