@@ -87,6 +87,13 @@ class ConformerEncoder(nn.Module):
                 nn.init.xavier_normal_(p)
 
     def forward(self, src, wav_len=None, speaker_embs=None, speaker_embs_length=None, return_attn=False):
+        state = self.forward_pre(src, wav_len, speaker_embs, speaker_embs_length, return_attn)
+        return self.forward_post(state, speaker_embs, speaker_embs_length)
+
+    def forward_pre(self, src, wav_len=None, speaker_embs=None, speaker_embs_length=None, return_attn=False):
+        """The part of forward() that does not need the speaker embedding: everything up to (not including) the first injection -
+        the recipe runs it beside the speaker branch. Returns the state forward_post() continues from (``state["x"]`` may be replaced
+        by a detached leaf: the captured step cuts the autograd graph there)."""
         C.require_gpu(src)
         if src.ndim == 4:
             b, t, c1, c2 = src.shape
@@ -94,13 +101,34 @@ class ConformerEncoder(nn.Module):
         T = src.shape[1]
         valid = abs_lengths_round(wav_len, T) if wav_len is not None else None
         x = self.custom_src_module(_cd(src))
+        state = {"valid": valid, "attns": [], "return_attn": return_attn, "next": 0, "pre": None, "inject_first": False}
         if -1 in self.injection_after and speaker_embs is not None:
+            state.update(x=x, pos=None, inject_first=True)
+            return state
+        pos = self.positional_encoding(x)
+        state.update(x=x, pos=pos)
+        return self._run_layers(state, speaker_embs, speaker_embs_length, stop_at_injection=True)
+
+    def forward_post(self, state, speaker_embs=None, speaker_embs_length=None):
+        if state["inject_first"]:
+            speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
+            state["x"] = self._inject_speaker_emb(state["x"], speaker_embs, speaker_embs_length)
+            state["pos"] = self.positional_encoding(state["x"])
+            state["inject_first"] = False
+        state = self._run_layers(state, speaker_embs, speaker_embs_length, stop_at_injection=False)
+        x = self.norm(state["x"]) if state["pre"] is None else state["pre"]
+        return (x, state["attns"]) if state["return_attn"] else x
+
+    def _run_layers(self, state, speaker_embs, speaker_embs_length, stop_at_injection):
+        x, pos, valid, pre, n = state["x"], state["pos"], state["valid"], state["pre"], len(self.layers)
+        return_attn = state["return_attn"]
+        i = state["next"]
+        if state.get("pending_injection"):   # forward_pre stopped right in front of this injection
             speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
             x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
-        pos = self.positional_encoding(x)
-        attns = []
-        pre, n = None, len(self.layers)
-        for i, layer in enumerate(self.layers):
+            state["pending_injection"] = False
+        while i < n:
+            layer = self.layers[i]
             inject = i in self.injection_after and speaker_embs is not None
             # a layer's norm2 is followed by another LayerNorm of the same rows - the next layer's first macaron LayerNorm, or the final
             # norm (models/conformer.py:223-233) - unless the speaker embedding is injected in between: one launch for the pair
@@ -108,14 +136,18 @@ class ConformerEncoder(nn.Module):
             x, attn, pre = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre, next_ln=nxt) if nxt is not None \
                 else layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre) + (None,)
             if return_attn:
-                attns.append(attn.detach())
+                state["attns"].append(attn.detach())
+            i += 1
             if inject:
+                if stop_at_injection:
+                    state.update(x=x, pre=pre, next=i, pending_injection=True)
+                    return state
                 # a callable = "not needed before this point": the recipe computes the speaker branch on a second HIP stream and
                 # joins it here, so it overlaps the mixture's front-end and the layers before the injection
                 speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
                 x = self._inject_speaker_emb(x, speaker_embs, speaker_embs_length)
-        x = self.norm(x) if pre is None else pre
-        return (x, attns) if return_attn else x
+        state.update(x=x, pre=pre, next=i)
+        return state
 
     def _inject_speaker_emb(self, src, spk, spk_len):
         spk = _cd(spk)
