@@ -20,6 +20,26 @@ def chain(x):
 
 xs = [torch.randn(4000, 256, device=dev).to(torch.bfloat16) for _ in range(2)]
 tiny = torch.zeros(64, device=dev)
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+hipEventDisableTiming, hipEventDisableSystemFence = 0x2, 0x20000000
+
+
+def raw_event(flags):
+    ev = ctypes.c_void_p()
+    assert hip.hipEventCreateWithFlags(ctypes.byref(ev), ctypes.c_uint(flags)) == 0
+    return ev
+
+
+def raw_record(ev, st):
+    assert hip.hipEventRecord(ev, ctypes.c_void_p(st.cuda_stream)) == 0
+
+
+def raw_wait(st, ev):
+    assert hip.hipStreamWaitEvent(ctypes.c_void_p(st.cuda_stream), ev, ctypes.c_uint(0)) == 0
+
+
+raw = {name: [raw_event(fl) for _ in range(3)] for name, fl in (("raw_fence", hipEventDisableTiming), ("raw_nofence", hipEventDisableTiming | hipEventDisableSystemFence))}
 for shared in (False, True):
     streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
     with torch.no_grad():
@@ -65,6 +85,24 @@ for shared in (False, True):
                 streams[0].wait_event(evs[1]); streams[0].wait_event(evs[2])
                 with torch.cuda.stream(streams[0]):
                     g0.replay()
+            elif mode == "late_record":    # both branches launched first, THEN the two event records and the join
+                for i in (0, 1):
+                    with torch.cuda.stream(streams[1 + i]):
+                        graphs[i].replay()
+                for i in (0, 1):
+                    evs[1 + i].record(streams[1 + i])
+                streams[0].wait_event(evs[1]); streams[0].wait_event(evs[2])
+                with torch.cuda.stream(streams[0]):
+                    g0.replay()
+            elif mode in raw:              # join only, events through the HIP API directly (with / without the system-scope fence)
+                e = raw[mode]
+                for i in (0, 1):
+                    with torch.cuda.stream(streams[1 + i]):
+                        graphs[i].replay()
+                    raw_record(e[1 + i], streams[1 + i])
+                raw_wait(streams[0], e[1]); raw_wait(streams[0], e[2])
+                with torch.cuda.stream(streams[0]):
+                    g0.replay()
             elif mode == "plain":
                 for i in (0, 1):
                     with torch.cuda.stream(streams[1 + i]):
@@ -76,4 +114,4 @@ for shared in (False, True):
         return (time.perf_counter() - t0) / reps * 1e3
 
     run("plain"); run("events")
-    print(f"shared pool={shared}: one chain {run('one'):.3f} ms; two graphs plain {run('plain'):.3f} ms; with start graph + events {run('events'):.3f} ms; fork only {run('fork_only'):.3f}; join only {run('join_only'):.3f}")
+    print(f"shared pool={shared}: one chain {run('one'):.3f} ms; two graphs plain {run('plain'):.3f} ms; with start graph + events {run('events'):.3f} ms; fork only {run('fork_only'):.3f}; join only {run('join_only'):.3f}; late record {run('late_record'):.3f}; raw events {run('raw_fence'):.3f}; raw events without system fence {run('raw_nofence'):.3f}")
