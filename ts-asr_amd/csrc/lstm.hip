@@ -216,24 +216,30 @@ template <int H, int BR>
 __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict__ gates, float *__restrict__ c, bf16_t *__restrict__ h,
                                                               const bf16_t *__restrict__ whh /*[4H,H]*/, bf16_t *xh /*[G][U][H/32][BR][32]*/,
                                                               unsigned *sync, int B, int U) {
-    constexpr int KS = H / 16, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 32;
+    constexpr int NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 32;
     static_assert(PP >= 1 && (BR & (BR - 1)) == 0 && BR <= 32, "BR in {8, 16, 32}");
     __shared__ __attribute__((aligned(16))) float pre[BR][LQ_UN * 4 + 4];     // [batch][unit*4 + gate]
     __shared__ __attribute__((aligned(16))) bf16_t hs[BR][LQ_UN];              // this step's h tile, laid out as it is published
     __shared__ __attribute__((aligned(16))) bf16_t hl[(H / 32) * BR * 40];     // h_{t-1}: [unit block][batch row][32 + 8 pad]
     __shared__ int ok_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5, nr = r & (BR - 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
     bf16_t *xh_g = xh + (size_t)bg * U * H * BR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xh_g, 0, U * H * BR * 2, 0x00020000);
-    // A operand (W_hh rows): MFMA row r of this wave = gate (r & 3) of unit u0 + 8*wave + (r >> 2) -> the four gates of a unit
-    // land in four consecutive accumulator registers of ONE lane
-    bf16x8 af[KS];
-    {
-        const bf16_t *wrow = whh + ((long long)(r & 3) * H + u0 + 8 * wave + (r >> 2)) * H;
+    // A operand (W_hh rows): MFMA row m of row block rb = gate (m & 3) of unit u0 + 8*wave + 4*rb + (m >> 2) -> the four gates of a
+    // unit land in the four accumulator registers of ONE lane
+    // v_mfma_f32_16x16x32_bf16: the batch side of the product has at most 16 rows, so the 32-column form spent half of every MFMA and
+    // of every B-fragment read on repeated columns. Two row blocks of 16 (4 units x 4 gates each) share one B fragment per 32-wide k step.
+    static_assert(BR <= 16, "the 16-column MFMA form covers groups of at most 16 batch rows");
+    constexpr int KS2 = H / 32;
+    const int m16 = lane & 15, kg = lane >> 4;
+    bf16x8 af[2][KS2];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s + 8 * hh);
+    for (int rb = 0; rb < 2; ++rb) {
+        const bf16_t *wrow = whh + ((long long)(m16 & 3) * H + u0 + 8 * wave + 4 * rb + (m16 >> 2)) * H;
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) af[rb][s] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * s + 8 * kg);
     }
     float cprev[PP];
 #pragma unroll
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
             const float4 g4 = *reinterpret_cast<const float4 *>(gates + (((long long)min(b0 + bl, B - 1) * U + t) * H + u0 + ul) * 4);
             gx[j][0] = g4.x; gx[j][1] = g4.y; gx[j][2] = g4.z; gx[j][3] = g4.w;
         }
-        f32x16 acc = {0};
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (t > 0) {
             if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * t), err) ? 1 : 0;
             __syncthreads();
@@ -273,16 +279,17 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
             }
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&hl[((s >> 1) * BR + nr) * 40 + (s & 1) * 16 + 8 * hh]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfrag, acc, 0, 0, 0);
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&hl[(s * BR + (m16 & (BR - 1))) * 40 + 8 * kg]);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][s], bfrag, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][s], bfrag, acc[1], 0, 0, 0);
             }
         }
         LQ_STAMP(1);   // operand loads + MFMA
-        if (r < BR) {
+        if (m16 < BR) {   // accumulator: column = batch row m16, rows 4*kg .. +3 of block rb = the four gates of unit 8*wave + 4*rb + kg
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4 *>(&pre[r][(8 * wave + 2 * q + hh) * 4]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            for (int rb = 0; rb < 2; ++rb)
+                *reinterpret_cast<float4 *>(&pre[m16][(8 * wave + 4 * rb + kg) * 4]) = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
         }
         __syncthreads();
         float4 gact[PP];
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
                                                               const bf16_t *__restrict__ dout, bf16_t *__restrict__ dgates,
                                                               const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][BR][128]*/,
                                                               unsigned *sync, int B, int U) {
-    constexpr int K4 = 4 * H, KSW = K4 / 16 / 4, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 128;   // KSW k-steps per wave
+    constexpr int K4 = 4 * H, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 128;
     constexpr int XLD = 136;                                               // staged row: 128 bf16 + 8 pad (16-byte slots rotate per row)
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];         // 96 KB (also what keeps one workgroup per CU)
     bf16_t *xl = reinterpret_cast<bf16_t *>(dyn_lds);                      // dgates_{t+1}: [H/32 workgroups x BR rows][XLD]
@@ -343,19 +350,23 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
     __shared__ float red[4][32][33];                                       // [wave][batch][unit]
     __shared__ __attribute__((aligned(16))) bf16_t dgt[BR][4 * LQ_UN];     // [batch][gate*32 + unit]: the published tile
     __shared__ int ok_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5, nr = r & (BR - 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
     bf16_t *xg_g = xg + (size_t)bg * U * K4 * BR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xg_g, 0, U * K4 * BR * 2, 0x00020000);
-    // A operand: row r = unit u0 + r of W_hh^T; the reduction index runs over the PUBLISHED order c' = wg'*128 + gate*32 + unit'
-    bf16x8 af[KSW];
-    {
-        const bf16_t *wrow = whhT + (long long)(u0 + r) * K4;
+    // A operand: row m of row block rb = unit u0 + 16*rb + m of W_hh^T; the reduction index runs over the PUBLISHED order c' = wg'*128 + gate*32 + unit'
+    static_assert(BR <= 16, "the 16-column MFMA form covers groups of at most 16 batch rows");
+    constexpr int KSW2 = K4 / 32 / 4;                    // 32-wide k steps per wave (v_mfma_f32_16x16x32_bf16, see the forward kernel)
+    const int m16 = lane & 15, kg = lane >> 4;
+    bf16x8 af[2][KSW2];
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) {
-            const int cp = 16 * (KSW * wave + i) + 8 * hh;
-            af[i] = *reinterpret_cast<const bf16x8 *>(wrow + ((cp & 127) >> 5) * H + (cp >> 7) * 32 + (cp & 31));
+    for (int rb = 0; rb < 2; ++rb) {
+        const bf16_t *wrow = whhT + (long long)(u0 + 16 * rb + m16) * K4;
+#pragma unroll
+        for (int i = 0; i < KSW2; ++i) {
+            const int cp = 32 * (KSW2 * wave + i) + 8 * kg;
+            af[rb][i] = *reinterpret_cast<const bf16x8 *>(wrow + ((cp & 127) >> 5) * H + (cp >> 7) * 32 + (cp & 31));
         }
     }
     float dcar[PP];
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             cpv[j] = t > 0 ? cpr : 0.f;
             dov[j] = (float)dout[((long long)b * U + t) * H + u0 + ul];
         }
-        f32x16 acc = {0};
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const bool last = (t == U - 1);
         if (!last) {
             if (tid == 0) ok_flag = lq_wait(ctr, (unsigned)(NWG * (U - 1 - t)), err) ? 1 : 0;
@@ -403,15 +414,18 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const int cp = 16 * (KSW * wave + i) + 8 * hh;
-                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&xl[((cp >> 7) * BR + nr) * XLD + (cp & 127)]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfrag, acc, 0, 0, 0);
+            for (int i = 0; i < KSW2; ++i) {
+                const int cp = 32 * (KSW2 * wave + i) + 8 * kg;
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(&xl[((cp >> 7) * BR + (m16 & (BR - 1))) * XLD + (cp & 127)]);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfrag, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfrag, acc[1], 0, 0, 0);
             }
         }
         LQB_STAMP(1);   // exchange loads + MFMA (issue)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) red[wave][r][(g & 3) + 8 * (g >> 2) + 4 * hh] = acc[g];
+        for (int rb = 0; rb < 2; ++rb)   // accumulator: column = batch row m16, rows = units 16*rb + 4*kg .. +3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave][m16][16 * rb + 4 * kg + j] = acc[rb][j];
         __syncthreads();
         LQB_STAMP(2);   // accumulators to LDS (waits for the MFMAs and their operands) + barrier
 #pragma unroll
