@@ -255,6 +255,13 @@ def main():
             fam[k] = e
         # dominant hand-written kernel = largest share of the step among the instrumented launches
         dom = max(fam, key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)
+        latency_bound = None
+        if dom is not None and "TFLOPps" not in fam[dom] and dom not in ab:
+            # (long-form, B = 1: the largest launch is a chain of dependent steps - persistent LSTM / RNN-T lattice - priced by steps, not by
+            # flops or bytes: the roofline object then describes the largest kernel that has a flop or byte model, and says so)
+            latency_bound = dom
+            cands = [k for k in fam if "TFLOPps" in fam[k] or k in ab]
+            dom = max(cands, key=lambda k: fam[k]["avg_ms"] * fam[k]["launches"], default=None)
         roof = None
         if dom is not None and "TFLOPps" in fam[dom]:
             roof = {"kernel": dom, "bound": "mfma", "achieved": fam[dom]["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -268,6 +275,8 @@ def main():
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": fam[dom]["avg_ms"]}
         if roof is not None:   # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py), newest round
             roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"])
+            if latency_bound is not None:
+                roof["largest_launch_without_flop_or_byte_model"] = {"kernel": latency_bound, **fam[latency_bound]}
         rnnt_ms = sum(fam[k]["avg_ms"] for k in ("joint_fwd", "rnnt_loss_fwd", "rnnt_loss_bwd", "joint_bwd") if k in fam)
         out = {
             "metric": f"utterance-frames/sec (conformer-t_scratch training step, T={T_MEL}, B={B_LOCAL}/GPU)" if args.config != "pretrained"
