@@ -150,6 +150,8 @@ class GraphSegments:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
         if os.environ.get("TSASR_SEG_ONE_STREAM", "0") != "0":      # A/B: every segment on one stream (no overlap at all)
             self.streams = [self.streams[0]] * n_streams
+        if os.environ.get("TSASR_SEG_STREAMS"):                       # A/B: e.g. "0,1,1,0" folds the four logical streams onto two
+            self.streams = [self.streams[int(k)] for k in os.environ["TSASR_SEG_STREAMS"].split(",")]
         self.items, self._cur, self._events = [], None, None
 
     def begin(self, name, stream, deps=()):
