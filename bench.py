@@ -116,6 +116,57 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher (the reference starts its ranks with `python -m torch.distributed.launch
+    --nproc_per_node=N`, README.md:38-51): spawn one rank per GPU through torch.distributed.run as a CHILD process and return its exit
+    code. Nothing in this (parent) process has touched the GPU - torch.cuda.device_count() does not initialise it - and nothing is
+    re-exec'ed. With fewer visible GPUs than ranks the run is a REHEARSAL of the multi-rank code path: every rank on GPU 0, collectives
+    over gloo (RCCL refuses two ranks on one device); the JSON line then says so and is not a scaling number."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    have = torch.cuda.device_count()
+    if have < n and "TSASR_DIST_BACKEND" not in env:
+        env["TSASR_DIST_BACKEND"] = "gloo"
+        log(f"{have} GPU(s) visible for {n} ranks: REHEARSAL on one GPU over gloo (not a scaling measurement)")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("spawning: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def allreduce_probe(brain, torch, world, reps=5):
+    """Measured cost of ONE gradient all-reduce of the whole arena (204 MB fp32 at configs[1]) outside the step, on the path the step uses
+    (bare ncclAllReduce of the direct RCCL communicator when there is one, else torch.distributed): ms per call, HIP events."""
+    import torch.distributed as dist
+    a = brain.arena
+    buf = torch.empty_like(a.grads).normal_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    direct = bool(getattr(a, "direct", False))
+    capi = importlib.import_module(PKG + "._capi")
+    import ctypes
+
+    def once():
+        if direct:
+            capi.check(capi.lib().tsasr_allreduce_bucket(capi.ptr(buf), buf.numel(), capi.F32, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "tsasr_allreduce_bucket")
+        else:
+            dist.all_reduce(buf)
+    once()
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, direct, buf.numel() * 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,13 +183,14 @@ def main():
     global B_LOCAL, T_MEL, T_ENROLL, U
     B_LOCAL, T_MEL, T_ENROLL, U = wl["B"], wl["T"], wl["Te"], wl["U"]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))     # `python bench.py --gpus N`: this process becomes the launcher, BEFORE anything touches a GPU
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with --gpus N (or run `python bench.py --gpus N`, which spawns them)")
     if os.environ.get("TSASR_DIST_BACKEND") == "gloo":   # rehearsal: every rank on the one visible GPU
         local_rank = 0
     device = f"cuda:{local_rank}"
@@ -231,6 +283,14 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm_info = {}
+    if world > 1:
+        ar_ms, direct, nbytes = allreduce_probe(brain, torch, world)
+        dpm = importlib.import_module(PKG + ".dp")
+        comm_info = {"backend": torch.distributed.get_backend(), "rccl_direct_ranks": int(dpm._DIRECT["ranks"]), "collectives_in_graph": bool(brain._graph_comm()) if brain._graph is not None else False,
+                     "allreduce_ms_whole_arena": round(ar_ms, 3), "allreduce_bytes": nbytes,
+                     "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1),
+                     "rehearsal_on_one_gpu": os.environ.get("TSASR_DIST_BACKEND") == "gloo"}
     nonfinite = brain.flush_nonfinite()
     # per-launch durations: plain mean of the HIP-event brackets of every instrumented launch (no fastest-of-N, no subtraction of the
     # empty event-pair time: the figure errs on the slow side of rocprofv3's kernel durations, profiles/r02_kernel_trace.md)
@@ -295,6 +355,8 @@ def main():
             "hip_kernels": fam,
             "roofline": roof,
         }
+        if comm_info:
+            out["comm"] = comm_info
         if not args.no_cpu_baseline and world == 1 and args.config == "scratch":
             out["cpu_baseline"] = cpu_baseline(brain, torch)
         print(json.dumps(out))

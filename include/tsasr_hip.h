@@ -225,14 +225,14 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
  * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
  * p, g, m, v: flat fp32 [n]; p_bf16 (may be NULL): bf16 shadow of p rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
- * norm_out (may be NULL): DEVICE float[2]: [0] = L2 norm of g before clipping; [1] += 1 when that norm is not finite - the update is then SKIPPED
+ * norm_out (may be NULL): DEVICE float = L2 norm of g before clipping; skipped_out (may be NULL): DEVICE float, += 1 when that norm is not finite - the update is then SKIPPED
  * (parameters and moments untouched; the reference's clip_grad_norm_ would write NaN into every weight, SB/core.py:1082-1093).
  * ------------------------------------------------------------------------------------------ */
 /* dst[i] += src[i] for `count` small fp32 vectors in one launch; table (DEVICE) = [count src ptrs][count dst ptrs][count int32 lengths]. */
 int tsasr_accumulate_many(const void *table, int count, void *stream);
 size_t tsasr_clip_adamw_workspace_bytes(void);
-int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
-                          float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
+int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, float *skipped_out,
+                          long long n, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -368,6 +368,8 @@ int tsasr_greedy_decode(const void *enc, const float *emb, const void *w_ih, con
 /* TEST AID (tests / tools only): overwrite the whole LDS of every CU with a 32-bit pattern, so that a kernel reading LDS it never wrote
  * sees the pattern instead of whatever the previous kernel left there. */
 int tsasr_debug_fill_lds(unsigned pattern, void *stream);
+/* TEST AID: nwords 32-bit words at p <- pattern (poisoning the captured step's free pool memory between replays). */
+int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream);
 int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);
 
 /* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module
@@ -392,6 +394,8 @@ int tsasr_allreduce_destroy(void);
  * node. Replaces ~310 small launches per step. */
 int tsasr_reduce_defer(int on);
 int tsasr_reduce_pending(void);
+/* Drops every queued reduction without running it and switches deferral off (error path of a step that raised half-way). */
+void tsasr_reduce_discard(void);
 size_t tsasr_reduce_table_bytes(int max_jobs);
 int tsasr_reduce_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 /* Only the jobs whose partial rows were produced on `stream` (complete in its order): the main stream reduces its share while a

@@ -404,6 +404,34 @@ def test_fused_clip_adamw_vs_torch():
     np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6, rtol=1e-5)
 
 
+def test_fused_clip_adamw_skips_a_nonfinite_gradient():
+    """A NaN / Inf in the gradient makes the global norm non-finite: the kernel leaves p, m, v (and the bf16 shadow) untouched and counts
+    the skipped step in its own device float; a finite gradient afterwards updates normally and leaves the counter alone.
+    (Deviation from the reference, stated in DESIGN.md: SB/core.py:1082-1093 would let clip_grad_norm_ write NaN into every weight.)"""
+    opt_mod = importlib.import_module("ts-asr_amd.optim")
+    n = 4099
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(n, generator=g)
+    pd, m, v = p0.to(DEV), torch.full((n,), 0.25, device=DEV), torch.full((n,), 0.5, device=DEV)
+    p16 = pd.to(torch.bfloat16)
+    norm, skipped = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    guard = torch.full((64,), 7.0, device=DEV)      # a 1-float norm buffer must not be written past its end (round-2 advisor finding)
+    norm1 = guard[31:32]
+    for bad in (float("nan"), float("inf")):
+        gr = torch.randn(n, generator=g)
+        gr[17] = bad
+        opt_mod._clip_adamw(pd, gr.to(DEV), m, v, norm1, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0, p16=p16, skipped_out=skipped)
+        assert torch.equal(pd.cpu(), p0) and float(m.min()) == 0.25 == float(m.max()) and float(v.min()) == 0.5 == float(v.max())
+        assert torch.equal(p16.cpu(), p0.to(torch.bfloat16))
+        assert not np.isfinite(float(norm1))
+    assert float(skipped) == 2.0
+    assert torch.equal(torch.cat([guard[:31], guard[32:]]), torch.full((63,), 7.0, device=DEV))
+    opt_mod._clip_adamw(pd, torch.randn(n, generator=g).to(DEV), m, v, norm, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0, p16=p16, skipped_out=skipped)
+    assert float(skipped) == 2.0 and np.isfinite(float(norm)) and not torch.equal(pd.cpu(), p0)
+    opt_mod._clip_adamw(pd, torch.full((n,), float("nan"), device=DEV), m, v, None, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0)   # both outputs optional
+    assert bool(torch.isfinite(pd).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(8000, 2048, 256), (8000, 256, 2048), (250, 144, 144), (1000, 640, 256), (129, 72, 200), (2048, 256, 8000),
                                    (4000, 256, 2048), (1000, 200, 1024)])   # the last two: 64x64 tiles at long K (wave-K main loops), ragged M / N
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])

@@ -89,17 +89,3 @@ def test_captured_step_is_bitwise_reproducible_across_processes():
     assert len(a) == 10 and a == b, "\n".join(x + "   |   " + y for x, y in zip(a, b) if x != y)
     g = [l.split()[-1] for l in a if l.startswith("g")]
     assert len(set(g)) >= 2       # different dropout masks per replay: the gradients do change from step to step
-
-
-def test_segmented_graph_step_equals_eager():
-    """The experimental form of the captured step (TSASR_GRAPH_SEGMENTS=1: ten hipGraphs on four streams with events between them, the
-    autograd graph cut at the joins - core.GraphSegments, recipes/tsasr.py::_device_step_segmented; off by default because it is slower,
-    profiles/r02_notes.md section 11) must compute what the single graph computes: the graph == eager tests of test_model_gpu.py run in
-    a child process with the switch on (the switch is read at import)."""
-    import subprocess
-    env = dict(os.environ, TSASR_GRAPH_SEGMENTS="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_model_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "replay_equals_eager"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    sys.stdout.write(r.stdout[-1500:])
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "deselected" in r.stdout

@@ -73,7 +73,7 @@ _PROTOS = {
     "tsasr_relpos_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "tsasr_accumulate_many": (c_int, [c_void_p, c_int, c_void_p]),
     "tsasr_clip_adamw_workspace_bytes": (c_size_t, []),
-    "tsasr_clip_adamw_step": (c_int, [c_void_p] * 7 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_clip_adamw_step": (c_int, [c_void_p] * 8 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_gemm_set_plan": (None, [c_int, c_int]),
     "tsasr_gemm_set_ring": (None, [c_int]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
@@ -100,6 +100,7 @@ _PROTOS = {
     "tsasr_transpose_many_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "tsasr_reduce_defer": (c_int, [c_int]),
     "tsasr_reduce_pending": (c_int, []),
+    "tsasr_reduce_discard": (None, []),
     "tsasr_reduce_table_bytes": (c_size_t, [c_int]),
     "tsasr_reduce_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_reduce_flush_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -108,6 +109,7 @@ _PROTOS = {
     "tsasr_abs_lengths": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "tsasr_greedy_decode": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_float, c_int, c_int, c_void_p]),
     "tsasr_debug_fill_lds": (c_int, [ctypes.c_uint, c_void_p]),
+    "tsasr_debug_fill": (c_int, [c_void_p, ctypes.c_uint, c_size_t, c_void_p]),
     "tsasr_count_nonfinite": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),
     "tsasr_allreduce_unique_id": (c_int, [c_void_p]),

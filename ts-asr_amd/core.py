@@ -29,12 +29,6 @@ logger = logging.getLogger(__name__)
 
 
 _EARLY_FLUSH = os.environ.get("TSASR_EARLY_FLUSH", "0") != "0"   # A/B knob (measured neutral on the step: off by default)
-# EXPERIMENT, off: the step as several graphs on several streams (GraphSegments). Two independent graphs on two streams do overlap their
-# short kernels (tools/two_graph_overlap.py: 0.57 ms for two 0.48 ms chains; the same chains forked inside ONE graph: 1.10 ms), but the
-# step's branches have to be joined, and with host-issued events between the graph launches ROCm 7.2 starts a later-launched graph only
-# when the earlier one has finished (profiles/r02_notes.md section 11): 14.3 ms against 12.85 for the single graph. External
-# (graph-node) events are refused by PyTorch on ROCm.
-_GRAPH_SEGMENTS = os.environ.get("TSASR_GRAPH_SEGMENTS", "0") != "0"
 _GRAPH_COMM = os.environ.get("TSASR_GRAPH_COMM", "1") != "0"     # multi-rank graph mode: bucketed all-reduces captured inside the step's graph
 
 class Stage(enum.Enum):
@@ -132,66 +126,6 @@ def parse_arguments(arg_list=None):
     if local_rank is not None and "cuda" in run_opts.get("device", "cuda"):
         run_opts["device"] = f"cuda:{local_rank}"
     return param_file, run_opts, overrides
-
-
-class GraphSegments:
-    """A training step captured as SEVERAL hipGraphs, each on a stream of its own, replayed with event dependencies between them.
-    Why: inside ONE captured graph ROCm 7.2 runs the short kernels of forked branches one after the other (two chains of 120 kernels at
-    M = 8000 / 4000 rows: 0.68 + 0.48 ms alone, 0.88 ms as forked branches of one graph, 0.77 ms as two graphs on two streams; two
-    M = 4000 chains: 1.10 ms forked in one graph - slower than back to back - 0.57 ms as two graphs: tools/two_graph_overlap.py), and
-    a third of this step is branches that do not depend on each other (speaker encoder / predictor / the mixture's front-end and
-    layers in front of the injection, forward and backward). All graphs share one memory pool; the caching allocator hands a freed
-    block only to the stream it was allocated on, and same-stream segments replay in capture order, so a block is never reused under
-    a segment that may still be running - provided every cross-stream reader is a dependency of the owner stream's next segment
-    (the recipe's plan guarantees that: recipes/tsasr.py)."""
-
-    def __init__(self, pool, device, n_streams=4):
-        self.pool, self.device = pool, device
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
-        if os.environ.get("TSASR_SEG_ONE_STREAM", "0") != "0":      # A/B: every segment on one stream (no overlap at all)
-            self.streams = [self.streams[0]] * n_streams
-        if os.environ.get("TSASR_SEG_STREAMS"):                       # A/B: e.g. "0,1,1,0" folds the four logical streams onto two
-            self.streams = [self.streams[int(k)] for k in os.environ["TSASR_SEG_STREAMS"].split(",")]
-        self.items, self._cur, self._events = [], None, None
-
-    def begin(self, name, stream, deps=()):
-        """End the segment being captured (if any) and start capturing the next one on ``stream``; returns its index for ``deps``."""
-        self.end()
-        g = torch.cuda.CUDAGraph()
-        ctx = torch.cuda.graph(g, pool=self.pool, stream=stream)
-        ctx.__enter__()
-        self._cur = (name, g, stream, tuple(deps), ctx)
-        return len(self.items)
-
-    def end(self):
-        if self._cur is not None:
-            name, g, stream, deps, ctx = self._cur
-            self._cur = None
-            ctx.__exit__(None, None, None)
-            if self.pool is None:
-                self.pool = g.pool()
-            self.items.append((name, g, stream, deps))
-
-    def abort(self, exc_type=None, exc=None, tb=None):
-        if self._cur is not None:
-            ctx = self._cur[4]
-            self._cur = None
-            ctx.__exit__(exc_type, exc, tb)
-
-    def replay(self):
-        if self._events is None:
-            self._events = [torch.cuda.Event() for _ in self.items]
-        cur = torch.cuda.current_stream()
-        for k, (name, g, stream, deps) in enumerate(self.items):
-            if not deps:
-                stream.wait_stream(cur)          # the static batch was filled on the caller's stream
-            for d in deps:
-                if self.items[d][2] is not stream:
-                    stream.wait_event(self._events[d])
-            with torch.cuda.stream(stream):
-                g.replay()
-                self._events[k].record(stream)
-        cur.wait_event(self._events[-1])
 
 
 class Brain:
@@ -421,35 +355,29 @@ class Brain:
         else:
             self._copy_batch(batch, key)
         torch.cuda.synchronize()
-        if _GRAPH_SEGMENTS and not self.distributed and getattr(self, "segmentable", lambda: False)():
-            # the step as several graphs on several streams (GraphSegments): branches that do not depend on each other really overlap
-            seg = GraphSegments(self._graph_pool, self.device)
-            saved = (self.arena.aux_streams, self._aux_streams)
-            self.arena.aux_streams, self._aux_streams = [], []    # no joins of the eager step's forked streams inside these captures
-            try:
-                loss = self._device_step_segmented(self._static_batches[key], should_step, seg)
-                seg.end()
-            except BaseException as e:   # noqa: BLE001
-                seg.abort(type(e), e, e.__traceback__)
-                raise
-            finally:
-                self.arena.aux_streams, self._aux_streams = saved
-            from . import ops as _ops
-            _ops.upload_captured_tables()
-            self.arena.upload_captured_tables()
-            if self._graph_pool is None:
-                self._graph_pool = seg.pool
-            flavour = ("step" if should_step else "accumulate", key)
-            self._graphs[flavour], self._static_loss[flavour] = seg, loss
-            self._graph = seg
-            return
         g = torch.cuda.CUDAGraph()
+        if os.environ.get("TSASR_GRAPH_DOT"):
+            g.enable_debug_mode()
         # multi-rank: the RCCL watchdog thread polls events while this thread captures; "thread_local" keeps its (legal) calls from
         # invalidating the capture (single rank keeps the strict default)
         mode = "thread_local" if self.distributed else "global"
-        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=mode):
-            loss, _ = self._device_step(self._static_batches[key], should_step, comm=self._graph_comm())
+        pool = None if os.environ.get("TSASR_GRAPH_POOL", "shared") == "private" else self._graph_pool
         from . import ops as _ops
+        # job-table pairs for this graph's batched launches (one per captured flush: per bucket with collectives in the graph, plus the
+        # early / duplicate-weight / final flushes), allocated NOW - pinned memory cannot be allocated inside a capture
+        n_tables = len(self.arena.buckets) + 6
+        _ops.reserve_captured_tables(n_tables)
+        self.arena.reserve_captured_tables(n_tables)
+        try:
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                loss, _ = self._device_step(self._static_batches[key], should_step, comm=self._graph_comm())
+        except BaseException:
+            # a capture that raised half-way: drop the queued launches and their operand references, leave the arena out of "backward"
+            _ops.discard_queues()
+            self.arena.abort_backward()
+            raise
+        if os.environ.get("TSASR_GRAPH_DOT"):
+            g.debug_dump(os.environ["TSASR_GRAPH_DOT"] + f".{len(self._graphs)}.dot")
         _ops.upload_captured_tables()             # job tables of the captured flushes: uploaded once, now (replays carry no memcpy node)
         self.arena.upload_captured_tables()
         if self._graph_pool is None:

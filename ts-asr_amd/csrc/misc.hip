@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, int wor
     if (sink && fill_lds[(threadIdx.x * 97) % words] != pattern) *sink = 1;   // keeps the stores alive
 }
 
+__global__ void fill_words_kernel(unsigned *p, unsigned pattern, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pattern;
+}
+
 extern "C" {
 
 /* TEST AID: fill the LDS of every CU with a 32-bit pattern (160 KB workgroups, enough of them that every CU runs at least one). */
@@ -64,6 +68,17 @@ int tsasr_debug_fill_lds(unsigned pattern, void *stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     fill_lds_kernel<<<4 * cus, 256, bytes, (hipStream_t)stream>>>(pattern, bytes / 4, nullptr);
     TSASR_CHECK_LAUNCH("tsasr_debug_fill_lds");
+    return 0;
+}
+
+/* TEST AID: fill `nwords` 32-bit words of device memory with a pattern (tools/det_stress.py --poison: NaN into every inactive block of the
+ * captured step's memory pool between replays - a kernel that reads a buffer before its producer of THIS replay wrote it then shows up as
+ * NaN instead of as the previous replay's nearly identical values). */
+int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream) {
+    TSASR_CHECK_ARG(p && ((uintptr_t)p & 3) == 0, "tsasr_debug_fill: null or misaligned pointer");
+    if (nwords == 0) return 0;
+    fill_words_kernel<<<(unsigned)std::min<size_t>(4096, (nwords + 255) / 256), 256, 0, (hipStream_t)stream>>>((unsigned *)p, pattern, nwords);
+    TSASR_CHECK_LAUNCH("tsasr_debug_fill");
     return 0;
 }
 

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float *__rest
 // hyper = {lr, 1 - beta1^t, 1 - beta2^t}
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, bf16_t *__restrict__ p16, const float *__restrict__ g,
                                                          float *__restrict__ m, float *__restrict__ v, const float *__restrict__ part,
-                                                         const float *__restrict__ hyper, float *__restrict__ norm_out, long long n,
-                                                         float beta1, float beta2, float eps, float wd, float max_norm) {
+                                                         const float *__restrict__ hyper, float *__restrict__ norm_out, float *__restrict__ skipped_out,
+                                                         long long n, float beta1, float beta2, float eps, float wd, float max_norm) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < OPT_PARTS; i += 256) s += part[i];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
     // The step is skipped instead (parameters, moments untouched); the host counts it through norm_out like a non-finite loss
     // (the reference only counts, SB/core.py:1115-1150, and clip_grad_norm_ then poisons the model one step before it raises).
     if (!(fabsf(norm) <= 3.0e38f)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[1] += 1.f;   // skipped steps since the host last cleared it
+        if (blockIdx.x == 0 && threadIdx.x == 0 && skipped_out) *skipped_out += 1.f;   // skipped steps since the host last cleared it
         return;
     }
     const float clip = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
@@ -159,9 +159,9 @@ int tsasr_accumulate_many(const void *table, int count, void *stream) {
 size_t tsasr_clip_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
 
 /* p, g, m, v: flat fp32 [n] (16-byte aligned); p_bf16: optional bf16 shadow of p (GEMM operand copy), rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}; norm_out: device float
- * (may be NULL, else TWO floats: [0] = total L2 norm of g before clipping, [1] += 1 when that norm is not finite - the update is then
- * skipped, parameters and moments untouched); max_norm <= 0 disables clipping. g is read, not modified. */
-int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, long long n,
+ * (may be NULL) = total L2 norm of g before clipping; skipped_out: device float (may be NULL), += 1 when that norm is not finite - the
+ * update is then skipped, parameters and moments untouched; max_norm <= 0 disables clipping. g is read, not modified. */
+int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, float *skipped_out, long long n,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
                           size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(p && g && m && v && hyper && workspace, "tsasr_clip_adamw_step: null pointer");
@@ -172,7 +172,7 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
     sumsq_partials_kernel<<<OPT_PARTS, 256, 0, st>>>(g, part, n);
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, (bf16_t *)p_bf16, g, m, v, part, hyper, norm_out, n, beta1, beta2, eps, weight_decay, max_norm);
+    clip_adamw_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, (bf16_t *)p_bf16, g, m, v, part, hyper, norm_out, skipped_out, n, beta1, beta2, eps, weight_decay, max_norm);
     TSASR_CHECK_LAUNCH("tsasr_clip_adamw_step");
     return 0;
 }

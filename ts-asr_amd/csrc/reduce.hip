@@ -193,6 +193,14 @@ int tsasr_reduce_defer(int on) {
 
 int tsasr_reduce_pending(void) { return (int)g_jobs.size(); }
 
+/* Drop every queued reduction without running it and switch deferral off (error paths: a step capture that raised half-way). */
+void tsasr_reduce_discard(void) {
+    g_jobs.clear();
+    g_job_streams.clear();
+    g_tiles = 0;
+    g_defer = 0;
+}
+
 size_t tsasr_reduce_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof(ReduceJob); }
 
 /* Runs every queued reduction in ONE launch. table_host: PINNED host memory, table_dev: device memory, both `table_bytes` >=

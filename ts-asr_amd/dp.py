@@ -84,7 +84,16 @@ def direct_capture_probe(device, world, rank, group=None):
     collectives (one all-reduce between replay and optimizer: round 1's form). The verdict is agreed over the process group (MIN)."""
     import sys
     from . import _capi as C
-    ok = 1
+
+    def agree(flag_value):
+        """MIN over the ranks: every rank takes the same branch next (a rank that replays a collective alone would wait for ever)."""
+        if is_initialized() and world > 1:
+            flag = torch.tensor([int(flag_value)], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item())
+        return int(flag_value)
+
+    ok, g, buf = 1, None, None
     try:
         buf = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=device)
         comm = torch.cuda.Stream(device=device)
@@ -95,20 +104,23 @@ def direct_capture_probe(device, world, rank, group=None):
             comm.wait_stream(cur)
             C.check(C.lib().tsasr_allreduce_bucket(C.ptr(buf), buf.numel(), C.F32, 1, ctypes.c_void_p(comm.cuda_stream)), "tsasr_allreduce_bucket")
             cur.wait_stream(comm)
+    except Exception as e:   # noqa: BLE001 - any failure means "do not capture collectives"
+        print(f"[ts-asr_amd] rank {rank}: capturing an RCCL all-reduce failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        ok = 0
+    # first agreement: did EVERY rank capture? Only then is the collective replayed (a replay on some ranks only never returns)
+    if not agree(ok):
+        return False
+    try:
         g.replay()
         torch.cuda.synchronize()
         n = _DIRECT["ranks"] or world    # ranks of the direct communicator (the one-rank GPU test tells the arena there are two)
         ok = int(bool(torch.allclose(buf, torch.full_like(buf, (n + 1) / 2.0), rtol=1e-6)))
         if not ok:
             print(f"[ts-asr_amd] rank {rank}: captured all-reduce replayed a wrong average ({float(buf[0])})", file=sys.stderr, flush=True)
-    except Exception as e:   # noqa: BLE001 - any failure means "do not capture collectives"
-        print(f"[ts-asr_amd] rank {rank}: capturing an RCCL all-reduce failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+    except Exception as e:   # noqa: BLE001
+        print(f"[ts-asr_amd] rank {rank}: replaying a captured RCCL all-reduce failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
         ok = 0
-    if is_initialized() and world > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ok = int(flag.item())
-    return bool(ok)
+    return bool(agree(ok))      # second agreement: the replayed value was right everywhere
 
 
 class GradArena:
@@ -147,7 +159,7 @@ class GradArena:
         # parameters instead sent layer 0's bucket one contribution early and the late one landed on top of the averaged gradient -
         # ranks drifted apart (tools/dp_gloo_gpu_check.py)
         self._contrib, self._contrib_step = {}, {}
-        self._handles, self.sent_log = [], []
+        self._handles, self.sent_log, self._next_send = [], [], 0
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_ring = [], None, None
@@ -290,6 +302,15 @@ class GradArena:
         if self._defer_ring is not None:
             self._defer_ring.upload_captured()
 
+    def reserve_captured_tables(self, n):
+        if self._defer_ring is not None:
+            self._defer_ring.reserve_captured(n)
+
+    def abort_backward(self):
+        """Error path (a step capture that raised): forget everything queued for this backward pass."""
+        self._deferred, self._wgrad_hold, self._wgrad_side_busy, self._handles = [], [], False, []
+        self.in_backward = False
+
     # ---- grouped weight gradients (csrc/wgrad.hip) -------------------------------------------------------
     def wgrad_queued(self, p):
         """ops._wgrad_into queued p's weight gradient. On a step that overlaps the all-reduce with backward, a bucket whose other
@@ -350,7 +371,18 @@ class GradArena:
             for b in self.buckets:
                 if b.get("queued", 0) and b["left"] == 0:
                     b["queued"] = 0
-                    self._send(b)
+                    self._ready(b)
+
+    def _ready(self, b):
+        """Bucket b is complete. Collectives are issued STRICTLY IN BUCKET-INDEX ORDER (as torch DDP's reducer does): a complete bucket
+        waits until every lower-index bucket has been sent. Ranks may complete buckets in different orders - an eager step runs the
+        predictor's backward right after the joint, a captured step (predictor forked in front of the encoder) after the whole
+        mixture encoder, and with length-bucketed batches one rank runs eagerly while another replays - but every rank must issue
+        the same sequence of ncclAllReduce calls, or counts mismatch and the ranks hang or average the wrong gradients."""
+        b["ready"] = True
+        while self._next_send < len(self.buckets) and self.buckets[self._next_send].get("ready"):
+            self._send(self.buckets[self._next_send])
+            self._next_send += 1
 
     # ---- per step --------------------------------------------------------------------------------------
     def begin_backward(self, will_sync):
@@ -361,7 +393,8 @@ class GradArena:
             from . import ops
             ops.reduce_defer_begin(self.device)
         for b in self.buckets:
-            b["left"], b["sent"], b["queued"] = sum(self._contrib.get(i, 1) for i in b["ids"]), False, 0
+            b["left"], b["sent"], b["queued"], b["ready"] = sum(self._contrib.get(i, 1) for i in b["ids"]), False, 0, False
+        self._next_send = 0
         if not self._order_final:
             self._contrib_step = {}
         self._handles, self.sent_log = [], []
@@ -378,7 +411,7 @@ class GradArena:
             if b.get("queued", 0):
                 self.flush_wgrads()
             else:
-                self._send(b)
+                self._ready(b)
 
     def _send(self, b):
         if b.get("sent"):
@@ -422,8 +455,9 @@ class GradArena:
         self._flush_deferred()
         self.in_backward = False
         if self._sync_this_step:
-            for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step
+            for b in self.buckets:  # buckets whose parameters got no gradient this step, or first (unordered) step: index order
                 self._send(b)
+            self._next_send = len(self.buckets)
             if self.direct and self.comm_stream is not None and self._handles:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)   # "wait" = one join of the communication stream
             for h, div, payload, back in self._handles:

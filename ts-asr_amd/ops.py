@@ -55,7 +55,7 @@ def begin_step(device):
 # of pairs, each guarded by an event (the host waits only when it laps the GPU by a whole ring); a flush inside a stream capture gets
 # a pair of its own for the life of the graph (filled at capture, uploaded once right after it - a replay carries no memcpy node).
 class TableRing:
-    def __init__(self, nbytes, device, eager_pairs=8, captured_pairs=120):
+    def __init__(self, nbytes, device, eager_pairs=8, captured_pairs=8):
         self.nbytes, self.device = int(nbytes), torch.device(device)
         n = eager_pairs + captured_pairs
         self.host = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(n)]
@@ -75,6 +75,15 @@ class TableRing:
         if self.events[k] is not None:
             self.events[k].synchronize()   # the launch that last read this pair has finished (no-op unless the host is a ring ahead)
         return k, self.host[k], self.dev[k], False
+
+    def reserve_captured(self, n):
+        """Make sure the next capture can take ``n`` pairs: called OUTSIDE a capture (pinned and device memory cannot be allocated
+        inside one), before every step capture - the pool grows with the number of captured graphs instead of being a fixed 120."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("TableRing.reserve_captured called inside a stream capture")
+        while len(self.host) - (self.eager_pairs + self.captured) < n:
+            self.host.append(torch.empty(self.nbytes, dtype=torch.uint8).pin_memory())
+            self.dev.append(torch.empty(self.nbytes, dtype=torch.uint8, device=self.device))
 
     def launched(self, k, nbytes=None):
         """Call right after the launch that reads pair k was enqueued."""
@@ -163,6 +172,22 @@ def upload_captured_tables():
             st["ring"].upload_captured()
 
 
+def reserve_captured_tables(n):
+    """Before a step capture: job-table pairs for up to ``n`` captured flushes of each batched launch (TableRing.reserve_captured)."""
+    for st in (_DEFER, _WG):
+        if st["ring"] is not None:
+            st["ring"].reserve_captured(n)
+
+
+def discard_queues():
+    """Error path of a failed step (a capture that raised half-way): drop every queued weight gradient and reduction, release their
+    operands, leave deferral off - the next step starts from a clean state."""
+    C.lib().tsasr_wgrad_discard()
+    C.lib().tsasr_reduce_discard()
+    _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"], _WG["bytes"] = [], set(), [], 0.0, 0, 0.0
+    _DEFER["keep"], _DEFER["on"] = [], False
+
+
 def reduce_defer_end():
     if not _DEFER["on"]:
         return
@@ -193,7 +218,13 @@ def wgrad_queue(weight, grad2d, dy2, x2):
             or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or grad2d.dtype != torch.float32:
         return False
     if id(weight) in _WG["ids"] or C.lib().tsasr_wgrad_pending() >= _WG_MAX_JOBS:   # a second gradient into the same tiles: order them
-        wgrad_flush()
+        # through the arena: the queue is shared by every stream of the step, so the launch has to be ordered after all of them and the
+        # operands have to outlive the streams' join (GradArena.flush_wgrads, hold) - a bare launch on the current stream is neither
+        sink = _GRAD_SINK
+        if sink is not None and getattr(sink, "in_backward", False):
+            sink.flush_wgrads(hold=True)
+        else:
+            wgrad_flush()
     C.check(C.lib().tsasr_wgrad_queue(C.ptr(dy2), C.ptr(x2), C.ptr(grad2d), N, K, M, dy2.stride(0), x2.stride(0), grad2d.stride(0)),
             "tsasr_wgrad_queue")
     _WG["ids"].add(id(weight))

@@ -66,7 +66,7 @@ class FusedClipAdamW:
         C.require_gpu(a.flat_params)
         with prof.region("clip_adamw"):
             C.check(C.lib().tsasr_clip_adamw_step(C.ptr(a.flat_params), C.ptr(a.flat_params16), C.ptr(a.grads), C.ptr(self.exp_avg),
-                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self._norm_buf), a.numel,
+                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self._norm_buf[0:1]), C.ptr(self._norm_buf[1:2]), a.numel,
                                                   float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.max_grad_norm,
                                                   C.ptr(self._ws), self._ws.numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
             a.refresh_transposed()
@@ -90,12 +90,12 @@ class FusedClipAdamW:
             {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
 
-def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm, p16=None):
-    """Stand-alone call of csrc/optim.hip on explicit buffers (unit tests)."""
+def _clip_adamw(p, g, m, v, norm_out, lr, b1, b2, eps, wd, t, max_norm, p16=None, skipped_out=None):
+    """Stand-alone call of csrc/optim.hip on explicit buffers (unit tests). norm_out / skipped_out: one device float each (or None)."""
     C.require_gpu(p, g, m, v)
     hyper = torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32).to(p.device)
     ws = torch.empty(max(256, C.lib().tsasr_clip_adamw_workspace_bytes()), dtype=torch.uint8, device=p.device)
-    C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(p16), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(hyper), C.ptr(norm_out), p.numel(),
+    C.check(C.lib().tsasr_clip_adamw_step(C.ptr(p), C.ptr(p16), C.ptr(g), C.ptr(m), C.ptr(v), C.ptr(hyper), C.ptr(norm_out), C.ptr(skipped_out), p.numel(),
                                           float(b1), float(b2), float(eps), float(wd), float(max_norm), C.ptr(ws), ws.numel(),
                                           C.stream_ptr()), "tsasr_clip_adamw_step")
 

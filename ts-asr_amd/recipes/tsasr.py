@@ -220,85 +220,6 @@ class TSASR(core.Brain):
             hyps, _, _, _ = hp.beam_searcher(enc_out)
         return logits, hyps
 
-    # ---- the captured step as several graphs (core.GraphSegments) -------------------------------------------------------------
-    def segmentable(self):
-        hp = self.hparams
-        enc = self.modules.encoder if "encoder" in self.modules else None
-        inj = getattr(enc, "injection_after", None)
-        return (self.variant != "none" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT) and torch.device(self.device).type == "cuda"
-                and hasattr(enc, "forward_pre") and inj is not None and len(inj) == 1 and getattr(hp, "injection_mode", None) is not None)
-
-    def _device_step_segmented(self, batch, should_step, seg):
-        """core.Brain._device_step cut where its branches fork and join:
-            start -> { speaker branch forward | predictor forward | mixture front-end + the layers in front of the injection }
-                  -> injection, remaining layers, joint, loss, and their backward
-                  -> { backward of the three branches | the queued weight gradients of the main part } -> reductions, clip + AdamW.
-        The autograd graph is cut at the three joins (detached leaves), so each branch's backward is its own torch.autograd.backward
-        call on the branch's stream. Same kernels, same arithmetic as the single-graph step; only what may run side by side changes."""
-        from .. import ops as _ops
-        from .. import rnnt
-        hp = self.hparams
-        epoch = hp.epoch_counter.current if hasattr(hp, "epoch_counter") else 0
-        batch = batch.to(self.device)
-        mixed, mixed_lens = batch.mixed_sig
-        tokens_bos, tokens_bos_lens = batch.tokens_bos
-        s0, s1, s2, s3 = seg.streams[:4]
-        k_start = seg.begin("start", s0)
-        _ops.begin_step(self.device)
-        self.arena.begin_backward(False)
-        self.arena._main_stream = None            # flushes must not join streams that are not part of the segment being captured
-        k_spk = seg.begin("speaker_fwd", s1, deps=[k_start])
-        spk, enroll_lens = self._speaker_embedding(batch, epoch)
-        spk_leaf = spk.detach().requires_grad_(spk.requires_grad)
-        k_pred = seg.begin("predictor_fwd", s2, deps=[k_start])
-        dec_out = self._predictor(tokens_bos, tokens_bos_lens)
-        dec_leaf = dec_out.detach().requires_grad_(dec_out.requires_grad)
-        k_pre = seg.begin("mixture_pre_fwd", s0, deps=[k_start])
-        augment = bool(getattr(hp, "augment", False))
-        if getattr(hp, "input_is_feats", False):
-            feats = mixed
-        else:
-            if augment and "speed_perturb" in self.modules:
-                mixed = self.modules.speed_perturb(mixed)
-            feats = self.modules.feature_extractor(mixed)
-            feats = self.modules.normalizer(feats, mixed_lens, epoch=epoch)
-        if augment and "augmentation" in self.modules:
-            feats = self.modules.augmentation(feats)
-        feats = self.modules.frontend(feats)
-        state = self.modules.encoder.forward_pre(feats, mixed_lens, spk_leaf, enroll_lens)
-        x_pre = state["x"]
-        x_leaf = x_pre.detach().requires_grad_(x_pre.requires_grad)
-        state["x"] = x_leaf
-        k_main = seg.begin("main", s0, deps=[k_spk, k_pred, k_pre])
-        enc_out = self.modules.encoder.forward_post(state, spk_leaf, enroll_lens)
-        enc_out = self.modules.encoder_proj(enc_out)
-        head = self.modules.transducer_head.w
-        tlen = abs_lengths_round(mixed_lens, enc_out.shape[1])
-        ulen = abs_lengths_round(batch.tokens.lengths.to(self.device), batch.tokens.data.shape[1])
-        logits = rnnt.fused_joint_logits(enc_out, dec_leaf, head.weight, head.bias, self.modules.joiner.nonlinearity.negative_slope, tlen, ulen)
-        loss = self.compute_objectives((logits, None), batch, Stage.TRAIN)
-        self.check_gradients(loss)
-        (loss / self.grad_accumulation_factor).backward()
-        deps = []
-        if _EARLY_WGRAD:
-            deps.append(seg.begin("main_weight_gradients", s3, deps=[k_main]))
-            self.arena.flush_wgrads(hold=True)
-        if x_pre.requires_grad and x_leaf.grad is not None:
-            deps.append(seg.begin("mixture_pre_bwd", s0, deps=[k_main]))
-            torch.autograd.backward(x_pre, x_leaf.grad)
-        if spk.requires_grad and spk_leaf.grad is not None:
-            deps.append(seg.begin("speaker_bwd", s1, deps=[k_main]))
-            torch.autograd.backward(spk, spk_leaf.grad)
-        if dec_out.requires_grad and dec_leaf.grad is not None:
-            deps.append(seg.begin("predictor_bwd", s2, deps=[k_main]))
-            torch.autograd.backward(dec_out, dec_leaf.grad)
-        seg.begin("finish", s0, deps=deps or [k_main])
-        self.arena.finish_backward()
-        if should_step:
-            self.optimizer.launch()
-            self.arena.zero_()
-        return loss.detach()
-
     def compute_objectives(self, predictions, batch, stage):
         logits, hyps = predictions
         _, mixed_lens = batch.mixed_sig
