@@ -28,6 +28,8 @@ WORKLOADS = {
                     name="BASELINE.json configs[1]: conformer-t_scratch 12L d256 (+6L speaker encoder), mel [32,1000,80] + enrollment mel [32,500,80] + tokens [32,120], injection cat, dropout 0.1"),
     "pretrained": dict(yaml="conformer-t_wavlm_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides={}, emb=512,
                        name="BASELINE.json configs[3]: conformer-t_wavlm (frozen speaker encoder's x-vector given as [32,1,512] -> speaker_proj 512->256 -> cat injection), mel [32,1000,80] + tokens [32,120], dropout 0.1"),
+    "none": dict(yaml="conformer-t_none_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides={}, emb=0,
+                 name="train_librispeechmix_none.py / conformer-t_none.yaml: the same transducer WITHOUT a speaker branch (12L d256 encoder, no injection), mel [32,1000,80] + tokens [32,120], dropout 0.1"),
     "longform": dict(yaml="conformer-t_scratch_mi355x.yaml", B=1, T=16000, Te=500, U=1920, emb=0,
                      overrides=dict(causal_encoder=True, frontend_padding="causal"),
                      name="BASELINE.json configs[4]: causal conformer-t (causal encoder + causal front-end padding, as the reference's --causal_encoder True --frontend_padding causal), B=1/GPU, mel [1,16000,80] -> T'=4000, tokens [1,1920], enrollment mel [1,500,80], dropout 0.1"),
@@ -78,9 +80,20 @@ def cpu_baseline(brain, torch, budget_steps=6, B=4):   # ~10 s of host work
     """Oracle (CPU restatement of the reference) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import rnnt_ref, tsasr_ref
     batch_mod = importlib.import_module(PKG + ".batch")
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TSASR_CPU_BASELINE_THREADS", "16")))  # the box's CPU share
+    # threads = the CPU share this job is given, not the host's core count: the GPU boxes of the pool hand a one-GPU job 16 CPUs of a
+    # 256-thread host (the pool's rule; more threads than the share are time-sliced, not faster). The cgroup quota, when one is set, and
+    # the affinity mask are reported next to the figure; TSASR_CPU_BASELINE_THREADS overrides the 16.
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    share = int(os.environ.get("TSASR_CPU_BASELINE_THREADS", "16"))
+    cores = max(1, min(len(os.sched_getaffinity(0)), share, int(quota) if quota and quota >= 1 else share))
     torch.set_num_threads(cores)
-    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()}, affinity={len(os.sched_getaffinity(0))})")
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()}, affinity={len(os.sched_getaffinity(0))}, cgroup cpu quota={quota})")
     sd = {f"{n}.{k}": v.detach().cpu().float().clone().requires_grad_(v.dtype.is_floating_point)
           for n, m in brain.modules.items() for k, v in m.state_dict().items()}
     cfg = dict(nhead=4, encoder_num_layers=12, speaker_num_layers=6, vocab_size=29, blank_index=0)
@@ -100,6 +113,7 @@ def cpu_baseline(brain, torch, budget_steps=6, B=4):   # ~10 s of host work
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(B * T_MEL / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "host": {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota, "cpu_share_of_a_one_gpu_job": share},
             "sample": f"fwd+loss+bwd of the same model/shape at B={B} (T=1000 mel, U=120, 5 s enrollment), fp32, median of {len(times)} steps after 1 warm-up; optimizer step excluded"}
 
 
@@ -339,8 +353,7 @@ def main():
                 roof["largest_launch_without_flop_or_byte_model"] = {"kernel": latency_bound, **fam[latency_bound]}
         rnnt_ms = sum(fam[k]["avg_ms"] for k in ("joint_fwd", "rnnt_loss_fwd", "rnnt_loss_bwd", "joint_bwd") if k in fam)
         out = {
-            "metric": f"utterance-frames/sec (conformer-t_scratch training step, T={T_MEL}, B={B_LOCAL}/GPU)" if args.config != "pretrained"
-                      else f"utterance-frames/sec (conformer-t_wavlm training step, T={T_MEL}, B={B_LOCAL}/GPU)",
+            "metric": f"utterance-frames/sec ({ {'pretrained': 'conformer-t_wavlm', 'none': 'conformer-t_none'}.get(args.config, 'conformer-t_scratch') } training step, T={T_MEL}, B={B_LOCAL}/GPU)",
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -368,6 +368,14 @@ int tsasr_greedy_decode(const void *enc, const float *emb, const void *w_ih, con
 /* TEST AID (tests / tools only): overwrite the whole LDS of every CU with a 32-bit pattern, so that a kernel reading LDS it never wrote
  * sees the pattern instead of whatever the previous kernel left there. */
 int tsasr_debug_fill_lds(unsigned pattern, void *stream);
+/* TEST AID: LDS canary (tools/lds_canary.py): wgs workgroups hold lds_bytes of LDS each and verify a pattern iters times while other
+ * streams' kernels run beside them; *errors (DEVICE uint) += corrupted words, first_bad (DEVICE uint[4] or NULL) describes one. */
+int tsasr_debug_lds_canary(int wgs, int lds_bytes, int iters, void *errors, void *first_bad, void *stream);
+/* TEST AID: barrier canary: wgs workgroups x rounds of {every wave writes a quarter of an LDS table, barrier, every lane reads words of
+ * all four waves}; *errors (DEVICE uint[2]) += words that were not yet visible behind the barrier. */
+int tsasr_debug_barrier_canary(int wgs, int rounds, void *errors, void *first_bad, void *stream);
+/* TEST AID: register canary: wgs x 256 lanes keep 48 VGPRs each and verify them iters times; *errors (DEVICE uint) += changed registers. */
+int tsasr_debug_vgpr_canary(int wgs, int iters, void *errors, void *first_bad, void *stream);
 /* TEST AID: nwords 32-bit words at p <- pattern (poisoning the captured step's free pool memory between replays). */
 int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream);
 int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);

@@ -364,7 +364,7 @@ def compute_forward(batch, sd, cfg, injection_mode="cat", causal=False, frontend
     f = frontend(f, sub("frontend."), frontend_padding)
     c["frontend"] = f
     e = conformer_encoder(f, batch["mixed_lens"], sd, "encoder.", H, cfg["encoder_num_layers"], spk,
-                          batch["enroll_lens"], injection_mode, (0,), causal)
+                          batch.get("enroll_lens"), injection_mode, (0,), causal)   # no speaker branch (train_librispeechmix_none.py:78): spk is None
     c["enc"] = e
     e = linear(e, sd, "encoder_proj.")
     c["enc_proj"] = e

@@ -358,3 +358,31 @@ def test_oracle_pretrained_variant_vs_reference_golden(golden, mode):
             elif k.startswith("grad:") and k[5:] in sd:
                 np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=2e-6, rtol=2e-3)
         assert n >= 60
+
+
+# ---------------------------------------------------------------------------------------------- the recipe without a speaker encoder
+@pytest.mark.parametrize("tag", ["full", "causal"])
+def test_oracle_none_variant_vs_reference_golden(golden, tag):
+    """train_librispeechmix_none.py:34-95 (conformer-t_none.yaml: no speaker modules, encoder built without injection arguments and
+    called as encoder(feats, lens)) against tests/golden/c1_none.npz (oracle/gen_golden_none.py, the reference's own modules)."""
+    g = golden["c1_none"]
+    sd = {k: v for k, v in full_state_dict(CFG1, "prod").items() if not k.startswith("speaker_")}
+    assert sorted(sd) == [str(k) for k in g["state_keys"] if not str(k).endswith(("inv_freq", "Embedding.weight", "compute_deltas.kernel"))]   # buffers / the frozen one-hot table
+    batch = {k: v for k, v in torch_batch(golden_inputs()).items() if not k.startswith("enroll")}
+    if tag == "full":
+        for v in sd.values():
+            v.requires_grad_(True)
+    c = {}
+    with torch.set_grad_enabled(tag == "full"):
+        logits = R.compute_forward(batch, sd, CFG1, None, causal=(tag == "causal"), collect=c)
+    np.testing.assert_allclose(c["enc"].detach().numpy(), g[f"enc:{tag}"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(logits.detach().numpy(), g[f"logits:{tag}"], atol=2e-4, rtol=1e-4)
+    if tag == "full":
+        probe = T(det_tensor("probe.logits", tuple(logits.shape), 1.0))
+        (logits * probe).sum().mul(1.0 / logits.numel()).backward()
+        n = 0
+        for k in g.files:
+            if k.startswith("norm:") and k[5:] in sd and sd[k[5:]].grad is not None:
+                assert float(sd[k[5:]].grad.double().norm()) == pytest.approx(float(g[k]), rel=2e-3, abs=1e-7), k
+                n += 1
+        assert n >= 50

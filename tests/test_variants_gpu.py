@@ -196,3 +196,130 @@ def test_pretrained_variant_training_step_vs_oracle(dtype):
     brain.arena.zero_()
     brain.fit_batch(make_batch(inp, emb))
     assert not torch.equal(w0, brain.modules.speaker_proj.w.weight) and brain.flush_nonfinite() == 0
+
+
+# ---------------------------------------------------------------------------------------------- the recipe without a speaker encoder
+def none_brain(dtype):
+    brain, h = entry._config1_brain(DEV, dtype, "conformer-t_none_mi355x.yaml")
+    assert brain.variant == "none" and not any(k.startswith("speaker") for k in brain.modules)
+    return brain, h
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_none_variant_forward_vs_reference_golden(golden, dtype):
+    """train_librispeechmix_none.py (no speaker branch, encoder(feats, lens)) on the HIP path vs tests/golden/c1_none.npz."""
+    g = golden["c1_none"]
+    brain, h = none_brain(dtype)
+    brain._setup_dtype()
+    brain.modules.eval()
+    core = importlib.import_module("ts-asr_amd.core")
+    with torch.no_grad():
+        logits, _ = brain.compute_forward(make_batch(golden_inputs()), core.Stage.VALID)
+    e_log = rel_l2(logits, g["logits:full"])
+    print(dtype, "none variant logits", e_log)
+    assert e_log < (3e-2 if dtype == "bf16" else 8e-3)       # fp32 mode: bf16 MFMA operands in attention and joint (as configs[0])
+
+
+def test_none_variant_training_steps_and_graph_replay():
+    """fit_batch of the `none` recipe in bf16: the loss of the first step equals the oracle's (no speaker keys in its state dict), every
+    parameter gradient matches the oracle's autograd, and hipGraph replays reproduce the eager losses bit for bit (this variant has no
+    forked stream at all: one chain of launches)."""
+    inp = golden_inputs()
+    core = importlib.import_module("ts-asr_amd.core")
+    brain, h = none_brain("bf16")
+    brain.modules.train()
+    brain.on_fit_start()
+    sd = state_dict_cpu(brain, grad=True)
+    assert not any(k.startswith("speaker") for k in sd)
+    brain.arena.begin_backward(False)
+    batch = make_batch(inp)
+    out = brain.compute_forward(batch, core.Stage.TRAIN)
+    loss = brain.compute_objectives(out, batch, core.Stage.TRAIN)
+    loss.backward()
+    brain.arena.finish_backward()
+    ob = {k: T(v) for k, v in inp.items() if not k.startswith("enroll")}
+    logits_o = R.compute_forward(ob, sd, CFG1, None)
+    loss_o = RR.transducer_loss_ref_torch(logits_o, T(inp["tokens"]), T(inp["mixed_lens"]), T(inp["tokens_lens"]), 0, "mean")
+    loss_o.backward()
+    assert float(loss) == pytest.approx(float(loss_o), rel=3e-2)
+    for mn, mod in brain.modules.items():
+        for k, p in mod.named_parameters():
+            if p.requires_grad:
+                ref = sd[f"{mn}.{k}"].grad
+                rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
+                assert rel < (1.5e-1 if ("pos_bias" in k or "linear_pos" in k) else 6e-2), (mn, k, rel)
+    losses = {}
+    for mode in ("eager", "graph"):
+        b2, _ = none_brain("bf16")
+        b2.modules.train()
+        if mode == "graph":
+            b2.enable_hip_graph(warmup_steps=2)
+        bt = make_batch(inp).to(DEV)
+        losses[mode] = [float(b2.fit_batch(bt)) for _ in range(6)]
+        if mode == "graph":
+            assert len(b2._graphs) == 1
+    assert losses["eager"] == losses["graph"], losses
+    assert losses["eager"][-1] < losses["eager"][0]
+
+
+# ---------------------------------------------------------------------------------------------- configs[1]: the whole model at full size
+def test_config1_full_size_whole_model_properties():
+    """BASELINE.json configs[1] (the benchmarked workload: 12 + 6 layers, d_model 256, B = 32, T = 1000 mel frames, U = 120, bf16, dropout
+    on, ragged lengths) through TSASR.compute_forward / compute_objectives / backward at FULL size - where no fixture fits, the properties
+    the domain offers: the loss equals the C oracle's (torchaudio semantics restated in float64: oracle/rnnt_ref.c) on the logits the HIP
+    path produced; every row of dlogits sums to 0 over the vocabulary and is 0 outside each utterance's lattice; every parameter gets a
+    finite gradient; a second, fresh run of two whole training steps is bit-identical (losses and every weight)."""
+    import bench
+    from oracle import rnnt_ref as RRc
+    core = importlib.import_module("ts-asr_amd.core")
+    bm = importlib.import_module("ts-asr_amd.batch")
+    B, T, U = 32, 1000, 120
+
+    def fresh():
+        torch.manual_seed(0)
+        brain, h, _ = bench.build_brain(DEV, "bf16", 1)
+        batch = bm.synthetic_batch(B, T, 500, U, feats=True, seed=1234, ragged=True).to(DEV)
+        return brain, batch
+
+    brain, batch = fresh()
+    brain.on_fit_start()
+    importlib.import_module("ts-asr_amd.ops").begin_step(DEV)
+    brain.arena.begin_backward(False)
+    logits, _ = brain.compute_forward(batch, core.Stage.TRAIN)
+    assert tuple(logits.shape) == (B, T // 4, U + 1, 29)
+    grabbed = []
+    logits.register_hook(lambda g: grabbed.append(g.detach().clone()))
+    loss = brain.compute_objectives((logits, None), batch, core.Stage.TRAIN)
+    loss.backward()
+    for s in brain._aux_streams:
+        torch.cuda.current_stream().wait_stream(s)
+    brain.arena.finish_backward()
+    torch.cuda.synchronize()
+    tl = (batch.mixed_sig.lengths.cpu() * (T // 4)).round().int().numpy()
+    ul = (batch.tokens.lengths.cpu() * U).round().int().numpy()
+    costs_ref, _ = RRc.rnnt_costs_grads(np.ascontiguousarray(logits.detach().float().cpu().numpy()), batch.tokens.data.cpu().int().numpy(), tl, ul, 0, want_grads=False)
+    assert float(loss) == pytest.approx(float(costs_ref.mean()), rel=2e-5)
+    dl = grabbed[0].float()
+    assert float(dl.sum(-1).abs().max()) < 5e-6
+    tmask = torch.arange(T // 4, device=DEV)[None, :, None] >= torch.as_tensor(tl, device=DEV)[:, None, None]
+    umask = torch.arange(U + 1, device=DEV)[None, None, :] > torch.as_tensor(ul, device=DEV)[:, None, None]
+    assert float(dl[(tmask | umask).expand(B, T // 4, U + 1)].abs().max()) == 0.0
+    n = 0
+    for mn, mod in brain.modules.items():
+        for k, p in mod.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), (mn, k)
+                n += 1
+    gn = float(brain.arena.grads.norm())
+    assert n > 400 and np.isfinite(gn) and gn > 0
+    del brain, logits, loss, dl, grabbed
+    runs = []
+    for _ in range(2):
+        b2, bt = fresh()
+        b2.modules.train()
+        ls = [float(b2.fit_batch(bt)) for _ in range(2)]
+        torch.cuda.synchronize()
+        runs.append((ls, b2.arena.flat_params.detach().clone()))
+        del b2
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][1] != runs[0][0][0] and all(np.isfinite(runs[0][0]))

@@ -182,6 +182,9 @@ for r in range(args.reps):
                     pdetail += (f"; FBANK step {i}: input checksums equal: {torch.equal(ci, ri)} ({ci.tolist()} vs {ri.tolist()}); output differs in {d.shape[0]} of {co.numel()}"
                                 f" values, utterances {sorted(set(d[:, 0].tolist()))}, frames {sorted(set(d[:, 1].tolist()))[:12]}, bins {sorted(set(d[:, 2].tolist()))[:12]}; "
                                 + ", ".join(f"{tuple(k.tolist())}: {float(co[tuple(k.tolist())])!r} vs {float(ro[tuple(k.tolist())])!r}" for k in d[:6]))
+                    later_in = [j for j, ((cj, _), (rj, _)) in enumerate(zip(run.fb_log, ref_fb)) if not torch.equal(cj, rj)]
+                    later_out = [j for j, ((_, oj), (_, qj)) in enumerate(zip(run.fb_log, ref_fb)) if not torch.equal(oj, qj)]
+                    pdetail += f"; steps whose Fbank INPUT checksums differ: {later_in}; steps whose Fbank OUTPUT differs: {later_out}"
                     break
         if dl or ds is not None or pdetail:
             bad += 1

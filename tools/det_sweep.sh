@@ -6,8 +6,9 @@ mkdir -p $O
 run() { # name, reps, env..., -- args
   name=$1; shift; reps=$1; shift
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  echo "== $name" ; env "${envs[@]}" timeout -k 10 900 python tools/det_stress.py --reps $reps "$@" > $O/$name.log 2>&1
-  echo "rc=$?"; grep "^rep\|RESULT\|poisoned\|Error" $O/$name.log | cut -c1-3000 | tail -8
+  echo "== $name" ; env "${envs[@]}" timeout -k 10 560 python tools/det_stress.py --reps $reps "$@" > $O/$name.log 2>&1
+  echo "rc=$?"; grep "^rep\|RESULT\|poisoned\|Error" $O/$name.log | cut -c1-1200 | tail -12
 }
-run fbank $REPS X=1 -- --snap 0 --probe 1 --fbank 1 --steps 8 --modes graph
+run default $REPS X=1 -- --snap 0 --steps 8 --modes graph
+run overlap4 $REPS TSASR_OVERLAP=4 -- --snap 0 --steps 8 --modes graph
 true

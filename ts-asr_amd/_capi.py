@@ -109,6 +109,9 @@ _PROTOS = {
     "tsasr_abs_lengths": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "tsasr_greedy_decode": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_float, c_int, c_int, c_void_p]),
     "tsasr_debug_fill_lds": (c_int, [ctypes.c_uint, c_void_p]),
+    "tsasr_debug_lds_canary": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tsasr_debug_barrier_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tsasr_debug_vgpr_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tsasr_debug_fill": (c_int, [c_void_p, ctypes.c_uint, c_size_t, c_void_p]),
     "tsasr_count_nonfinite": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),

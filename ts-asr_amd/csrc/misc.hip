@@ -57,7 +57,108 @@ __global__ void fill_words_kernel(unsigned *p, unsigned pattern, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pattern;
 }
 
+// TEST AID: LDS canary. A workgroup fills `words` 32-bit words of its own LDS with a pattern derived from its id, then verifies and
+// rewrites them `iters` times; every word that does not read back as written is counted. Run beside another stream's kernels it
+// detects writes that land outside their own LDS allocation (an LDS-DMA with a destination beyond the workgroup's allocation is not
+// a `ds_write`: nothing says it is bounds-checked the same way).
+__global__ __launch_bounds__(256) void lds_canary_kernel(int words, int iters, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
+    extern __shared__ unsigned cw[];
+    const unsigned key = 0xA5000000u ^ (blockIdx.x * 2654435761u);
+    for (int i = threadIdx.x; i < words; i += 256) cw[i] = key ^ (unsigned)i;
+    __syncthreads();
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = threadIdx.x; i < words; i += 256) {
+            const unsigned v = cw[i];
+            if (v != (key ^ (unsigned)i)) {
+                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x; first_bad[1] = (unsigned)i; first_bad[2] = v; first_bad[3] = key ^ (unsigned)i; }
+                ++bad;
+                cw[i] = key ^ (unsigned)i;
+            }
+        }
+        __builtin_amdgcn_s_sleep(32);
+        __syncthreads();
+    }
+    if (bad) atomicAdd(errors, bad);
+}
+
+// TEST AID: register canary. Every lane keeps 48 known values in VGPRs (pinned there by empty asm statements), sleeps, and checks them
+// `iters` times: a value that changed was written by somebody else - this wave never writes them after the first assignment.
+__global__ __launch_bounds__(256) void vgpr_canary_kernel(int iters, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
+    unsigned v[48];
+    const unsigned key = 0x5A000000u ^ ((blockIdx.x * 256u + threadIdx.x) * 2246822519u);
+#pragma unroll
+    for (int i = 0; i < 48; ++i) { v[i] = key + (unsigned)i * 0x01000193u; asm volatile("" : "+v"(v[i])); }
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_sleep(16);
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            asm volatile("" : "+v"(v[i]));
+            if (v[i] != key + (unsigned)i * 0x01000193u) {
+                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x * 256u + threadIdx.x; first_bad[1] = (unsigned)i; first_bad[2] = v[i]; first_bad[3] = key + (unsigned)i * 0x01000193u; }
+                ++bad;
+                v[i] = key + (unsigned)i * 0x01000193u;
+            }
+        }
+    }
+    if (bad) atomicAdd(errors, bad);
+}
+
+// TEST AID: barrier canary. The cross-wave pattern of the log-mel kernel (a table every wave fills a quarter of, one workgroup barrier,
+// then every wave reads all of it): each round the four waves write round-dependent words, meet at the barrier, and every lane checks
+// four words written by each OTHER wave. A mismatch = the barrier let a wave through before the others' LDS stores were visible.
+__global__ __launch_bounds__(256) void barrier_canary_kernel(int rounds, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
+    __shared__ unsigned pad0[4096];          // 16 KB in front (the log-mel kernel keeps its FFT buffers there)
+    __shared__ unsigned tab[256 + 1280];     // the shared table sits at the log-mel kernel's offset of its twiddles (20496 B = 5124 words)
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    pad0[tid] = tid;
+    unsigned bad = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const unsigned key = 0xC3000000u ^ (unsigned)(rd * 40503u) ^ (blockIdx.x << 8);
+        tab[1028 + tid] = key + tid;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned idx = w * 64 + ((lane * 7 + rd) & 63), v = tab[1028 + idx];
+            if (v != key + idx) {
+                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x; first_bad[1] = (wave << 16) | (w << 8) | lane; first_bad[2] = v; first_bad[3] = key + idx; }
+                ++bad;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(errors, bad);
+    if (pad0[(tid * 5) & 4095] == 0xFFFFFFFFu) errors[1] = 1;   // keeps pad0 allocated
+}
+
 extern "C" {
+
+/* TEST AID: `wgs` workgroups run `rounds` write / barrier / cross-wave read rounds; *errors (DEVICE uint[2]) += stale words seen. */
+int tsasr_debug_barrier_canary(int wgs, int rounds, void *errors, void *first_bad, void *stream) {
+    TSASR_CHECK_ARG(wgs > 0 && rounds > 0 && errors, "tsasr_debug_barrier_canary: bad arguments");
+    barrier_canary_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(rounds, (unsigned *)errors, (unsigned *)first_bad);
+    TSASR_CHECK_LAUNCH("tsasr_debug_barrier_canary");
+    return 0;
+}
+
+/* TEST AID: `wgs` workgroups of 256 lanes keep 48 VGPRs each and verify them `iters` times; *errors (DEVICE uint) += changed registers. */
+int tsasr_debug_vgpr_canary(int wgs, int iters, void *errors, void *first_bad, void *stream) {
+    TSASR_CHECK_ARG(wgs > 0 && iters > 0 && errors, "tsasr_debug_vgpr_canary: bad arguments");
+    vgpr_canary_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(iters, (unsigned *)errors, (unsigned *)first_bad);
+    TSASR_CHECK_LAUNCH("tsasr_debug_vgpr_canary");
+    return 0;
+}
+
+/* TEST AID: `wgs` workgroups hold `lds_bytes` of LDS each, check them `iters` times; *errors (device uint) += corrupted words seen,
+ * first_bad (device uint[4], may be NULL) = {workgroup, word, value read, value expected} of one of them. */
+int tsasr_debug_lds_canary(int wgs, int lds_bytes, int iters, void *errors, void *first_bad, void *stream) {
+    TSASR_CHECK_ARG(wgs > 0 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && iters > 0 && errors, "tsasr_debug_lds_canary: bad arguments");
+    (void)hipFuncSetAttribute((const void *)lds_canary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    lds_canary_kernel<<<wgs, 256, lds_bytes, (hipStream_t)stream>>>(lds_bytes / 4, iters, (unsigned *)errors, (unsigned *)first_bad);
+    TSASR_CHECK_LAUNCH("tsasr_debug_lds_canary");
+    return 0;
+}
 
 /* TEST AID: fill the LDS of every CU with a 32-bit pattern (160 KB workgroups, enough of them that every CU runs at least one). */
 int tsasr_debug_fill_lds(unsigned pattern, void *stream) {

@@ -156,13 +156,12 @@ class TSASR(core.Brain):
                 spk_ready.record(side)
                 if _EARLY_WGRAD and spk is not None and spk.requires_grad:
                     spk.register_hook(self._flush_main_wgrads)
-                # The predictor joins the fork only while the step is being captured into a hipGraph (mode "3": always). Eager steps
-                # with the predictor on a forked stream showed run-to-run deviations (~1e-4 of the loss, 1-2 % of 8-step runs when the
-                # host is not synchronised every step; tools/eager_repeat.py) whose cause was not found - ruled out: uninitialised
-                # memory, leftover LDS, the persistent LSTM kernels, hipMemsetAsync, the grouped weight gradients.
-                # With only the speaker branch forked 357 such runs were identical; replays of a captured step are bitwise reproducible
-                # across processes (tests/test_recipe_gpu.py). Eager steps are host-bound: the predictor's overlap buys nothing there.
-                if _OVERLAP_MODE == "3" or (_OVERLAP_MODE == "1" and torch.cuda.is_current_stream_capturing()):
+                # The predictor follows the speaker branch on the forked stream, in eager and in captured steps alike (one autograd
+                # topology: gradient buckets complete in the same order either way). Round 2 kept it on the main stream in eager steps
+                # because runs with it forked deviated once in ~100; the cause was found in round 3 and is not a stream-ordering
+                # matter: packed-fp32 instructions of one kernel returning wrong values while the per-step LSTM kernels ran beside it
+                # (profiles/r03_notes.md section 1; the library no longer contains such instructions). "2" = speaker branch only.
+                if _OVERLAP_MODE in ("1", "3"):
                     dec_out = self._predictor(tokens_bos, tokens_bos_lens)
             if _OVERLAP_MODE == "4":
                 # "4" (A/B, measured equal: 13.43 vs 13.44 ms): the predictor on a stream of its own
