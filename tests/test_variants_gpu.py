@@ -277,6 +277,7 @@ def test_config1_full_size_whole_model_properties():
 
     def fresh():
         torch.manual_seed(0)
+        importlib.import_module("ts-asr_amd.ops").seed_state(torch.device(DEV)).zero_()   # the device-side dropout step counter is per process
         brain, h, _ = bench.build_brain(DEV, "bf16", 1)
         batch = bm.synthetic_batch(B, T, 500, U, feats=True, seed=1234, ragged=True).to(DEV)
         return brain, batch
