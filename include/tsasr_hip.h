@@ -220,6 +220,16 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
                           float *d_bias_v, int B, int T, int H, int Dh, float scale, int causal, float pdrop,
                           unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *workspace, size_t workspace_bytes,
                           void *stream);
+/* Deferred d(pk) (csrc/attention.hip): the d(pk) pass of tsasr_relpos_attn_bwd feeds only the weight gradient of linear_pos. While
+ * tsasr_relpos_dpk_defer(1) is in force the call QUEUES the pass (workspace, key_lens and dpk of each call stay alive and untouched;
+ * dpk is not written yet) and tsasr_relpos_dpk_flush runs all queued passes as one launch + one launch for the sums of their partials
+ * (same blocks and order of sums as the per-call launches: bit-identical dpk). table_host: pinned host memory, table_dev: device memory,
+ * both >= tsasr_relpos_dpk_table_bytes(tsasr_relpos_dpk_pending()); the tsasr_wgrad_flush protocol under stream capture. */
+int tsasr_relpos_dpk_defer(int on);
+int tsasr_relpos_dpk_pending(void);
+size_t tsasr_relpos_dpk_table_bytes(int max_jobs);
+int tsasr_relpos_dpk_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
+void tsasr_relpos_dpk_discard(void);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093

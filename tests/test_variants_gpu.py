@@ -324,3 +324,40 @@ def test_config1_full_size_whole_model_properties():
         del b2
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert runs[0][0][1] != runs[0][0][0] and all(np.isfinite(runs[0][0]))
+
+
+def test_deferred_grouped_dpk_is_bit_identical_to_per_layer_launches(monkeypatch):
+    """The d(pk) passes of the attention backward are queued during the arena's backward and run as ONE grouped launch in front of the
+    grouped weight gradients (csrc/attention.hip, tsasr_relpos_dpk_defer / _flush; ops.dpk_flush): same blocks, same arithmetic, same order
+    of sums as the per-layer launches - every gradient of the step, linear_pos.weight's included, must be bit-identical with the knob
+    off; and the deferred path must really have been taken (2 + 2 layers queued at configs[0])."""
+    ops = importlib.import_module("ts-asr_amd.ops")
+    capi = importlib.import_module("ts-asr_amd._capi")
+    core = importlib.import_module("ts-asr_amd.core")
+    inp = golden_inputs()
+    grads, seen = {}, {}
+    real_flush = ops.dpk_flush
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_DPK_DEFER", flag)
+        pend = []
+        monkeypatch.setattr(ops, "dpk_flush", lambda pend=pend: (pend.append(capi.lib().tsasr_relpos_dpk_pending()), real_flush())[1])
+        brain, h = entry._config1_brain(DEV, "bf16")
+        brain.modules.train()
+        brain.on_fit_start()
+        ops.begin_step(DEV)
+        brain.arena.begin_backward(False)
+        batch = make_batch(inp)
+        out = brain.compute_forward(batch, core.Stage.TRAIN)
+        loss = brain.compute_objectives(out, batch, core.Stage.TRAIN)
+        loss.backward()
+        for s_ in brain._aux_streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        brain.arena.finish_backward()
+        torch.cuda.synchronize()
+        grads[flag] = {f"{mn}.{k}": p.grad.detach().clone() for mn, mod in brain.modules.items() for k, p in mod.named_parameters() if p.requires_grad}
+        seen[flag] = sum(pend)
+        assert capi.lib().tsasr_relpos_dpk_pending() == 0
+    assert seen[True] == 4 and seen[False] == 0, seen          # 2 mixture + 2 speaker layers went through the grouped launch
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
+    assert float(grads[True]["encoder.layers.0.mha_layer.linear_pos.weight"].abs().max()) > 0

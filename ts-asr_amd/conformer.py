@@ -106,14 +106,19 @@ class ConformerEncoder(nn.Module):
             state.update(x=x, pos=None, inject_first=True)
             return state
         pos = self.positional_encoding(x)
-        state.update(x=x, pos=pos)
+        state.update(x=x, pos=pos, pks=self._project_pos(pos))
         return self._run_layers(state, speaker_embs, speaker_embs_length, stop_at_injection=True)
+
+    def _project_pos(self, pos):
+        """Every layer's projected positional table, made ahead of the first layer (RelPosMHAXL.project_pos)."""
+        return [layer.mha_layer.project_pos(pos) for layer in self.layers]
 
     def forward_post(self, state, speaker_embs=None, speaker_embs_length=None):
         if state["inject_first"]:
             speaker_embs = speaker_embs() if callable(speaker_embs) else speaker_embs
             state["x"] = self._inject_speaker_emb(state["x"], speaker_embs, speaker_embs_length)
             state["pos"] = self.positional_encoding(state["x"])
+            state["pks"] = self._project_pos(state["pos"])
             state["inject_first"] = False
         state = self._run_layers(state, speaker_embs, speaker_embs_length, stop_at_injection=False)
         x = self.norm(state["x"]) if state["pre"] is None else state["pre"]
@@ -121,6 +126,7 @@ class ConformerEncoder(nn.Module):
 
     def _run_layers(self, state, speaker_embs, speaker_embs_length, stop_at_injection):
         x, pos, valid, pre, n = state["x"], state["pos"], state["valid"], state["pre"], len(self.layers)
+        pks = state.get("pks") or [None] * n
         return_attn = state["return_attn"]
         i = state["next"]
         if state.get("pending_injection"):   # forward_pre stopped right in front of this injection
@@ -133,8 +139,8 @@ class ConformerEncoder(nn.Module):
             # a layer's norm2 is followed by another LayerNorm of the same rows - the next layer's first macaron LayerNorm, or the final
             # norm (models/conformer.py:223-233) - unless the speaker embedding is injected in between: one launch for the pair
             nxt = None if inject else (self.norm.norm if i == n - 1 else self.layers[i + 1].ffn_module1[0])
-            x, attn, pre = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre, next_ln=nxt) if nxt is not None \
-                else layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre) + (None,)
+            x, attn, pre = layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre, next_ln=nxt, pk=pks[i]) if nxt is not None \
+                else layer(x, pos_embs=pos, valid_lens=valid, need_attn=return_attn, prenorm=pre, pk=pks[i]) + (None,)
             if return_attn:
                 state["attns"].append(attn.detach())
             i += 1

@@ -23,8 +23,10 @@
 // qkv layout: [B, T, H, 3*Dh] with Q|K|V interleaved per head (attention.py:549-553); pk: [2T-1, H*Dh];
 // pos_bias_u/v: the (Dh, H) parameter's storage reinterpreted as [H, Dh] (a view, not a transpose; attention.py:586-592).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -1119,15 +1121,16 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
 #define SH_LD 136
 #define DPK_LD 72
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ ds, const T *__restrict__ qv /*[H][B*T][Dh]*/,
-                                                         const int32_t *__restrict__ key_lens, float *__restrict__ part /*[G][R][H*64]*/,
-                                                         int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup, int isplit,
-                                                         int i_span) {
-    // isplit > 1 (long sequences, few utterances): blockIdx.z = utterance group * isplit + query range; a workgroup walks the query
-    // blocks of [ipart * i_span, (ipart + 1) * i_span) only - the band rows around r = T-1 are reached by every query block
+__device__ __forceinline__ void dpk_body(const T *__restrict__ ds, const T *__restrict__ qv /*[H][B*T][Dh]*/,
+                                         const int32_t *__restrict__ key_lens, float *__restrict__ part /*[G][R][H*64]*/,
+                                         int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup, int isplit, int i_span,
+                                         int bx, int by, int bz) {
+    // (bx, by, bz) = the block index of the one-job launch; isplit > 1 (long sequences, few utterances): bz = utterance group * isplit +
+    // query range; a workgroup walks the query blocks of [ipart * i_span, (ipart + 1) * i_span) only - the band rows around r = T-1 are
+    // reached by every query block
     __shared__ __attribute__((aligned(16))) T raw[64 * SH_LD];
     __shared__ __attribute__((aligned(16))) bf16_t a_tile[64 * DPK_LD], b_tile[64 * DPK_LD];
-    const int r0 = blockIdx.x * 64, h = blockIdx.y, grp = blockIdx.z / isplit, ipart = blockIdx.z % isplit;
+    const int r0 = bx * 64, h = by, grp = bz / isplit, ipart = bz % isplit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int rblk = wave & 1, dblk = wave >> 1;
     const int R = 2 * Tn - 1;
@@ -1192,7 +1195,7 @@ __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ d
         }
     }
     // accumulator: rows = band rows 32*rblk + (g&3) + 8(g>>2) + 4hh, column = head dim 32*dblk + r
-    float *pw = part + ((long long)blockIdx.z * R) * (H * 64) + h * 64 + 32 * dblk + r;
+    float *pw = part + ((long long)bz * R) * (H * 64) + h * 64 + 32 * dblk + r;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         const int rg = r0 + 32 * rblk + (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -1200,11 +1203,18 @@ __global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ d
     }
 }
 
-// dpk[r][h*Dh + d] = sum over the utterance groups of part[g][r][h*64 + d], written in the io dtype
 template <typename T>
-__global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict__ part, T *__restrict__ dpk, int R, int H, int Dh, int G) {
+__global__ __launch_bounds__(256) void relpos_dpk_kernel(const T *__restrict__ ds, const T *__restrict__ qv, const int32_t *__restrict__ key_lens,
+                                                         float *__restrict__ part, int Bn, int Tn, int Tp, int H, int Dh, int causal, int bgroup,
+                                                         int isplit, int i_span) {
+    dpk_body<T>(ds, qv, key_lens, part, Bn, Tn, Tp, H, Dh, causal, bgroup, isplit, i_span, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// dpk[r][h*Dh + d] = sum over the utterance groups of part[g][r][h*64 + d], written in the io dtype (blocks `blk` of `nblk` of one job)
+template <typename T>
+__device__ __forceinline__ void dpk_reduce_body(const float *__restrict__ part, T *__restrict__ dpk, int R, int H, int Dh, int G, int blk, int nblk) {
     const long long n = (long long)R * H * 64;
-    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    for (long long e = blk * 256LL + threadIdx.x; e < n; e += (long long)nblk * 256) {
         const int c = (int)(e % (H * 64)), d = c & 63, hq = c >> 6;
         const long long rr = e / (H * 64);
         if (d >= Dh) continue;
@@ -1212,6 +1222,44 @@ __global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict
         for (int g = 0; g < G; ++g) sum += part[(long long)g * n + e];
         st1(dpk + rr * (H * Dh) + hq * Dh + d, sum);
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dpk_reduce_kernel(const float *__restrict__ part, T *__restrict__ dpk, int R, int H, int Dh, int G) {
+    dpk_reduce_body<T>(part, dpk, R, H, Dh, G, blockIdx.x, gridDim.x);
+}
+
+// ---- deferred d(pk): the pass feeds nothing in backward but the weight gradient of linear_pos (pos_embs carries no gradient), so the
+// training step only QUEUES it (tsasr_relpos_dpk_defer) and runs the passes of all layers as ONE launch (+ one for the sums of the
+// partials) right before the grouped weight-gradient launch that consumes them: 12 + 6 pairs of latency-bound launches (25 + 10 us and
+// 13 + 11 us per layer at configs[1], two dependent launch gaps each) leave the critical path of the encoder's backward, and the one
+// launch fills the chip. Same blocks, same arithmetic, same order of sums as the per-layer launches: bit-identical d(pk).
+struct DpkJob {
+    const void *ds, *qv;
+    const int32_t *key_lens;
+    float *part;
+    void *dpk;
+    int Bn, Tn, Tp, H, Dh, causal, bgroup, isplit, i_span, G, nbx, io_dtype;
+    int tile0, ntiles, rtile0, rtiles;      // first block / block count of this job in the grouped pass and in the grouped reduction
+};
+
+__device__ __forceinline__ int dpk_find_job(const DpkJob *__restrict__ jobs, int njobs, int bid, bool reduce) {
+    int k = 0;
+    while (k + 1 < njobs && (reduce ? jobs[k + 1].rtile0 : jobs[k + 1].tile0) <= bid) ++k;
+    return __builtin_amdgcn_readfirstlane(k);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_dpk_group_kernel(const DpkJob *__restrict__ jobs, int njobs) {
+    const DpkJob j = jobs[dpk_find_job(jobs, njobs, blockIdx.x, false)];
+    const int lid = blockIdx.x - j.tile0;
+    dpk_body<T>((const T *)j.ds, (const T *)j.qv, j.key_lens, j.part, j.Bn, j.Tn, j.Tp, j.H, j.Dh, j.causal, j.bgroup, j.isplit, j.i_span,
+                lid % j.nbx, (lid / j.nbx) % j.H, lid / (j.nbx * j.H));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dpk_reduce_group_kernel(const DpkJob *__restrict__ jobs, int njobs) {
+    const DpkJob j = jobs[dpk_find_job(jobs, njobs, blockIdx.x, true)];
+    dpk_reduce_body<T>(j.part, (T *)j.dpk, 2 * j.Tn - 1, j.H, j.Dh, j.G, blockIdx.x - j.rtile0, j.rtiles);
 }
 
 extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
@@ -1280,6 +1328,9 @@ static size_t attn_part_bytes(int B, int T, int H) {
     return align_up((size_t)cdiv(B, attn_bgroup(B, T)) * attn_dpk_max_isplit(T) * (2 * T - 1) * H * 64 * sizeof(float), 256);
 }
 
+static std::vector<DpkJob> g_dpk_jobs;
+static int g_dpk_defer = 0;
+
 __global__ void attn_zero_kernel(uint4 *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -1326,6 +1377,12 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
                                                                                                           nparts, part_keys);
     relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
                                                                           qv, Tn, Tp, H, Dh, causal);
+    if (g_dpk_defer) {   // queued: both passes run in tsasr_relpos_dpk_flush (workspace, key_lens and dpk stay alive until then)
+        DpkJob j{ds, qv, key_lens, part, dpk, B, Tn, Tp, H, Dh, causal, bg, isplit, i_span, G * isplit, cdiv(R, 64),
+                 sizeof(T) == 2 ? TSASR_BF16 : TSASR_F32, 0, cdiv(R, 64) * H * G * isplit, 0, std::min(1024, cdiv(R * H * 64, 256))};
+        g_dpk_jobs.push_back(j);
+        return;
+    }
     relpos_dpk_kernel<T><<<dim3(cdiv(R, 64), H, G * isplit), 256, 0, st>>>(ds, qv, key_lens, part, B, Tn, Tp, H, Dh, causal, bg, isplit, i_span);
     dpk_reduce_kernel<T><<<std::min(1024, cdiv(R * H * 64, 256)), 256, 0, st>>>(part, (T *)dpk, R, H, Dh, G * isplit);
 }
@@ -1441,6 +1498,60 @@ int tsasr_relpos_attn_bwd(const void *qkv, const void *pk, const float *bias_u, 
         tsasr_reduce_submit(slab + h * 128 + 64, d_bias_v + h * Dh, (long long)H * 128, AT_NW * B * nqt, Dh, 0, st);
     }
     TSASR_CHECK_LAUNCH("tsasr_relpos_attn_bwd");
+    return 0;
+}
+
+/* 1: tsasr_relpos_attn_bwd queues its d(pk) pass instead of launching it (the workspace, key_lens and dpk of every queued call must stay
+ * alive and untouched until tsasr_relpos_dpk_flush); 0: launched inside the call (default). dpk is NOT written until the flush. */
+int tsasr_relpos_dpk_defer(int on) {
+    TSASR_CHECK_ARG(on || g_dpk_jobs.empty(), "tsasr_relpos_dpk_defer(0) with %d passes still queued: call tsasr_relpos_dpk_flush first", (int)g_dpk_jobs.size());
+    g_dpk_defer = on ? 1 : 0;
+    return 0;
+}
+int tsasr_relpos_dpk_pending(void) { return (int)g_dpk_jobs.size(); }
+size_t tsasr_relpos_dpk_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof(DpkJob); }
+void tsasr_relpos_dpk_discard(void) { g_dpk_jobs.clear(); g_dpk_defer = 0; }
+
+/* Runs every queued d(pk) pass: ONE launch for the passes, one for the sums of their partials (per io dtype present). table_host: PINNED
+ * host memory, table_dev: device memory, both >= tsasr_relpos_dpk_table_bytes(tsasr_relpos_dpk_pending()); copied host -> device on `stream`
+ * except while it is being captured (then the caller uploads table_host after the capture: the protocol of tsasr_wgrad_flush). */
+int tsasr_relpos_dpk_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream) {
+    if (g_dpk_jobs.empty()) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    std::stable_sort(g_dpk_jobs.begin(), g_dpk_jobs.end(), [](const DpkJob &a, const DpkJob &b) { return a.io_dtype < b.io_dtype; });
+    const size_t need = g_dpk_jobs.size() * sizeof(DpkJob);
+    TSASR_CHECK_ARG(table_host && table_dev && table_bytes >= need, "tsasr_relpos_dpk_flush: job table too small (%zu < %zu bytes)", table_bytes, need);
+    struct Group { int first, count, tiles, rtiles, dtype; };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < g_dpk_jobs.size(); ++i) {
+        DpkJob &j = g_dpk_jobs[i];
+        if (groups.empty() || groups.back().dtype != j.io_dtype) groups.push_back(Group{(int)i, 0, 0, 0, j.io_dtype});
+        Group &g = groups.back();
+        j.tile0 = g.tiles; j.rtile0 = g.rtiles;
+        g.tiles += j.ntiles; g.rtiles += j.rtiles; g.count += 1;
+    }
+    memcpy(table_host, g_dpk_jobs.data(), need);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone) {
+        hipError_t e = hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            tsasr_set_error("tsasr_relpos_dpk_flush: job table upload failed: %s", hipGetErrorString(e));
+            return TSASR_E_LAUNCH;
+        }
+    }
+    for (const Group &g : groups) {
+        const DpkJob *tab = (const DpkJob *)table_dev + g.first;
+        if (g.dtype == TSASR_BF16) {
+            relpos_dpk_group_kernel<bf16_t><<<g.tiles, 256, 0, st>>>(tab, g.count);
+            dpk_reduce_group_kernel<bf16_t><<<g.rtiles, 256, 0, st>>>(tab, g.count);
+        } else {
+            relpos_dpk_group_kernel<float><<<g.tiles, 256, 0, st>>>(tab, g.count);
+            dpk_reduce_group_kernel<float><<<g.rtiles, 256, 0, st>>>(tab, g.count);
+        }
+    }
+    g_dpk_jobs.clear();
+    TSASR_CHECK_LAUNCH("tsasr_relpos_dpk_flush");
     return 0;
 }
 

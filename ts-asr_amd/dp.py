@@ -392,6 +392,7 @@ class GradArena:
         if not self._sync_this_step and self.device.type == "cuda":   # (a bucket may only be sent once its gradients are final)
             from . import ops
             ops.reduce_defer_begin(self.device)
+            ops.dpk_defer_begin(self.device)      # d(pk) passes of the attention backward: queued, run grouped in front of the weight gradients
         for b in self.buckets:
             b["left"], b["sent"], b["queued"], b["ready"] = sum(self._contrib.get(i, 1) for i in b["ids"]), False, 0, False
         self._next_send = 0
@@ -451,6 +452,7 @@ class GradArena:
                 if self.wgrad_stream is not None:
                     torch.cuda.current_stream().wait_stream(self.wgrad_stream)
                 self._wgrad_side_busy, self._wgrad_hold = False, []
+            ops.dpk_defer_end()         # (nothing is left unless no weight-gradient launch followed the last attention backward)
             ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()
         self.in_backward = False

@@ -450,11 +450,20 @@ class RelPosMHAXL(nn.Module):
         out = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
         return (out, attn) if return_attn_weights else out
 
-    def _context(self, x, pos_embs, key_lens, causal, need_weights):
+    def project_pos(self, pos_embs):
+        """(pk, deferrable): pk = linear_pos(pos_embs) [2T-1, D] - depends on the weights and the positional table only, so the encoder
+        computes it for ALL its layers ahead of the first one (the main stream then does it while it would otherwise wait for the speaker
+        branch at the injection, instead of once per layer on the critical path). deferrable: d(pk) has ONE reader - that weight's
+        gradient - when pk is the HIP GEMM of a leaf weight over the gradient-free table (ops._RelPosAttnFn.backward)."""
+        pos = _pos_cd(pos_embs)
+        w = self.linear_pos.weight
+        return ops.matmul_nt(pos, w), bool(ops._gemm_ok(pos, w) and w.is_leaf and not pos.requires_grad)
+
+    def _context(self, x, pos_embs, key_lens, causal, need_weights, pk=None):
         qkv = ops.matmul_nt(x, self.in_proj_weight)                          # [B,T,H*3*Dh] per-head interleaved Q|K|V
-        pk = ops.matmul_nt(_pos_cd(pos_embs), self.linear_pos.weight)        # [2T-1, D]
+        pk, deferrable = self.project_pos(pos_embs) if pk is None else pk
         return ops.relpos_attention(qkv, pk, self.pos_bias_u, self.pos_bias_v, key_lens, self.num_heads, self.scale, causal,
-                                    self.dropout if self.training else 0.0, need_weights)
+                                    self.dropout if self.training else 0.0, need_weights, dpk_deferrable=deferrable)
 
     def forward_add(self, x, res, pos_embs, key_lens=None, causal=False, need_weights=False):
         """res + out_proj(attention(x)) with the projection bias and the residual add in one epilogue pass."""
@@ -540,7 +549,7 @@ class ConformerEncoderLayer(nn.Module):
         return ops.dropout_add(y, pff[3].bias, x, 0.5, self.dropout, self.training)
 
     def forward(self, x, src_mask=None, src_key_padding_mask=None, pos_embs=None, valid_lens=None, need_attn=True, prenorm=None,
-                next_ln=None):
+                next_ln=None, pk=None):
         """Returns (x, attention weights [B,H,T,T] or None). The reference always materialises the weights
         (Conformer.py:247-254); the encoder passes need_attn=False unless return_attn is requested.
         Every ``residual + branch`` of Conformer.py:243-259 is fused with the LayerNorm that reads it (ops.add_layer_norm).
@@ -560,7 +569,7 @@ class ConformerEncoderLayer(nn.Module):
         h = ops.ffn_core(y, pff1[0].weight, pff1[0].bias, pff1[3].weight, self.slope, p, tr)
         x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
         causal = self.causal or src_mask is not None
-        o, attn = mha._context(y, pos_embs, valid_lens, (max(self.chunk_size, 1) if causal else 0), need_attn)
+        o, attn = mha._context(y, pos_embs, valid_lens, (max(self.chunk_size, 1) if causal else 0), need_attn, pk=pk)   # pk: mha.project_pos(pos_embs), made ahead by the encoder
         x, y = ops.add_layer_norm(ops.matmul_nt(o, mha.out_proj.weight), mha.out_proj.bias, x, conv.layer_norm)   # + skip ; conv LN
         c = conv.core(y)
         x, y = ops.add_layer_norm(c, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)          # + conv ; ffn2 LN

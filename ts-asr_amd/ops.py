@@ -167,14 +167,14 @@ def reduce_flush_own_stream():
 def upload_captured_tables():
     """After a stream capture: copy the job tables the captured flushes filled on the host to their device twins (a graph replay
     carries no memcpy node; each captured graph owns its pair for life)."""
-    for st in (_DEFER, _WG):
+    for st in (_DEFER, _WG, _DPK):
         if st["ring"] is not None:
             st["ring"].upload_captured()
 
 
 def reserve_captured_tables(n):
     """Before a step capture: job-table pairs for up to ``n`` captured flushes of each batched launch (TableRing.reserve_captured)."""
-    for st in (_DEFER, _WG):
+    for st in (_DEFER, _WG, _DPK):
         if st["ring"] is not None:
             st["ring"].reserve_captured(n)
 
@@ -184,6 +184,8 @@ def discard_queues():
     operands, leave deferral off - the next step starts from a clean state."""
     C.lib().tsasr_wgrad_discard()
     C.lib().tsasr_reduce_discard()
+    C.lib().tsasr_relpos_dpk_discard()
+    _DPK["on"] = False
     _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"], _WG["bytes"] = [], set(), [], 0.0, 0, 0.0
     _DEFER["keep"], _DEFER["on"] = [], False
 
@@ -243,11 +245,51 @@ def wgrad_pending():
     return len(_WG["params"])
 
 
+# Deferred d(pk) passes of the attention backward (csrc/attention.hip, tsasr_relpos_dpk_defer): queued per layer while the gradient arena
+# is in backward, run as one grouped launch right in front of the grouped weight-gradient launch that consumes their outputs.
+_DPK = {"ring": None, "on": False}
+_DPK_MAX_JOBS = 64
+_DPK_DEFER = os.environ.get("TSASR_DPK_DEFER", "1") != "0"   # A/B knob
+
+
+def dpk_defer_begin(device):
+    if not _DPK_DEFER or torch.device(device).type != "cuda":
+        return
+    if _DPK["ring"] is None:
+        _DPK["ring"] = TableRing(C.lib().tsasr_relpos_dpk_table_bytes(_DPK_MAX_JOBS), device)
+    C.check(C.lib().tsasr_relpos_dpk_defer(1), "tsasr_relpos_dpk_defer")
+    _DPK["on"] = True
+
+
+def dpk_deferring():
+    return _DPK["on"]
+
+
+def dpk_flush():
+    """Run every queued d(pk) pass now, on the current stream (two launches); a no-op when nothing is queued."""
+    if _DPK["ring"] is None or C.lib().tsasr_relpos_dpk_pending() == 0:
+        return
+    ring = _DPK["ring"]
+    k, host, dev, _ = ring.acquire()
+    with prof.region("relpos_dpk_group"):
+        C.check(C.lib().tsasr_relpos_dpk_flush(C.ptr(host), C.ptr(dev), host.numel(), C.stream_ptr()), "tsasr_relpos_dpk_flush")
+    ring.launched(k)
+
+
+def dpk_defer_end():
+    if not _DPK["on"]:
+        return
+    dpk_flush()
+    C.check(C.lib().tsasr_relpos_dpk_defer(0), "tsasr_relpos_dpk_defer")
+    _DPK["on"] = False
+
+
 def wgrad_flush(hold=None):
     """One launch for every queued weight gradient (on the current stream, which must be ordered after their producers); returns the
     parameters whose gradients it completed. `hold`: a list that takes over the operand references (a launch on a side stream: the
     caller releases them once the consumer stream has joined it)."""
     done = _WG["params"]
+    dpk_flush()      # queued d(pk) passes produce operands of the linear_pos weight gradients in this launch: they go first, same stream
     if done:
         ring = _WG["ring"]
         k, host, dev, _ = ring.acquire()
@@ -398,6 +440,7 @@ class _LinearFn(torch.autograd.Function):
                     and weight.grad.is_contiguous()):
                 _wgrad_into(sink, weight, weight.grad.view(N, K), dy2, x2)                           # grad += dy^T . x
             else:
+                dpk_flush()     # dy may be a deferred d(pk): the plain GEMM reads it now
                 dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
         return dx, dw
 
@@ -412,6 +455,7 @@ def _wgrad_into(sink, weight, grad2d, dy2, x2):
         _WG["bytes"] = _WG.get("bytes", 0.0) + 2.0 * M * (N + K) + 8.0 * N * K   # dy and x (bf16) read once, the fp32 gradient read and written
         sink.wgrad_queued(weight)
         return
+    dpk_flush()         # dy2 may be a deferred d(pk): the split-K GEMM below reads it now
     gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, defer_ok=True)
     sink.mark_ready(weight)
 
@@ -1273,8 +1317,9 @@ def frontend_convs(x, w1, b1, w2, b2, padding):
 # ---------------------------------------------------------------------------------------------------------
 class _RelPosAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed):
+    def forward(ctx, qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed, dpk_deferrable=False):
         C.require_gpu(qkv, pk)
+        ctx.dpk_deferrable = bool(dpk_deferrable)
         qkvc, pkc = qkv.contiguous(), pk.contiguous()
         B, T, D3 = qkvc.shape
         D = D3 // 3
@@ -1309,20 +1354,34 @@ class _RelPosAttnFn(torch.autograd.Function):
         du, dv = torch.empty_like(u), torch.empty_like(v)
         _keep(du, dv)
         ws = _ws(C.lib().tsasr_relpos_attn_bwd_workspace_bytes(B, T, H), qkvc.device)
+        # d(pk) feeds only linear_pos's weight gradient. When that consumer is the arena's queued grouped launch (the caller says so:
+        # pk came out of _LinearFn on a bf16 leaf weight) and reductions are being deferred (the workspace then outlives the step's
+        # backward), the pass is queued and runs grouped with every other layer's right before that launch (dpk_flush in wgrad_flush)
+        sink = _GRAD_SINK
+        defer = (ctx.dpk_deferrable and _DPK["on"] and _DEFER["on"] and sink is not None and getattr(sink, "in_backward", False)
+                 and getattr(sink, "collect_wgrads", False) and _WG["ring"] is not None and C.lib().tsasr_relpos_dpk_pending() < _DPK_MAX_JOBS)
+        if defer:
+            _keep(key_lens)               # the queued pass reads it at the flush, after autograd has released this node's saved tensors
+        if _DPK["on"] and not defer:      # this call launches its own pass (queued ones first: the switch refuses to go off over a queue)
+            dpk_flush()
+            C.check(C.lib().tsasr_relpos_dpk_defer(0), "tsasr_relpos_dpk_defer")
         with prof.region("relpos_attn_bwd"):
             C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
                                                   C.ptr(lse), C.ptr(dqkv), C.ptr(dpk), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
                                                   pdrop, seed, C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc), C.ptr(ws), ws.numel(), C.stream_ptr()),
                     "tsasr_relpos_attn_bwd")
-        return dqkv, dpk, _pgrad(pu, du), _pgrad(pv, dv), None, None, None, None, None, None
+        if _DPK["on"] and not defer:
+            C.check(C.lib().tsasr_relpos_dpk_defer(1), "tsasr_relpos_dpk_defer")     # (this call launched its pass itself)
+        return dqkv, dpk, _pgrad(pu, du), _pgrad(pv, dv), None, None, None, None, None, None, None
 
 
-def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights):
-    """Fused HIP kernels (forward and backward) unless the caller wants the [B,H,T,T] weights back (plots only)."""
+def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights, dpk_deferrable=False):
+    """Fused HIP kernels (forward and backward) unless the caller wants the [B,H,T,T] weights back (plots only). ``dpk_deferrable``:
+    the caller made ``pk`` with ops.matmul_nt on the HIP GEMM path and nothing else reads its gradient (see _RelPosAttnFn.backward)."""
     if need_weights:
         return _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights)
     p = float(dropout_p)
-    return _RelPosAttnFn.apply(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0), None
+    return _RelPosAttnFn.apply(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0, dpk_deferrable), None
 
 
 def _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights):
