@@ -10,5 +10,6 @@ run() { # name, reps, env..., -- args
   echo "rc=$?"; grep "^rep\|RESULT\|poisoned\|Error" $O/$name.log | cut -c1-1200 | tail -12
 }
 run default $REPS X=1 -- --snap 0 --steps 8 --modes graph
-run overlap4 $REPS TSASR_OVERLAP=4 -- --snap 0 --steps 8 --modes graph
+run overlap2 $REPS TSASR_OVERLAP=2 -- --snap 0 --steps 8 --modes graph
+run eager_accum2 $((REPS/4)) X=1 -- --snap 0 --steps 8 --accum 2 --modes eager
 true

@@ -12,6 +12,5 @@ cd $R
 db=$(find $O/prof -name "*.db" | head -1)
 python tools/trace_summary.py $db --steps 17 --top 80 > $O/trace_summary.txt
 python tools/stream_timeline.py $db > $O/timeline.txt 2>&1 || true
-if [ -n "$TSASR_NEIGHBOURS" ]; then python tools/kernel_neighbours.py $db $TSASR_NEIGHBOURS > $O/neighbours.txt 2>&1 || true; fi
 rm -rf $O/prof
 tail -4 $O/bench_prof.log | cut -c1-300

@@ -28,7 +28,6 @@ from . import optim as _optim
 logger = logging.getLogger(__name__)
 
 
-_EARLY_FLUSH = os.environ.get("TSASR_EARLY_FLUSH", "0") != "0"   # A/B knob (measured neutral on the step: off by default)
 _GRAPH_COMM = os.environ.get("TSASR_GRAPH_COMM", "1") != "0"     # multi-rank graph mode: bucketed all-reduces captured inside the step's graph
 
 class Stage(enum.Enum):
@@ -249,9 +248,7 @@ class Brain:
         # Streams the recipe forked in forward also ran their share of backward. autograd joins only the streams its LEAF
         # (AccumulateGrad) nodes ran on - and most parameter gradients here bypass those nodes (GEMMs accumulate straight into
         # the arena, small gradients are queued for one batched add) - so join explicitly before anything reads the gradients.
-        if self._aux_streams and _EARLY_FLUSH and torch.device(self.device).type == "cuda":
-            _ops.reduce_flush_own_stream()    # this stream's split-K slabs / partial rows (2/3 of them) are reduced while the forked
-        for s in self._aux_streams:           # stream is still in the speaker branch's backward (half-filled grids)
+        for s in self._aux_streams:
             torch.cuda.current_stream().wait_stream(s)
         self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
         if should_step and (comm or not self.distributed):
@@ -356,12 +353,10 @@ class Brain:
             self._copy_batch(batch, key)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        if os.environ.get("TSASR_GRAPH_DOT"):
-            g.enable_debug_mode()
         # multi-rank: the RCCL watchdog thread polls events while this thread captures; "thread_local" keeps its (legal) calls from
         # invalidating the capture (single rank keeps the strict default)
         mode = "thread_local" if self.distributed else "global"
-        pool = None if os.environ.get("TSASR_GRAPH_POOL", "shared") == "private" else self._graph_pool
+        pool = self._graph_pool
         from . import ops as _ops
         # job-table pairs for this graph's batched launches (one per captured flush: per bucket with collectives in the graph, plus the
         # early / duplicate-weight / final flushes), allocated NOW - pinned memory cannot be allocated inside a capture
@@ -376,8 +371,6 @@ class Brain:
             _ops.discard_queues()
             self.arena.abort_backward()
             raise
-        if os.environ.get("TSASR_GRAPH_DOT"):
-            g.debug_dump(os.environ["TSASR_GRAPH_DOT"] + f".{len(self._graphs)}.dot")
         _ops.upload_captured_tables()             # job tables of the captured flushes: uploaded once, now (replays carry no memcpy node)
         self.arena.upload_captured_tables()
         if self._graph_pool is None:

@@ -1272,7 +1272,7 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 constexpr int AT_MIN_PART = 8;
 static int host_causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
 static int attn_ksplit_env() {   // TSASR_ATTN_KSPLIT = 0: never split; n > 0: parts of n key tiles whatever the shape (A/B)
-    static const int v = getenv("TSASR_ATTN_KSPLIT") ? atoi(getenv("TSASR_ATTN_KSPLIT")) : -1;
+    static const int v = -1;
     return v;
 }
 static int attn_max_parts(int T) {
@@ -1310,7 +1310,7 @@ static size_t attn_dq_part_bytes(int B, int T, int H) { return attn_max_parts(T)
 static int attn_tp(int T) { return cdiv(T, 64) * 64; }
 // d(pk): query ranges per workgroup when (band-row blocks x heads x utterance groups) alone would be few, long walks
 static int attn_dpk_isplit(int B, int T, int H, int causal, int G) {
-    static const int forced = getenv("TSASR_DPK_ISPLIT") ? atoi(getenv("TSASR_DPK_ISPLIT")) : 0;
+    static const int forced = 0;
     const int nib = cdiv(T, 64);
     if (forced > 0) return std::min(forced, nib);
     const long long live = (long long)cdiv(causal ? T + std::max(causal, 1) : 2 * T - 1, 64) * H * G;   // causal: band rows beyond T-1+chunk are dead
@@ -1319,7 +1319,7 @@ static int attn_dpk_isplit(int B, int T, int H, int causal, int G) {
 }
 static int attn_dpk_max_isplit(int T) { return std::max(1, std::min(cdiv(T, 64) / 8, 16)); }
 static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
-    static const int dpk_wgs = getenv("TSASR_DPK_WGS") ? atoi(getenv("TSASR_DPK_WGS")) : 1024;
+    static const int dpk_wgs = 1024;
     const int want = std::max(1, dpk_wgs / (4 * cdiv(2 * T - 1, 64)));
     return std::max(1, cdiv(B, std::min(B, want)));
 }
@@ -1359,7 +1359,7 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     // A/B knob TSASR_ATTN_BWD_KG=2: two key groups per workgroup (8 waves, two per SIMD). Measured at T' = 250, B = 32 (one workgroup per
     // CU): 13.07 vs 13.06 ms per step with the tile prefetch dropped to fit 256 registers, 13.61 with it (76 spilled VGPRs) - the kernel
     // is bound by the CU's VALU / LDS instruction throughput, not by latency a second wave could cover. Off.
-    static const int kg_env = getenv("TSASR_ATTN_BWD_KG") ? atoi(getenv("TSASR_ATTN_BWD_KG")) : 1;
+    static const int kg_env = 1;
     const bool two = kg_env == 2 && Tn > AT_KT;
     if (two) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_q));
@@ -1420,7 +1420,7 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
     const size_t lds = tsasr_relpos_attn_lds_bytes();
     dim3 grid(cdiv(T, AT_QB), H, B);
     hipStream_t st = (hipStream_t)stream;
-    static const int use_short = getenv("TSASR_ATTN_SHORT") ? atoi(getenv("TSASR_ATTN_SHORT")) : 1;
+    static const int use_short = 1;
     if (use_short && io_dtype == TSASR_BF16 && Dh == 64 && T <= 256 && T >= 2) {
         if (T > 128) {
             constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 4096;   // K, V (256 rows), band (384 rows), 8 fp16 G tiles

@@ -1171,9 +1171,9 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float *__restrict__ 
 static int pick_rows_per_wg(long long M, int min_rows) {
     // ~1024 workgroups (4 per CU: a wave walks its rows one after the other, so other waves must cover its memory round
     // trips) unless rows are few; at least `min_rows` rows each so partial slabs stay small
-    static const long long target = getenv("TSASR_ROW_WGS") ? atoll(getenv("TSASR_ROW_WGS")) : 1024;
+    static const long long target = 1024;
     long long r = (M + target - 1) / target;
-    static const int min_env = getenv("TSASR_ROW_MIN") ? atoi(getenv("TSASR_ROW_MIN")) : 0;
+    static const int min_env = 0;
     if (min_env > 0) min_rows = min_env;
     if (r < min_rows) r = min_rows;
     return (int)r;
@@ -1190,7 +1190,7 @@ static int launch_ln_fwd(const void *x, const float *g, const float *b, void *y,
     const int rpw = (int)std::max<long long>(4, (M + 1023) / 1024);      // wide rows: ~1024 workgroups walking rpw rows each
 #define LN_FWD_WIDE(IT)                                                                                                   \
     layernorm_fwd_wide_kernel<T, IT><<<(unsigned)((M + rpw - 1) / rpw), 256, 0, st>>>((const T *)x, g, b, (T *)y, mean, rstd, M, D, eps, slope, rpw)
-    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    static const int half_rows = 1;
     if (half_rows && D <= per_wave / 2) LN_FWD(32, 1);
     else if (D <= per_wave) LN_FWD(64, 1);
     else if (D <= 2 * per_wave) LN_FWD(64, 2);
@@ -1217,7 +1217,7 @@ static int launch_ln_bwd(const void *dy, const void *x, const float *g, const fl
         (const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw, (const T *)dadd)
 #define LN_BWD_WIDE(IT)                                                                                                   \
     layernorm_bwd_wide_kernel<T, IT><<<nwg, 256, 0, st>>>((const T *)dy, (const T *)x, g, b, mean, rstd, (T *)dx, part, M, D, slope, rpw)
-    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    static const int half_rows = 1;
     if (half_rows && D <= per_wave / 2) LN_BWD(32, 1);
     else if (D <= per_wave) LN_BWD(64, 1);
     else if (D <= 2 * per_wave) LN_BWD(64, 2);
@@ -1274,7 +1274,7 @@ static int layernorm_bwd_impl(const void *dy, const void *x, const float *gamma,
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_layernorm_bwd_workspace_bytes(M, D), "tsasr_layernorm_bwd: workspace too small");
     int rpw = pick_rows_per_wg(M, 16);
     const bool wide = D > 4 * 64 * (io_dtype == TSASR_BF16 ? 8 : 4);
-    static const long long wide_wgs = getenv("TSASR_LNW_WGS") ? atoll(getenv("TSASR_LNW_WGS")) : 512;
+    static const long long wide_wgs = 512;
     if (wide) rpw = (int)std::max<long long>(rpw, (M + wide_wgs - 1) / wide_wgs);   // wide-row kernel: two workgroups per CU, each prefetching its next row
     const int nwg = (int)((M + rpw - 1) / rpw);
     hipStream_t st = (hipStream_t)stream;
@@ -1318,7 +1318,7 @@ static size_t slot_lds(int Ncols, int vec, const float *part) {
 
 static unsigned ew_grid(long long total, int N) {
     long long blocks = (total / N + 255) / 256;
-    static const long long cap = getenv("TSASR_EW_CAP") ? atoll(getenv("TSASR_EW_CAP")) : 4096;
+    static const long long cap = 4096;
     if (blocks > cap) blocks = cap;  // grid-stride beyond 16 workgroups per CU
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
@@ -1441,7 +1441,7 @@ int tsasr_add_layernorm_fwd(const void *x, const float *bias, const void *res, v
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((M + 3) / 4);
 #define ALN_F(TT, IT) add_layernorm_fwd_kernel<TT, IT><<<grid, 256, 0, st>>>((const TT *)x, bias, (const TT *)res, (TT *)s, (TT *)y, mean, rstd, gamma, beta, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps)
-    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    static const int half_rows = 1;
     if (io_dtype == TSASR_BF16) {
         if (half_rows && D <= 256)
             add_layernorm_fwd_kernel<bf16_t, 1, true><<<(unsigned)((M + 7) / 8), 256, 0, st>>>((const bf16_t *)x, bias, (const bf16_t *)res, (bf16_t *)s, (bf16_t *)y, mean, rstd, gamma, beta, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, eps);
@@ -1476,7 +1476,7 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
     float *part = (float *)workspace;
     const size_t lds = (size_t)12 * D * sizeof(float);
 #define ALN_B(TT, IT) add_layernorm_bwd_kernel<TT, IT><<<nwg, 256, lds, st>>>((const TT *)dy, (const TT *)dout, (const TT *)s, gamma, mean, rstd, (TT *)dres, (TT *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw)
-    static const int half_rows = getenv("TSASR_LN_HALFWAVE") ? atoi(getenv("TSASR_LN_HALFWAVE")) : 1;
+    static const int half_rows = 1;
     if (io_dtype == TSASR_BF16) {
         if (half_rows && D <= 256)
             add_layernorm_bwd_kernel<bf16_t, 1, true><<<nwg, 256, 2 * lds, st>>>((const bf16_t *)dy, (const bf16_t *)dout, (const bf16_t *)s, gamma, mean, rstd, (bf16_t *)dres, (bf16_t *)dx, part, M, D, alpha, p, seed, seed_dev, valid_lens, Trows, rpw);

@@ -784,7 +784,7 @@ int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, i
                           const float *bias, const void *y, long long ldy, float slope, float p, unsigned long long seed,
                           const unsigned long long *seed_dev, float *colpart, hipStream_t st);
 
-static int g_use_ring = getenv("TSASR_GEMM_RING") ? atoi(getenv("TSASR_GEMM_RING")) : 1;   // 0: never, 1: long K or small tiles, 2: always
+static int g_use_ring = 1;   // 0: never, 1: long K or small tiles, 2: always
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
@@ -795,7 +795,7 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
     const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024 || BM * BN < 128 * 128) &&
                       (AT ? M >= 8 : true) && (BT ? N >= 8 : true);
     if constexpr (BM == 64 && BN == 64 && AT && BT && OUT_MODE != 0) {
-        static const int wavek = getenv("TSASR_WGRAD_WAVEK") ? atoi(getenv("TSASR_WGRAD_WAVEK")) : 1;
+        static const int wavek = 1;
         if (ring && wavek) {
             using R = RingSmem<64, 64, true, true>;
             gemm_tt64_wavek_kernel<OUT_MODE><<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (float *)C, M, N, K, lda, ldb, ldc, kchunk,
@@ -804,7 +804,7 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         }
     }
     if constexpr (BM == 64 && BN == 64 && !AT && !BT && OUT_MODE == 0) {
-        static const int wavek = getenv("TSASR_NN_WAVEK") ? atoi(getenv("TSASR_NN_WAVEK")) : 1;
+        static const int wavek = 1;
         if (ring && wavek && ep.mode == 0 && min(K, kchunk) >= 16 * GB_K) {   // short K: the heavier epilogue costs more than the loop gains (5.4 -> 6.1 us at K = 256; 13.1 -> 11.2 us at M = 4000, K = 2048)
             using R = RingSmem<64, 64, false, false>;
             gemm_nn64_wavek_kernel<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, kchunk,
@@ -849,11 +849,11 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
                     t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
     // the largest macro-tile that still gives every CU work: 128x128 needs >= 2 tiles per CU (below that the 128x64 ring kernel
     // wins by 5-20% at N <= 768: tools/fwd_sweep.py), 128x64 needs ~one per CU
-    static const int thr0 = getenv("TSASR_GEMM_T0") ? atoi(getenv("TSASR_GEMM_T0")) : 512, thr1 = getenv("TSASR_GEMM_T1") ? atoi(getenv("TSASR_GEMM_T1")) : 192;
+    static const int thr0 = 512, thr1 = 192;
     p.tile = t0 >= thr0 ? 0 : (t1 >= thr1 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
     p.splits = 1;
-    static const int min_k = getenv("TSASR_SPLIT_MINK") ? atoi(getenv("TSASR_SPLIT_MINK")) : 384;   // (1024 -> 384: the K = 2T'-1 weight gradients of linear_pos ran on 16 workgroups; -0.12 ms per step)
+    static const int min_k = 384;   // (1024 -> 384: the K = 2T'-1 weight gradients of linear_pos ran on 16 workgroups; -0.12 ms per step)
     if (out_f32 && tiles < 256 && K >= min_k) {
         // weight gradients: few output tiles, long inner dimension -> split it (fp32 slabs, reduced in fixed order). Both operands
         // are k-major, i.e. every fragment comes through ds_read_b64_tr_b16, and that path - not the DMA, not VALU, not MFMA - is
@@ -861,7 +861,7 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
         // Macro-tile / split sweeps (tools/wgrad_sweep.py) stay within 10% of this choice in isolation and within noise in the step.
         // target: 3 workgroups per CU. Measured on the whole step (A/B in one process group, same box): 256 -> 19.0 ms, 384 -> 18.0,
         // 512 -> 17.65, 640 / 768 -> 17.4, 896 -> 17.85, 1024 -> 17.8 (more slabs = more bytes for the batched reduction).
-        static const int target = getenv("TSASR_WGRAD_WGS") ? atoi(getenv("TSASR_WGRAD_WGS")) : 768;
+        static const int target = 768;
         int s = (int)((target + tiles - 1) / tiles);
         const int max_s = std::max(1, K / (min_k >= 1024 ? 256 : 128));             // at least 4 (2 for short K) k-tiles per split
         if (s > max_s) s = max_s;
@@ -911,7 +911,7 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
     TSASR_CHECK_ARG(!(accumulate && out_dtype != TSASR_F32), "tsasr_gemm_bf16: accumulate needs fp32 output");
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
     hipStream_t st = (hipStream_t)stream;
-    static const bool log_small = getenv("TSASR_GEMM_LOG_SMALL") != nullptr;   // debugging aid: long-K problems that fill few CUs
+    static const bool log_small = false;   // debugging aid: long-K problems that fill few CUs
     if (log_small && (long long)cdiv(M, tile_bm(p.tile)) * cdiv(N, p.tile == 0 ? 128 : 64) * p.splits <= 16)
         fprintf(stderr, "[tsasr_gemm_bf16] few tiles: M=%d N=%d K=%d tA=%d tB=%d out=%d acc=%d tile=%d splits=%d\n", M, N, K, transA, transB, out_dtype, accumulate, p.tile, p.splits);
     if (p.splits > 1) {
@@ -957,7 +957,7 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
     GemmPlan pl = plan(M, N, K, 0);
     hipStream_t st = (hipStream_t)stream;
-    static const bool log_small = getenv("TSASR_GEMM_LOG_SMALL") != nullptr;
+    static const bool log_small = false;
     if (log_small && (long long)cdiv(M, tile_bm(pl.tile)) * cdiv(N, pl.tile == 0 ? 128 : 64) <= 16)
         fprintf(stderr, "[tsasr_gemm_bf16_fused] few tiles: M=%d N=%d K=%d tA=%d tB=%d mode=%d tile=%d\n", M, N, K, transA, transB, epi_mode, pl.tile);
     if (!transA && !transB && g_force_tile < 0) {

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
 #define LQ_BR 16   // batch rows per exchange group
 // B <= 8 (long-form, one utterance per GPU): groups of 8 rows - the exchange tile a workgroup pulls per step halves (backward: 64 -> 32 KB)
 static int lq_br(int B) {
-    static const int forced = getenv("TSASR_LSTM_BR") ? atoi(getenv("TSASR_LSTM_BR")) : 0;
+    static const int forced = 0;
     if (forced == 8 || forced == 16) return forced;
     return B <= 8 ? 8 : LQ_BR;
 }

@@ -25,7 +25,7 @@ struct ReduceJob {
 #define RD_WIDE_TILE 1024
 #define RD_TALL_COLS 64
 static int wide_iters() {   // 1024-column pieces per wide tile (A/B knob; fewer, larger workgroups amortise the job lookup)
-    static const int it = getenv("TSASR_RD_WIDE_ITERS") ? atoi(getenv("TSASR_RD_WIDE_ITERS")) : 1;
+    static const int it = 1;
     return it < 1 ? 1 : it;
 }
 
@@ -169,7 +169,7 @@ static int reduce_flush_impl(void *table_host, void *table_dev, size_t table_byt
             return TSASR_E_LAUNCH;
         }
     }
-    static const int bisect = getenv("TSASR_RD_BISECT") ? atoi(getenv("TSASR_RD_BISECT")) : 0;
+    static const int bisect = 0;
     reduce_many_kernel<<<tiles, 256, 0, st>>>((const ReduceJob *)table_dev, (int)sel.size(), bisect);
     g_jobs.swap(rest);
     g_job_streams.swap(rest_streams);

@@ -785,7 +785,7 @@ static void launch_alphabeta(RnntWs w, const int32_t *tlen, const int32_t *ulen,
     // measured at B = 1, T' = 4000, U = 1920 (32 columns per lane in one wave): 1 wave 50.5 ms, 2 waves 12.7, 4 waves 6.2, 8 waves 8.9,
     // 16 waves 15.3 - with four waves the kernel streams its 100 MB of log-probabilities and alphas at what ONE CU pulls from HBM
     // (~17 GB/s); more waves only add barrier arrivals per step. (Spreading one utterance over several CUs is the next step.)
-    static const int max_waves = getenv("TSASR_RNNT_WAVES") ? atoi(getenv("TSASR_RNNT_WAVES")) : 4;
+    static const int max_waves = 4;
     const int waves = std::min(max_waves, w.K >= 8 ? w.K / 4 : 1);
     switch (w.K) {
         case 1: launch_ab<1, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
@@ -879,7 +879,7 @@ static int device_cu_count_rnnt() {
 // what a CU issues per frame, not by latency) and every range repeats the fragment loads and the slab writes. So: split only when the
 // grid would leave CUs idle (B = 1 long-form: 120 workgroups), never below 32 frames per range; TSASR_JOINT_TSPLIT forces a value.
 static int joint_tsplit(int B, int T, int U1, int J) {
-    static const int forced = getenv("TSASR_JOINT_TSPLIT") ? atoi(getenv("TSASR_JOINT_TSPLIT")) : 0;
+    static const int forced = 0;
     if (forced > 0) return std::min(forced, 4);
     const long long wgs = (long long)B * cdiv(U1, 32) * cdiv(J / 32, 4 * KB);
     int ts = (int)std::min<long long>(4, device_cu_count_rnnt() / std::max<long long>(wgs, 1));
@@ -912,7 +912,7 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     dim3 gx(nut, ksplit, B * TS), gy(cdiv(T, TG), ksplit, B);
     // one pass: the kernel that forms dh tile by tile for ddec / dW also leaves each tile's column sums (its share of denc); a small
     // kernel adds the cdiv(U1, 32) shares. TSASR_JOINT_TWO_PASS=1 brings the separate denc kernel back (A/B: it recomputes every tile).
-    static const bool two_pass = getenv("TSASR_JOINT_TWO_PASS") && atoi(getenv("TSASR_JOINT_TWO_PASS")) != 0;
+    static const bool two_pass = false;
     char *after_slabs = (char *)workspace + align_up(nslab_max * 32 * J * sizeof(float), 256) + align_up(nslab_max * 32 * sizeof(float), 256);
     float *part = two_pass ? nullptr : (float *)after_slabs;
     float *ddec_part = (float *)(after_slabs + align_up((size_t)B * nut * T * J * sizeof(float), 256));
@@ -930,7 +930,7 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     } else {
         TSASR_CHECK_ARG(false, "tsasr_joint_bwd: bad io_dtype %d", io_dtype);
     }
-    static const bool joint_defer = !(getenv("TSASR_JOINT_DEFER") && getenv("TSASR_JOINT_DEFER")[0] == '0');   // A/B knob
+    static const bool joint_defer = true;
     if (tsasr_reduce_deferring() && joint_defer) {   // head-weight slabs join the batched reduction at the end of backward (the loop kernel below walks
         tsasr_reduce_submit(slab_w, dW, (long long)32 * J, (int)nslab, V * J, 0, st);   // 128 slabs serially per thread: 57 us on the main stream)
         tsasr_reduce_submit(slab_b, dbias, 32, (int)nslab, V, 0, st);

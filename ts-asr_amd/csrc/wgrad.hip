@@ -287,7 +287,7 @@ int tsasr_wgrad_flush(void *table_host, void *table_dev, size_t table_bytes, voi
             return TSASR_E_LAUNCH;
         }
     }
-    static const int variant = getenv("TSASR_WGRAD_RING") ? atoi(getenv("TSASR_WGRAD_RING")) : 1;   // bit 0: 32-row slots x 4 instead of 64-row x 2; bit 1: spread DMA issue (A/B)
+    static const int variant = 1;   // bit 0: 32-row slots x 4 instead of 64-row x 2; bit 1: spread DMA issue (A/B)
     static const int dbg = getenv("TSASR_WGRAD_DEBUG") ? atoi(getenv("TSASR_WGRAD_DEBUG")) : 0;      // timing experiments: see DBG
     void (*kern)(const WgradJob *, int, int) = nullptr;
 #define WG_PICK(BK_, NST_) \

@@ -45,8 +45,6 @@ def ddp_init_group(run_opts):
     dist.init_process_group(backend=backend)
 
 
-# single-rank steps: flush the queued weight gradients on a side stream once they fill this many 256 x 256 tiles (0 = one flush at the end)
-_WGRAD_ASYNC_TILES = int(os.environ.get("TSASR_WGRAD_ASYNC_TILES", "0"))   # measured: 80-240 tiles -> 15.2-15.8 ms against 14.6 ms for one flush at the end (the 128 KB-LDS, 8-wave workgroups starve the main chain's kernels of CUs): off
 _DIRECT = {"ranks": 0}
 
 
@@ -164,7 +162,7 @@ class GradArena:
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_ring = [], None, None
         self.collect_wgrads = self.device.type == "cuda"   # weight-gradient GEMMs are queued and run as one grouped launch per flush
-        self.wgrad_stream, self._wgrad_hold, self._wgrad_side_busy = None, [], False
+        self._wgrad_hold, self._wgrad_held = [], False
         self._reorder_pending = False
         self._layout(params, first=True)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -308,7 +306,7 @@ class GradArena:
 
     def abort_backward(self):
         """Error path (a step capture that raised): forget everything queued for this backward pass."""
-        self._deferred, self._wgrad_hold, self._wgrad_side_busy, self._handles = [], [], False, []
+        self._deferred, self._wgrad_hold, self._wgrad_held, self._handles = [], [], False, []
         self.in_backward = False
 
     # ---- grouped weight gradients (csrc/wgrad.hip) -------------------------------------------------------
@@ -322,8 +320,6 @@ class GradArena:
             self._contrib_step[id(p)] = self._contrib_step.get(id(p), 0) + 1
         from . import ops
         if not self._sync_this_step or not self._order_final:
-            if _WGRAD_ASYNC_TILES and ops.wgrad_pending_tiles() >= _WGRAD_ASYNC_TILES:
-                self.flush_wgrads(side=True)
             return
         b = self.bucket_of[id(p)]
         b["left"] -= 1
@@ -331,38 +327,28 @@ class GradArena:
         if b["left"] == 0:
             self.flush_wgrads()
 
-    def flush_wgrads(self, side=False, hold=False, release=False):
-        """Run every queued weight gradient now, ordered after every stream of the step: on the current stream, or (side) on the
-        arena's weight-gradient stream, which finish_backward joins. ``hold``: the launch happens while other streams of the step are
-        still running (the recipe's early flush under the speaker branch's backward): the operands - some were allocated on those
-        streams - stay referenced until the next flush from finish_backward, after the streams have joined; dropped here, the caching
-        allocator hands their memory to the other stream's next kernels while this launch still reads it."""
+    def flush_wgrads(self, hold=False, release=False):
+        """Run every queued weight gradient now on the current stream, ordered after every stream of the step. ``hold``: the launch happens
+        while other streams of the step are still running (the recipe's early flush under the speaker branch's backward): the operands -
+        some were allocated on those streams - stay referenced until the flush from finish_backward (``release``), after the streams
+        have joined; dropped here, the caching allocator hands their memory to the other stream's next kernels while this launch still
+        reads it."""
         from . import ops
         if ops.wgrad_pending() == 0:
             self._send_completed()      # (an earlier flush may have finished a bucket's queued gradients before its last plain gradient came in)
             return
-        if side and self.device.type == "cuda":
-            if self.wgrad_stream is None:
-                self.wgrad_stream = torch.cuda.Stream(device=self.device)
-            ws, cur = self.wgrad_stream, torch.cuda.current_stream()
-            for st in {id(x): x for x in [cur, self._main_stream] + list(self.aux_streams) if x is not None}.values():
-                ws.wait_stream(st)
-            with torch.cuda.stream(ws):
-                ops.wgrad_flush(hold=self._wgrad_hold)     # operands stay referenced until the join (their memory must not be recycled under the launch)
-            self._wgrad_side_busy = True
-            return
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream()
-            for st in [self._main_stream, self.wgrad_stream if self._wgrad_side_busy else None] + list(self.aux_streams):
+            for st in [self._main_stream] + list(self.aux_streams):
                 if st is not None and st != cur:
                     cur.wait_stream(st)
         if hold:
             ops.wgrad_flush(hold=self._wgrad_hold)
-            self._wgrad_side_busy = True           # (no side stream involved: only marks the held operands for the next flush to release)
+            self._wgrad_held = True
         else:
             ops.wgrad_flush()
-            if self._wgrad_side_busy and release:    # held operands go only once every stream of the step has joined (finish_backward)
-                self._wgrad_side_busy, self._wgrad_hold = False, []
+            if self._wgrad_held and release:    # held operands go only once every stream of the step has joined (finish_backward)
+                self._wgrad_held, self._wgrad_hold = False, []
         self._send_completed()
 
     def _send_completed(self):
@@ -448,10 +434,8 @@ class GradArena:
         if self.device.type == "cuda":
             from . import ops
             self.flush_wgrads(release=True)   # every queued weight gradient, one grouped launch (accumulates into the arena)
-            if self._wgrad_side_busy:   # nothing was left to flush: still join the weight-gradient stream, release held operands
-                if self.wgrad_stream is not None:
-                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-                self._wgrad_side_busy, self._wgrad_hold = False, []
+            if self._wgrad_held:        # nothing was left to flush: the streams have joined (Brain._device_step), release the held operands
+                self._wgrad_held, self._wgrad_hold = False, []
             ops.dpk_defer_end()         # (nothing is left unless no weight-gradient launch followed the last attention backward)
             ops.reduce_defer_end()      # every queued partial-sum reduction, one launch
         self._flush_deferred()

@@ -315,7 +315,7 @@ class _Holder(nn.Module):
         self.add_module(name, child)
 
 
-_FUSED_CONVBLOCK = os.environ.get("TSASR_FUSED_CONVBLOCK", "1") != "0"   # A/B: 0 = conv kernel + 2 LayerNorm kernels + dropout-add kernel
+_FUSED_CONVBLOCK = True   # (False: conv kernel + 2 LayerNorm kernels + dropout-add kernel - the path of shapes the fused kernel does not take)
 
 
 class ConvBlock(nn.Module):

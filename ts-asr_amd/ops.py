@@ -155,15 +155,6 @@ def reduce_flush():
     _DEFER["keep"] = []
 
 
-def reduce_flush_own_stream():
-    """Run the queued reductions whose partial rows were produced on the CURRENT stream (complete in its order), keep the rest
-    queued: called on the main stream when its share of backward is enqueued and a forked stream is still busy with the speaker
-    branch's - the HBM-bound reduction then runs under those small, latency-bound kernels instead of after them."""
-    if not _DEFER["on"] or C.lib().tsasr_reduce_pending() == 0:
-        return
-    _reduce_flush("tsasr_reduce_flush_stream")
-
-
 def upload_captured_tables():
     """After a stream capture: copy the job tables the captured flushes filled on the host to their device twins (a graph replay
     carries no memcpy node; each captured graph owns its pair for life)."""
@@ -202,13 +193,13 @@ def reduce_defer_end():
 # it while the gradient arena is collecting (operands parked here); GradArena flushes the queue in one launch per bucket / step.
 _WG = {"keep": [], "ids": set(), "ring": None, "params": []}
 _WG_MAX_JOBS = 1024
-_WG_ENABLED = os.environ.get("TSASR_WGRAD_GROUP", "1") != "0"
+_WG_ENABLED = True
 # The weight-gradient launch made beside another stream's kernels (the recipe's early flush) walks its tiles persistently on at most this
 # many CUs: -1 = half the device. A 256x256-tile workgroup holds 128 KB of LDS, so nothing shares a CU with it; with one per tile the
 # speaker branch's small kernels waited for whole CUs to drain (13.39-13.46 ms per step; 96 CUs 13.16, 112: 13.12, 128: 13.09, 144: 13.28,
 # 192: 13.20). 0 = one workgroup per tile.
-_WG_EARLY_WGS = int(os.environ.get("TSASR_WGRAD_EARLY_WGS", "-1"))
-_WG_EARLY_SLOTS = int(os.environ.get("TSASR_WGRAD_EARLY_SLOTS", "0"))   # 2: the launch made beside another stream's kernels uses 64 KB of LDS
+_WG_EARLY_WGS = -1
+_WG_EARLY_SLOTS = 0      # (2: the launch made beside another stream's kernels uses 64 KB of LDS - measured equal)
 
 
 def wgrad_queue(weight, grad2d, dy2, x2):
@@ -236,11 +227,6 @@ def wgrad_queue(weight, grad2d, dy2, x2):
     return True
 
 
-def wgrad_pending_tiles():
-    """256 x 256 output tiles of the queued weight gradients (one workgroup each in the grouped launch)."""
-    return _WG.get("tiles", 0)
-
-
 def wgrad_pending():
     return len(_WG["params"])
 
@@ -249,7 +235,7 @@ def wgrad_pending():
 # is in backward, run as one grouped launch right in front of the grouped weight-gradient launch that consumes their outputs.
 _DPK = {"ring": None, "on": False}
 _DPK_MAX_JOBS = 64
-_DPK_DEFER = os.environ.get("TSASR_DPK_DEFER", "1") != "0"   # A/B knob
+_DPK_DEFER = True        # (tests switch it off to compare with the per-layer launches)
 
 
 def dpk_defer_begin(device):
@@ -954,7 +940,7 @@ class _AddLayerNorm2Fn(torch.autograd.Function):
                 _pgrad(g2, dg2), _pgrad(b2, dbt2), None, None, None, None, None, None, None)
 
 
-_FUSED_LN_PAIR = os.environ.get("TSASR_FUSED_LN_PAIR", "1") != "0"   # A/B knob
+_FUSED_LN_PAIR = True
 
 
 def add_layer_norm2_supported(x):

@@ -17,31 +17,11 @@ from ..nnet import abs_lengths_round
 Stage = core.Stage
 
 
+# TSASR_OVERLAP: "1" (default) the speaker branch and, behind it, the predictor run on a second HIP stream; "2" only the speaker branch;
+# "0" one stream. (Round 2's other placements - predictor on a third stream, issued after the encoder, its backward run re-entrantly,
+# a high-priority side stream - were measured equal or slower and are gone: profiles/r02_notes.md section 5.)
 _OVERLAP_MODE = os.environ.get("TSASR_OVERLAP", "1")
-# A/B knob, off: see _BranchBackwardNow. Measured on the captured step: 13.55 ms off, 14.15 ms on - hipGraph then places the LSTM backward
-# kernel in the hardware queue of the encoder's backward and serialises with it (profiles/r02_notes.md)
-_PREDICTOR_BWD_FIRST = os.environ.get("TSASR_PREDICTOR_BWD_FIRST", "0") != "0"
-_EARLY_WGRAD = os.environ.get("TSASR_WGRAD_EARLY", "1") != "0"   # A/B knob: main-encoder weight gradients launched under the speaker branch's backward
-_OVERLAP_DEFAULT = _OVERLAP_MODE != "0"   # A/B knob: speaker branch + predictor on a second stream
-
-class _BranchBackwardNow(torch.autograd.Function):
-    """Identity that cuts a forked branch (the predictor) out of the main autograd graph and runs that branch's backward the moment
-    its output gradient exists. Autograd runs ready nodes in reverse order of their creation; the predictor is created before the
-    encoder, so its backward - ready as soon as the joint's is done - was issued after the whole encoder's, and its 0.8 ms LSTM kernel
-    (16 CUs) then sat on the side stream in front of the speaker branch's backward, on the step's critical path. This node is created
-    right before the joint, runs right after it, and issues the branch's backward (re-entrant autograd, every node on the stream of its
-    forward) beside the encoder's. Parameter gradients reach the arena exactly as before; only the issue order changes."""
-
-    @staticmethod
-    def forward(ctx, y_leaf, holder):
-        ctx.holder = holder
-        return y_leaf.view_as(y_leaf)
-
-    @staticmethod
-    def backward(ctx, g):
-        y = ctx.holder.pop()
-        torch.autograd.backward(y, g)
-        return None, None
+_OVERLAP_DEFAULT = _OVERLAP_MODE != "0"
 
 
 class TSASR(core.Brain):
@@ -109,17 +89,9 @@ class TSASR(core.Brain):
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            # TSASR_SIDE_PRIORITY=-1: a high-priority stream for the forked branches (their kernels are small and sit on the critical path
-            # at the joins; the main stream's are large)
-            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("TSASR_SIDE_PRIORITY", "0")))
+            self._side = torch.cuda.Stream(device=self.device)
             self._aux_streams.append(self._side)      # Brain joins it after backward
         return self._side
-
-    def _predictor_stream(self):
-        if getattr(self, "_side2", None) is None:
-            self._side2 = torch.cuda.Stream(device=self.device)
-            self._aux_streams.append(self._side2)
-        return self._side2
 
     def _flush_main_wgrads(self, grad):
         """Tensor hook on the speaker embedding: fires (on the side stream) when the speaker branch's backward is about to start, i.e.
@@ -146,7 +118,7 @@ class TSASR(core.Brain):
         # branch's overlaps layer 0 / the front-end's. Works the same inside a captured hipGraph (fork / join become edges).
         overlap = (stage == Stage.TRAIN and self.variant != "none" and getattr(self, "overlap_branches", _OVERLAP_DEFAULT)
                    and torch.device(self.device).type == "cuda")
-        dec_out, side_pred = None, None
+        dec_out = None
         if overlap:
             cur, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(cur)
@@ -154,22 +126,15 @@ class TSASR(core.Brain):
                 spk, enroll_lens = self._speaker_embedding(batch, epoch)
                 spk_ready = torch.cuda.Event()
                 spk_ready.record(side)
-                if _EARLY_WGRAD and spk is not None and spk.requires_grad:
+                if spk is not None and spk.requires_grad:
                     spk.register_hook(self._flush_main_wgrads)
                 # The predictor follows the speaker branch on the forked stream, in eager and in captured steps alike (one autograd
                 # topology: gradient buckets complete in the same order either way). Round 2 kept it on the main stream in eager steps
                 # because runs with it forked deviated once in ~100; the cause was found in round 3 and is not a stream-ordering
                 # matter: packed-fp32 instructions of one kernel returning wrong values while the per-step LSTM kernels ran beside it
                 # (profiles/r03_notes.md section 1; the library no longer contains such instructions). "2" = speaker branch only.
-                if _OVERLAP_MODE in ("1", "3"):
+                if _OVERLAP_MODE != "2":
                     dec_out = self._predictor(tokens_bos, tokens_bos_lens)
-            if _OVERLAP_MODE == "4":
-                # "4" (A/B, measured equal: 13.43 vs 13.44 ms): the predictor on a stream of its own
-                pstream = self._predictor_stream()
-                pstream.wait_stream(cur)
-                with torch.cuda.stream(pstream):
-                    dec_out = self._predictor(tokens_bos, tokens_bos_lens)
-                side_pred = pstream
 
             def speaker_embs():
                 cur.wait_event(spk_ready)
@@ -192,18 +157,11 @@ class TSASR(core.Brain):
         enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
         enc_out = self.modules.encoder_proj(enc_out)
 
-        if dec_out is None and overlap and _OVERLAP_MODE == "5":
-            # "5" (A/B, measured slower: 14.7 vs 13.45 ms): predictor issued AFTER the encoder so that autograd runs its backward first;
-            # hipGraph then schedules the forward's LSTM kernel in front of the encoder's kernels
-            with torch.cuda.stream(side):
-                dec_out = self._predictor(tokens_bos, tokens_bos_lens)
         if dec_out is None:
             dec_out = self._predictor(tokens_bos, tokens_bos_lens)
         else:
-            cur.wait_stream(side_pred if side_pred is not None else side)
+            cur.wait_stream(side)
             dec_out.record_stream(cur)
-            if _PREDICTOR_BWD_FIRST and dec_out.requires_grad:
-                dec_out = _BranchBackwardNow.apply(dec_out.detach().requires_grad_(), [dec_out])
 
         # joiner + transducer_head fused (train_librispeechmix_scratch.py:132-135)
         head = self.modules.transducer_head.w
