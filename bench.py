@@ -184,7 +184,7 @@ def allreduce_probe(brain, torch, world, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)      # 2.5 s of timed replays at configs[1]: averages box-to-box jitter, visible to a utilisation sampler
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
