@@ -17,7 +17,8 @@ SMALL = ["--d_model", "144", "--nhead", "4", "--encoder_num_layers", "2", "--spe
          "--decoder_neurons", "128", "--compute_dtype", "bf16"]
 
 
-@pytest.mark.parametrize("yaml_name,graph", [("conformer-t_scratch_mi355x.yaml", True), ("conformer-t_wavlm_mi355x.yaml", False)])
+@pytest.mark.parametrize("yaml_name,graph", [("conformer-t_scratch_mi355x.yaml", True), ("conformer-t_wavlm_mi355x.yaml", False),
+                                             ("conformer-t_none_mi355x.yaml", True)])
 def test_recipe_main_fit_and_evaluate(yaml_name, graph):
     """Two epochs of Brain.fit over 6 length-bucketed synthetic batches (validation with the greedy searcher after each), then
     Brain.evaluate with the beam searcher: losses finite and falling, hypotheses produced, optimizer steps counted."""
