@@ -261,6 +261,11 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
  * (SB/nnet/attention.py:820-836) without a separate pass over the [M, d_ffn] hidden activation:
  *   epi_mode 1: C = dropout_p(LeakyReLU_slope(A.B + bias[n]));   epi_mode 2 (its backward on the dgrad GEMM):
  *   C = (A.B) * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]) and dbias[n] = column sums of C.  Masks: counter-based, (seed + *seed_dev, m*N+n). */
+/* nbatch products with one shared left operand in ONE launch: C_i [M,N] = A [M,K] . B_i^T, B_i = btab[i] (a DEVICE array of device
+ * pointers to bf16 [N,K] matrices, row stride ldb), C_i = C + i * c_batch elements. The 12 + 6 `linear_pos` projections of the one
+ * positional table (SB/nnet/attention.py:433, 560: every RelPosMHAXL layer projects the same pos_embs). K % 64 == 0, N % 8 == 0. */
+int tsasr_gemm_bf16_nt_batched(const void *A, const void *const *btab, void *C, int M, int N, int K, long long lda, long long ldb,
+                               long long ldc, long long c_batch, int nbatch, void *stream);
 size_t tsasr_gemm_bf16_fused_workspace_bytes(int M, int N);
 int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                           int transA, int transB, int epi_mode, const float *bias, const void *y, long long ldy, float slope, float p,
@@ -325,6 +330,13 @@ int tsasr_add_layernorm2_bwd(const void *dz, const void *dy, const void *dout, c
 /* Whole-sequence LSTM recurrences (all U steps of tsasr_lstm_step_fwd / _bwd). bf16, H in {256, 512}, B <= 256: one persistent
  * launch per direction (workgroups exchange h_t / dG_t through write-through stores and an arrival counter); otherwise a loop of
  * the per-step kernels. Replaces the time loop inside torch.nn.LSTM (speechbrain/nnet/RNN.py:244-278). */
+/* Input projection of the predictor when its Embedding is one-hot and frozen (speechbrain/nnet/embedding.py:76-95 consider_as_one_hot,
+ * train_librispeechmix_scratch.py:117-119 `embedding` -> `decoder`): gates [B,U,H,4] fp32 = b_ih + b_hh + the token's column of w_ih
+ * [4H, I] (fp32), i.e. F.embedding + x . W_ih^T + biases of torch.nn.LSTM without the gather, the casts and the GEMM. tokens int64 [B,U];
+ * token k -> column k-1 above `blank`, k below it, blank -> zeros. xp (may be NULL): bf16 [B*U, Ip] one-hot rows + ones in columns I, I+1
+ * (I + 2 <= Ip <= H): the operand the backward's weight-gradient GEMM contracts with. */
+int tsasr_lstm_onehot_gates(const long long *tokens, const float *w_ih, const float *b_ih, const float *b_hh, float *gates, void *xp, int B,
+                            int U, int H, int I, int Ip, int blank, void *stream);
 int tsasr_lstm_seq_persistent(int B, int H, int io_dtype);   /* 1: one persistent launch per direction on this device for this shape */
 size_t tsasr_lstm_seq_workspace_bytes(int B, int U, int H);   /* first 256 bytes: uint32 {arrival counter, error word} per batch group; a non-zero error word = an inter-workgroup wait timed out (outputs poisoned with NaN) */
 int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, int H, int io_dtype, void *workspace,
@@ -388,6 +400,8 @@ int tsasr_debug_barrier_canary(int wgs, int rounds, void *errors, void *first_ba
 int tsasr_debug_vgpr_canary(int wgs, int iters, void *errors, void *first_bad, void *stream);
 /* TEST AID: nwords 32-bit words at p <- pattern (poisoning the captured step's free pool memory between replays). */
 int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream);
+/* tool aid: *out (uint64, device) = the device wall clock (100 MHz ticks) when a one-thread kernel reaches the head of `stream` */
+int tsasr_debug_stamp(void *out, void *stream);
 int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);
 
 /* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module

@@ -504,6 +504,46 @@ def test_lstm_hip_path_vs_oracle(ops, B, U, H):
         assert float((a - r_).norm() / r_.norm()) < 3e-2, k
 
 
+@pytest.mark.parametrize("B,U,H,blank", [(8, 21, 256, 0), (32, 121, 512, 0), (5, 7, 128, 3)])
+def test_onehot_predictor_vs_oracle(ops, B, U, H, blank):
+    """embedding -> decoder in one call (nnet.LSTM.forward_tokens: a token selects a column of W_ih, tsasr_lstm_onehot_gates) against
+    the oracle's one-hot embedding + explicit recurrence, forward, lengths mask and every parameter gradient; blank = 3 exercises the
+    tokens below the blank index (SB/nnet/embedding.py:83-90)."""
+    from importlib import import_module
+    from oracle import tsasr_ref as R
+    nnet = import_module("ts-asr_amd.nnet")
+    V = 29
+    g = torch.Generator().manual_seed(11)
+    emb = nnet.Embedding(V, consider_as_one_hot=True, blank_id=blank).to(DEV)
+    dec = nnet.LSTM(H, input_size=V - 1, re_init=True).to(DEV)
+    tok = torch.randint(0, V, (B, U), generator=g)
+    rel = torch.linspace(1.0, 0.5, B)
+    dout = torch.randn(B, U, H, generator=g)
+    sd = {"rnn." + k: v.detach().cpu().clone().requires_grad_() for k, v in dec.rnn.state_dict().items()}
+    ref, _ = R.lstm(R.one_hot_embedding(tok, V, blank), sd, "")
+    keep = (torch.arange(U)[None, :] < torch.floor(rel * U)[:, None]).float()[..., None]
+    ref = ref * keep
+    ref.backward(dout)
+    assert ops.lstm_onehot_supported(tok.to(DEV), dec.rnn, V)
+    nnet.set_compute_dtype(torch.bfloat16)      # (this module's fixtures run the stage tests in fp32)
+    try:
+        out, _ = dec.forward_tokens(tok.to(DEV), emb, lengths=rel.to(DEV))
+        assert out.dtype == torch.bfloat16
+        out.backward(dout.to(DEV).to(torch.bfloat16))
+        grads = {k: getattr(dec.rnn, k).grad.clone() for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")}
+        for p_ in dec.parameters():
+            p_.grad = None
+        out2, _ = dec(emb(tok.to(DEV)), lengths=rel.to(DEV))     # the two-module form (F.embedding + the GEMM input projection)
+    finally:
+        nnet.set_compute_dtype(torch.float32)
+    assert float((out.float().cpu() - ref.detach()).norm() / ref.detach().norm()) < 1e-2
+    assert float(out.float().cpu()[keep.expand_as(ref) == 0].abs().max()) == 0.0
+    for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        a, r_ = grads[k].cpu(), sd["rnn." + k].grad
+        assert float((a - r_).norm() / r_.norm()) < 3e-2, k
+    assert float((out2.float() - out.float()).norm() / out.float().norm()) < 1e-2      # same function, two routes
+
+
 def test_lstm_persistent_kernels_survive_graph_replay_with_dirty_workspace():
     """The whole-sequence kernels rely on arrival counters in the first 256 workspace bytes being zero at launch. Inside a
     replayed hipGraph the workspace is recycled memory: fill it (counters AND exchange payload) with 0xFF between replays; every

@@ -82,6 +82,7 @@ _PROTOS = {
     "tsasr_gemm_set_plan": (None, [c_int, c_int]),
     "tsasr_gemm_set_ring": (None, [c_int]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
+    "tsasr_gemm_bf16_nt_batched": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 4 + [c_int, c_void_p]),
     "tsasr_gemm_bf16_fused_workspace_bytes": (c_size_t, [c_int] * 2),
     "tsasr_gemm_bf16_fused": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_float, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_gemm_bf16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
@@ -98,6 +99,7 @@ _PROTOS = {
     "tsasr_add_layernorm2_fwd": (c_int, [c_void_p] * 14 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
     "tsasr_add_layernorm2_bwd_workspace_bytes": (c_size_t, [c_ll, c_int]),
     "tsasr_add_layernorm2_bwd": (c_int, [c_void_p] * 18 + [c_ll, c_int, c_float, c_float, c_ull, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_lstm_onehot_gates": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "tsasr_lstm_seq_persistent": (c_int, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "tsasr_lstm_seq_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
@@ -118,6 +120,7 @@ _PROTOS = {
     "tsasr_debug_barrier_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tsasr_debug_vgpr_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tsasr_debug_fill": (c_int, [c_void_p, ctypes.c_uint, c_size_t, c_void_p]),
+    "tsasr_debug_stamp": (c_int, [c_void_p, c_void_p]),
     "tsasr_count_nonfinite": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),
     "tsasr_allreduce_unique_id": (c_int, [c_void_p]),

@@ -111,6 +111,10 @@ class ConformerEncoder(nn.Module):
 
     def _project_pos(self, pos):
         """Every layer's projected positional table, made ahead of the first layer (RelPosMHAXL.project_pos)."""
+        from .nnet import _pos_cd
+        pks = ops.project_many(_pos_cd(pos), [layer.mha_layer.linear_pos.weight for layer in self.layers])   # one launch for all layers
+        if pks is not None:
+            return [(pk, True) for pk in pks]     # (deferrable: RelPosMHAXL.project_pos - leaf weights, gradient-free table, HIP GEMM)
         return [layer.mha_layer.project_pos(pos) for layer in self.layers]
 
     def forward_post(self, state, speaker_embs=None, speaker_embs_length=None):

@@ -24,6 +24,7 @@ import torch
 
 from . import dp as _dp
 from . import optim as _optim
+from . import prof
 
 logger = logging.getLogger(__name__)
 
@@ -236,26 +237,43 @@ class Brain:
         self.on_fit_batch_end(batch, outputs, loss, should_step)
         return loss
 
+    def _loss_seed(self, loss):
+        key = (loss.dtype, loss.device, int(self.grad_accumulation_factor))
+        seeds = self.__dict__.setdefault("_loss_seeds", {})
+        if key not in seeds:
+            seeds[key] = torch.full((), 1.0 / self.grad_accumulation_factor, dtype=loss.dtype, device=loss.device)
+        return seeds[key]
+
     def _device_step(self, batch, should_step, comm):
         """Everything of one micro-batch that runs on the GPU; no host synchronisation, no host->device copies: capturable."""
         from . import ops as _ops
         _ops.begin_step(self.device)
+        prof.stamp_begin(self.device)
+        prof.stamp("step starts [main]")
         self.arena.begin_backward(should_step and comm)
         outputs = self.compute_forward(batch, Stage.TRAIN)
         loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
         self.check_gradients(loss)
-        (loss / self.grad_accumulation_factor).backward()
+        # d(loss / factor) = 1 / factor: handed to backward() as a constant kept on the device, instead of a division node in front of the
+        # loss (SB/core.py:1066 `(loss / self.grad_accumulation_factor).backward()`: three element-wise launches less per step, same bits)
+        loss.backward(gradient=self._loss_seed(loss))
         # Streams the recipe forked in forward also ran their share of backward. autograd joins only the streams its LEAF
         # (AccumulateGrad) nodes ran on - and most parameter gradients here bypass those nodes (GEMMs accumulate straight into
         # the arena, small gradients are queued for one batched add) - so join explicitly before anything reads the gradients.
+        prof.stamp("backward done [main]")
         for s in self._aux_streams:
+            if prof.STAMPS:
+                with torch.cuda.stream(s):
+                    prof.stamp("backward done [side]")
             torch.cuda.current_stream().wait_stream(s)
         self.arena.finish_backward()          # waits for the overlapped bucket all-reduces (if any), averages over ranks
+        prof.stamp("weight gradients and reductions done [main]")
         if should_step and (comm or not self.distributed):
             if comm and not (torch.device(self.device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
                 self.optimizer.prepare()      # host half (step count, lr -> device): never inside a capture (_fit_batch_graph does it before a replay)
             self.optimizer.launch()           # clip (global L2 norm, max_grad_norm) + AdamW in one pass over the arena
             self.arena.zero_()
+            prof.stamp("optimizer done [main]")
         return loss.detach(), outputs
 
     # ---- hipGraph replay of the whole step (HIP streams and graphs instead of a tracing compiler) -----------------

@@ -39,6 +39,10 @@ struct EpiArgs {
     unsigned long long seed;
     const unsigned long long *seed_dev;
     float *colpart;   // [gridDim.y][N] partial column sums (mode 2)
+    // batched form (tsasr_gemm_bf16_nt_batched): workgroups of grid row blockIdx.y multiply A by B = btab[blockIdx.y] and write the C
+    // matrix c_batch elements after the previous one; NULL: one product
+    const void *const *btab;
+    long long c_batch;
 };
 
 template <int BM, int BN, bool AT, bool BT>
@@ -428,9 +432,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
+    const bf16_t *Bm = B;
+    if (ep.btab) {      // workgroup-uniform
+        Bm = reinterpret_cast<const bf16_t *>(ep.btab[blockIdx.y]);
+        Cv = reinterpret_cast<bf16_t *>(Cv) + (long long)blockIdx.y * ep.c_batch;
+    }
     const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
     TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
-    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
+    TB::src_ptrs(Bm, ldb, n0, N, kbeg, wave, lane, gb);
     const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
     int a_off[RB][GB_K / 16][TA::NFO], b_off[CB][GB_K / 16][TB::NFO];
 #pragma unroll
@@ -936,6 +945,22 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
         launch_tile<1>(p.tile, transA, transB, A, B, C, M, N, K, lda, ldb, ldc, 1, p.kchunk, 0, st);
     }
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16");
+    return 0;
+}
+
+/* C_i [M,N] = A [M,K] . B_i^T for i < nbatch in ONE launch: A shared, B_i = btab[i] (DEVICE array of nbatch device pointers to bf16
+ * [N,K] matrices, row stride ldb), C_i = C + i * c_batch elements (row stride ldc), all bf16. K % 64 == 0, N % 8 == 0. */
+int tsasr_gemm_bf16_nt_batched(const void *A, const void *const *btab, void *C, int M, int N, int K, long long lda, long long ldb,
+                               long long ldc, long long c_batch, int nbatch, void *stream) {
+    TSASR_CHECK_ARG(A && btab && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch < 65536, "tsasr_gemm_bf16_nt_batched: bad arguments");
+    TSASR_CHECK_ARG(K % GB_K == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && c_batch % 8 == 0,
+                    "tsasr_gemm_bf16_nt_batched: K must be a multiple of %d, N and the strides multiples of 8 bf16", GB_K);
+    EpiArgs ep{};
+    ep.btab = btab; ep.c_batch = c_batch;
+    using R = RingSmem<64, 64, false, false>;
+    dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 64)), (unsigned)nbatch);
+    gemm_bf16_ring_kernel<64, 64, false, false, 0><<<grid, 256, R::BYTES, (hipStream_t)stream>>>((const bf16_t *)A, nullptr, C, M, N, K, lda, ldb, ldc, K, 0, 1, ep);
+    TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_nt_batched");
     return 0;
 }
 

@@ -520,6 +520,32 @@ static void launch_seq_bwd(const float *gates, const float *c, const void *dout,
 }
 
 
+// ---- input projection of a ONE-HOT embedding ---------------------------------------------------------------------------------------
+// The predictor's Embedding is one-hot (SB/nnet/embedding.py:76-95 consider_as_one_hot: token k -> e_{k-1}, blank -> 0) and frozen, so
+// x . W_ih^T is a column of W_ih: gates[b,u,h,g] = b_ih[gH+h] + b_hh[gH+h] + W_ih[gH+h][col(token)], in fp32, gate-minor as the recurrence
+// kernels read it. Replaces embedding gather + casts + padded copies + GEMM (17 launches). xp [B*U][Ip] bf16 is the padded one-hot input
+// the backward's weight-gradient GEMM contracts with (ones in columns I, I+1: the bias gradient rides in column I).
+__global__ __launch_bounds__(256) void lstm_onehot_gates_kernel(const long long *__restrict__ tokens, const float *__restrict__ w_ih,
+                                                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+                                                                 float *__restrict__ gates, bf16_t *__restrict__ xp, long long BU, int H, int I,
+                                                                 int Ip, int blank) {
+    const long long n = BU * H;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long row = e / H;
+        const int h = (int)(e - row * H);
+        const long long tok = tokens[row];
+        const int col = (tok == blank || tok < 0) ? -1 : (int)(tok > blank ? tok - 1 : tok);
+        float v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = g * H + h;
+            v[g] = b_ih[k] + b_hh[k] + ((col >= 0 && col < I) ? w_ih[(long long)k * I + col] : 0.f);
+        }
+        *reinterpret_cast<float4 *>(gates + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (xp && h < Ip) xp[row * Ip + h] = (bf16_t)((h == col || h == I || h == I + 1) ? 1.f : 0.f);
+    }
+}
+
 extern "C" {
 
 int tsasr_lstm_cell_fwd(float *gates, float *c, void *h, int B, int U, int H, int t, int io_dtype, void *stream) {
@@ -592,6 +618,20 @@ static bool seq_persistent_ok(int B, int H, int io_dtype) {   // sync words: 2 p
     static const int force_off = getenv("TSASR_LSTM_PERSISTENT") ? (atoi(getenv("TSASR_LSTM_PERSISTENT")) == 0) : 0;
     return !force_off && io_dtype == TSASR_BF16 && (H == 256 || H == 512) && cdiv(B, lq_br(B)) <= 16 &&
            cdiv(B, lq_br(B)) * (H / LQ_UN) <= device_cu_count();
+}
+
+/* gates [B,U,H,4] fp32 = the x-part of the gate pre-activations (both biases included) for one-hot embedded tokens [B,U] (int64):
+ * row gH+h of w_ih [4H, I] fp32 at the token's column (token k -> column k-1 above `blank`, k below it; blank -> no column). xp (may be
+ * NULL): bf16 [B*U, Ip], Ip >= I + 2, Ip <= H: the one-hot rows with ones in columns I and I+1 (operand of the weight-gradient GEMM). */
+int tsasr_lstm_onehot_gates(const long long *tokens, const float *w_ih, const float *b_ih, const float *b_hh, float *gates, void *xp, int B,
+                            int U, int H, int I, int Ip, int blank, void *stream) {
+    TSASR_CHECK_ARG(tokens && w_ih && b_ih && b_hh && gates && B > 0 && U > 0 && H > 0 && I > 0, "tsasr_lstm_onehot_gates: bad arguments");
+    TSASR_CHECK_ARG(!xp || (Ip >= I + 2 && Ip <= H), "tsasr_lstm_onehot_gates: need I + 2 <= Ip <= H (I=%d Ip=%d H=%d)", I, Ip, H);
+    const long long n = (long long)B * U * H;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    lstm_onehot_gates_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(tokens, w_ih, b_ih, b_hh, gates, (bf16_t *)xp, (long long)B * U, H, I, Ip, blank);
+    TSASR_CHECK_LAUNCH("tsasr_lstm_onehot_gates");
+    return 0;
 }
 
 /* 1 when tsasr_lstm_seq_fwd/bwd run as ONE persistent launch for this shape on the current device (the workspace's first 256 bytes

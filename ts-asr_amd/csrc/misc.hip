@@ -172,6 +172,17 @@ int tsasr_debug_fill_lds(unsigned pattern, void *stream) {
     return 0;
 }
 
+/* TOOL AID: *out = the device's constant-rate wall clock (100 MHz) at the moment this one-thread kernel runs on `stream` - a captured
+ * step carries a handful of these (prof.stamp, TSASR_STAMPS=1) to show when each phase REALLY starts in an unprofiled replay; rocprofv3's
+ * kernel trace perturbs exactly that (tools/step_stamps.py). */
+__global__ void stamp_kernel(unsigned long long *out) { *out = wall_clock64(); }
+int tsasr_debug_stamp(void *out, void *stream) {
+    TSASR_CHECK_ARG(out && ((uintptr_t)out & 7) == 0, "tsasr_debug_stamp: null or misaligned pointer");
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>((unsigned long long *)out);
+    TSASR_CHECK_LAUNCH("tsasr_debug_stamp");
+    return 0;
+}
+
 /* TEST AID: fill `nwords` 32-bit words of device memory with a pattern (tools/det_stress.py --poison: NaN into every inactive block of the
  * captured step's memory pool between replays - a kernel that reads a buffer before its producer of THIS replay wrote it then shows up as
  * NaN instead of as the previous replay's nearly identical values). */

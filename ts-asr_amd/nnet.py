@@ -129,6 +129,20 @@ class LSTM(nn.Module):
             out = ops.mask_time(out, ops.abs_lengths(lengths, x.shape[1], 1))
         return out, hn
 
+    def forward_tokens(self, tokens, embedding, lengths=None):
+        """decoder(embedding(tokens), lengths=lengths) for the recipes' predictor (train_librispeechmix_scratch.py:117-119). With the
+        frozen one-hot Embedding of the TS-ASR YAMLs and bf16 compute, the embedding lookup and the LSTM's input projection collapse
+        into one launch (ops.lstm_onehot: a token selects a column of W_ih); anything else takes the two modules as they are."""
+        if (_COMPUTE_DTYPE == torch.bfloat16 and isinstance(embedding, Embedding) and embedding.consider_as_one_hot
+                and not embedding.Embedding.weight.requires_grad
+                and ops.lstm_onehot_supported(tokens, self.rnn, embedding.num_embeddings)):
+            C.require_gpu(tokens)
+            out = ops.lstm_onehot(tokens, self.rnn, embedding.blank_id)
+            if lengths is not None:
+                out = ops.mask_time(out, ops.abs_lengths(lengths, tokens.shape[1], 1))
+            return out, None
+        return self.forward(embedding(tokens), lengths=lengths)
+
 
 class LayerNorm(nn.Module):
     def __init__(self, input_size=None, input_shape=None, eps=1e-05, elementwise_affine=True):

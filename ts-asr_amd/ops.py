@@ -42,9 +42,13 @@ def seed_state(device):
     return _seed_dev[key]
 
 
+_LEN_CACHE = {}       # abs_lengths results of the current step
+
+
 def begin_step(device):
     """Call once at the start of a training step: restarts the per-step call index and advances the device seed counter."""
     _seed_counter[0] = 0
+    _LEN_CACHE.clear()
     if torch.device(device).type == "cuda":
         C.check(C.lib().tsasr_seed_advance(C.ptr(seed_state(device)), 0x9E3779B97F4A7C15, C.stream_ptr()), "tsasr_seed_advance")
 
@@ -177,6 +181,7 @@ def discard_queues():
     C.lib().tsasr_reduce_discard()
     C.lib().tsasr_relpos_dpk_discard()
     _DPK["on"] = False
+    _DPK["outs"].clear()
     _WG["keep"], _WG["ids"], _WG["params"], _WG["flops"], _WG["tiles"], _WG["bytes"] = [], set(), [], 0.0, 0, 0.0
     _DEFER["keep"], _DEFER["on"] = [], False
 
@@ -233,7 +238,7 @@ def wgrad_pending():
 
 # Deferred d(pk) passes of the attention backward (csrc/attention.hip, tsasr_relpos_dpk_defer): queued per layer while the gradient arena
 # is in backward, run as one grouped launch right in front of the grouped weight-gradient launch that consumes their outputs.
-_DPK = {"ring": None, "on": False}
+_DPK = {"ring": None, "on": False, "outs": set()}      # outs: data_ptr of every d(pk) tensor whose pass is still queued
 _DPK_MAX_JOBS = 64
 _DPK_DEFER = True        # (tests switch it off to compare with the per-layer launches)
 
@@ -253,6 +258,7 @@ def dpk_deferring():
 
 def dpk_flush():
     """Run every queued d(pk) pass now, on the current stream (two launches); a no-op when nothing is queued."""
+    _DPK["outs"].clear()
     if _DPK["ring"] is None or C.lib().tsasr_relpos_dpk_pending() == 0:
         return
     ring = _DPK["ring"]
@@ -426,9 +432,143 @@ class _LinearFn(torch.autograd.Function):
                     and weight.grad.is_contiguous()):
                 _wgrad_into(sink, weight, weight.grad.view(N, K), dy2, x2)                           # grad += dy^T . x
             else:
-                dpk_flush()     # dy may be a deferred d(pk): the plain GEMM reads it now
+                if dy.data_ptr() in _DPK["outs"] or dy2.data_ptr() in _DPK["outs"]:
+                    dpk_flush()     # dy is a deferred d(pk): the plain GEMM reads it now
                 dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
         return dx, dw
+
+
+_PTR_TABLES = {}     # device arrays of weight-shadow addresses for the batched projections, by the tuple of addresses
+
+
+class _ProjectManyFn(torch.autograd.Function):
+    """(x . W_0^T, ..., x . W_{L-1}^T) for one shared x [M, K] and L same-shaped weights in ONE launch (tsasr_gemm_bf16_nt_batched): the
+    projections of the positional table for every layer of an encoder. x carries no gradient; each weight gradient goes where
+    _LinearFn.backward would send it (the arena's grouped launch)."""
+
+    @staticmethod
+    def forward(ctx, x2, table, *weights):
+        L = len(weights)
+        N, K = weights[0].shape
+        M = x2.shape[0]
+        out = torch.empty(L, M, N, dtype=torch.bfloat16, device=x2.device)
+        with prof.region("gemm_bf16_nt_batched", 2.0 * M * N * K * L):
+            C.check(C.lib().tsasr_gemm_bf16_nt_batched(C.ptr(x2), C.ptr(table), C.ptr(out), M, N, K, x2.stride(0), K, N, M * N, L,
+                                                       C.stream_ptr()), "tsasr_gemm_bf16_nt_batched")
+        ctx.save_for_backward(x2)
+        ctx.weights = weights
+        return tuple(out[i] for i in range(L))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (x2,) = ctx.saved_tensors
+        M, K = x2.shape
+        grads = []
+        for i, (w, dy) in enumerate(zip(ctx.weights, dys)):
+            dw = None
+            if dy is not None and ctx.needs_input_grad[2 + i]:
+                N = w.shape[0]
+                dy2 = dy.reshape(M, N)
+                if not dy2.is_contiguous():
+                    dy2 = dy2.contiguous()
+                sink = _GRAD_SINK
+                if sink is not None and w.is_leaf and sink.accepts(w) and w.grad.dtype == torch.float32 and w.grad.is_contiguous():
+                    _wgrad_into(sink, w, w.grad.view(N, K), dy2, x2)
+                else:
+                    if dy.data_ptr() in _DPK["outs"] or dy2.data_ptr() in _DPK["outs"]:
+                        dpk_flush()
+                    dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(w.dtype).view(w.shape)
+            grads.append(dw)
+        return (None, None, *grads)
+
+
+def project_many(x2, weights):
+    """[x2 . W^T for W in weights] (bf16 [M, N] each) in one launch, or None when the batched kernel does not take the case: every
+    weight needs a live bf16 shadow at a fixed address (the gradient arena's: the address table is built once per set of weights,
+    outside any stream capture), same shape, K a multiple of 64."""
+    if len(weights) < 2 or x2.dim() != 2 or not x2.is_cuda or x2.dtype != torch.bfloat16 or x2.requires_grad or x2.stride(1) != 1 \
+            or x2.stride(0) % 8 or x2.data_ptr() % 16:
+        return None
+    N, K = weights[0].shape[0], weights[0].shape[1]
+    if K % 64 or N % 8 or x2.shape[1] != K:
+        return None
+    ptrs = []
+    for w in weights:
+        sh = getattr(w, "_bf16", None)
+        if (w.dim() != 2 or tuple(w.shape) != (N, K) or sh is None or getattr(w, "_bf16_ver", -1) != w._version or not sh.is_contiguous()
+                or sh.data_ptr() % 16 or not w.is_leaf):
+            return None
+        ptrs.append(sh.data_ptr())
+    key = tuple(ptrs)
+    table = _PTR_TABLES.get(key)
+    if table is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if len(_PTR_TABLES) > 64:
+            _PTR_TABLES.clear()
+        table = _PTR_TABLES[key] = torch.tensor(ptrs, dtype=torch.int64).to(x2.device)
+    return list(_ProjectManyFn.apply(x2, table, *weights))
+
+
+class _LinearEpiFn(torch.autograd.Function):
+    """dropout_p(LeakyReLU_slope(x . W^T + bias)) with the whole chain in the GEMM's epilogue (tsasr_gemm_bf16_fused mode 1: slope < 0 = no
+    activation): no element-wise pass over the output. Backward: the mask / activation derivative and the bias gradient in one pass
+    over dy when there is a mask or an activation (the kernel regenerates the mask from the seed), the bias gradient alone as column
+    sums otherwise; then the data and weight gradients exactly as _LinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, p, seed):
+        N, K = weight.shape[0], weight.shape[1]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w16 = _bf16_weight(weight).view(N, K) if weight.dim() == 3 else _bf16_weight(weight)
+        if w16.stride(1) != 1 or w16.stride(0) % 8 != 0 or w16.data_ptr() % 16 != 0:
+            w16 = w16.contiguous()
+        M = x2.shape[0]
+        b = None if bias is None else _f32(bias).contiguous()
+        y = gemm_bf16_fused(x2, w16, M, N, K, K, w16.stride(0), 0, 0, 1, bias=b, slope=float(slope), p=float(p), seed=seed)
+        masked = slope >= 0 or p > 0
+        ctx.save_for_backward(x2, w16, y if masked else None)
+        ctx.weight, ctx.bias, ctx.xshape, ctx.cfg = weight, bias, x.shape, (float(slope), float(p), seed)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16, y = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        slope, p, seed = ctx.cfg
+        N, K = weight.shape[0], weight.shape[1]
+        M = x2.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        db = None
+        if y is not None:
+            dz = torch.empty_like(y)
+            db = torch.empty(N, dtype=torch.float32, device=y.device) if bias is not None else None
+            _keep(db)
+            ws = _ws(C.lib().tsasr_colpart_workspace_bytes(M, N), y.device) if bias is not None else None
+            with prof.region("bias_act_dropout_bwd"):
+                C.check(C.lib().tsasr_bias_act_dropout_bwd(C.ptr(dy2), C.ptr(y), C.ptr(dz), C.ptr(db), M, N, slope, p, seed,
+                                                           C.ptr(seed_state(y.device)), C.io_dtype(y),
+                                                           C.ptr(ws), 0 if ws is None else ws.numel(), C.stream_ptr()),
+                        "tsasr_bias_act_dropout_bwd")
+            dy2 = dz
+        elif bias is not None and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(dy2, weight, w16, M, N, K).view(ctx.xshape)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = _GRAD_SINK
+            if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
+                    and weight.grad.is_contiguous()):
+                _wgrad_into(sink, weight, weight.grad.view(N, K), dy2, x2)
+            else:
+                dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
+        return dx, dw, (None if db is None else _pgrad(bias, db)), None, None, None
 
 
 def _wgrad_into(sink, weight, grad2d, dy2, x2):
@@ -441,7 +581,8 @@ def _wgrad_into(sink, weight, grad2d, dy2, x2):
         _WG["bytes"] = _WG.get("bytes", 0.0) + 2.0 * M * (N + K) + 8.0 * N * K   # dy and x (bf16) read once, the fp32 gradient read and written
         sink.wgrad_queued(weight)
         return
-    dpk_flush()         # dy2 may be a deferred d(pk): the split-K GEMM below reads it now
+    if dy2.data_ptr() in _DPK["outs"]:
+        dpk_flush()     # dy2 is a deferred d(pk): the split-K GEMM below reads it now
     gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, defer_ok=True)
     sink.mark_ready(weight)
 
@@ -529,13 +670,19 @@ def matmul_nt(x, weight):
     return F.linear(x, _w(weight, x))
 
 
+_LINEAR_EPILOGUE = True     # (tests switch it off to compare with the GEMM + element-wise pass pair)
+
+
 def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
-    """Library GEMM + ONE hand-written epilogue pass (bias, LeakyReLU, dropout); bias-only rows ride the GEMM epilogue."""
+    """bf16: ONE HIP GEMM with bias / LeakyReLU / dropout in its epilogue (_LinearEpiFn). Otherwise GEMM + one hand-written epilogue pass."""
     if act_slope is None and not (training and dropout_p > 0):
         if bias is None:
             return matmul_nt(x, weight)
         if not _gemm_ok(x, weight):
             return F.linear(x, _w(weight, x), _w(bias, x))
+    if _gemm_ok(x, weight) and _LINEAR_EPILOGUE:
+        p = float(dropout_p) if training else 0.0
+        return _LinearEpiFn.apply(x, weight, bias, -1.0 if act_slope is None else float(act_slope), p, next_seed() if p > 0 else 0)
     return bias_act_dropout(matmul_nt(x, weight), bias, act_slope, dropout_p, training)
 
 
@@ -562,10 +709,23 @@ class _LstmFn(torch.autograd.Function):
     weight gradients are single HIP GEMMs over all (b,t). Every launch is graph-capturable."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
-        B, U, I = x.shape
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, onehot_blank=None):
         H = w_hh.shape[1]
         dev = x.device
+        if onehot_blank is not None:
+            # x = token ids [B,U] of a frozen one-hot Embedding: the input projection is a column of W_ih per token - one launch writes
+            # the gate pre-activations (fp32 weights and biases, no rounding to bf16) and the padded one-hot rows the backward contracts with
+            B, U = x.shape
+            I = w_ih.shape[1]
+            Ip = (I + 2 + 7) // 8 * 8
+            tok = x if x.dtype == torch.int64 else x.long()
+            xp = torch.empty(B * U, Ip, dtype=torch.bfloat16, device=dev)
+            gates = torch.empty(B, U, H, 4, dtype=torch.float32, device=dev)
+            C.check(C.lib().tsasr_lstm_onehot_gates(C.ptr(tok.contiguous()), C.ptr(_f32(w_ih).contiguous()), C.ptr(_f32(b_ih).contiguous()),
+                                                    C.ptr(_f32(b_hh).contiguous()), C.ptr(gates), C.ptr(xp), B, U, H, I, Ip, int(onehot_blank),
+                                                    C.stream_ptr()), "tsasr_lstm_onehot_gates")
+            return _LstmFn._recurrence(ctx, xp, gates.view(B * U, 4 * H), w_ih, w_hh, b_ih, b_hh, (B, U, I))
+        B, U, I = x.shape
         # x-part of the gate pre-activations, laid out [B,U,H,4] (gate-minor: the kernels move a unit's four gates as one float4)
         perm = lambda t: t.view(4, H, *t.shape[1:]).transpose(0, 1).reshape(t.shape)  # noqa: E731
         # input projection on the HIP GEMM too: the inner dimension (28 embedding columns) is padded to a multiple of 8 and the bias
@@ -582,6 +742,13 @@ class _LstmFn(torch.autograd.Function):
         wp[:, I] = b_hi
         wp[:, I + 1] = bias - b_hi.float()
         gates = gemm_bf16(xp, wp, B * U, 4 * H, Ip, Ip, Ip, 0, 0, out_dtype=torch.float32)
+        return _LstmFn._recurrence(ctx, xp, gates, w_ih, w_hh, b_ih, b_hh, (B, U, I))
+
+    @staticmethod
+    def _recurrence(ctx, xp, gates, w_ih, w_hh, b_ih, b_hh, in_shape):
+        B, U, I = in_shape
+        H = w_hh.shape[1]
+        dev = xp.device
         c = torch.empty(B, U, H, dtype=torch.float32, device=dev)
         h = torch.empty(B, U, H, dtype=torch.bfloat16, device=dev)
         whh16 = _bf16_weight(w_hh).contiguous()
@@ -629,7 +796,20 @@ class _LstmFn(torch.autograd.Function):
             wq = torch.zeros(4 * H, Ip, dtype=torch.bfloat16, device=dev)
             wq[:, :I] = w_ih
             dx = gemm_bf16(dg2, wq, B * U, Ip, 4 * H, 4 * H, Ip, 0, 1)[:, :I].reshape(B, U, I)
-        return dx, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db.to(b_ih.dtype), db.to(b_hh.dtype)
+        return dx, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), db.to(b_ih.dtype), db.to(b_hh.dtype), None
+
+
+def lstm_onehot_supported(tokens, rnn, num_embeddings):
+    """True when ops.lstm_onehot takes this predictor: token ids on the GPU, single-layer unidirectional LSTM over V-1 one-hot inputs,
+    more than one step, hidden size the recurrence kernels take."""
+    H = rnn.hidden_size
+    return (tokens.is_cuda and not tokens.dtype.is_floating_point and tokens.dim() == 2 and tokens.shape[1] > 1 and rnn.num_layers == 1
+            and not rnn.bidirectional and rnn.bias and H % 16 == 0 and rnn.input_size == num_embeddings - 1 and rnn.input_size + 2 <= H)
+
+
+def lstm_onehot(tokens, rnn, blank):
+    """LSTM over one-hot embedded ``tokens`` [B,U] (frozen Embedding(consider_as_one_hot=True)): bf16 outputs [B,U,H]."""
+    return _LstmFn.apply(tokens, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, int(blank))
 
 
 def lstm(x, rnn, hx=None):
@@ -989,11 +1169,21 @@ def abs_lengths(rel, dim, mode=0):
     torch.round: models/conformer.py:272, SB/nnet/losses.py:58-59), 1 = floor (SB/nnet/RNN.py:35), 2 = ceil clamped to dim."""
     import ctypes
     C.require_gpu(rel)
+    # the recipe asks for the same lengths several times per step (encoder mask, joint, loss): one launch per (tensor, size, rule,
+    # stream). An entry holds its source tensor, so the address cannot be handed to another tensor while the entry lives; an in-place
+    # update of the source changes its version. Cleared at every begin_step.
+    key = (rel.data_ptr(), rel._version, tuple(rel.shape), rel.dtype, int(dim), int(mode), torch.cuda.current_stream().cuda_stream)
+    hit = _LEN_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
     r = rel.detach().float().contiguous()
     out = torch.empty(r.shape[0], dtype=torch.int32, device=r.device)
     pr, po = (ctypes.c_void_p * 1)(r.data_ptr()), (ctypes.c_void_p * 1)(out.data_ptr())
     pd, pm = (ctypes.c_int * 1)(int(dim)), (ctypes.c_int * 1)(int(mode))
     C.check(C.lib().tsasr_abs_lengths(pr, po, pd, pm, 1, r.shape[0], C.stream_ptr()), "tsasr_abs_lengths")
+    if len(_LEN_CACHE) >= 32:
+        _LEN_CACHE.clear()
+    _LEN_CACHE[key] = (rel, out)
     return out
 
 
@@ -1348,6 +1538,7 @@ class _RelPosAttnFn(torch.autograd.Function):
                  and getattr(sink, "collect_wgrads", False) and _WG["ring"] is not None and C.lib().tsasr_relpos_dpk_pending() < _DPK_MAX_JOBS)
         if defer:
             _keep(key_lens)               # the queued pass reads it at the flush, after autograd has released this node's saved tensors
+            _DPK["outs"].add(dpk.data_ptr())    # whoever reads dpk outside the grouped weight-gradient launch flushes first (_LinearFn.backward)
         if _DPK["on"] and not defer:      # this call launches its own pass (queued ones first: the switch refuses to go off over a queue)
             dpk_flush()
             C.check(C.lib().tsasr_relpos_dpk_defer(0), "tsasr_relpos_dpk_defer")

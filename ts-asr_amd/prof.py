@@ -2,6 +2,7 @@
 bench.py switches it on for the timed region to obtain the live average launch duration of a named kernel family
 (the `roofline` object of its JSON line); off by default - zero overhead in training."""
 import contextlib
+import os
 
 import torch
 
@@ -80,3 +81,38 @@ def reset():
     _records.clear()
     _work.clear()
     _bytes.clear()
+
+
+# ---- phase stamps inside a captured step (tools/step_stamps.py) ------------------------------------------------------------------------
+# TSASR_STAMPS=1: the recipe drops a one-thread kernel that stores the device wall clock at a few points of the step, on whatever stream
+# is current there. Replayed with the graph, they give the true start time of each phase without a profiler attached.
+STAMPS = os.environ.get("TSASR_STAMPS", "0") == "1"
+_stamp_buf = None
+_stamp_names = []
+
+
+def stamp_begin(device):
+    """Start of a step: (re)use a 256-slot buffer (allocated once, before any capture)."""
+    global _stamp_buf
+    if not STAMPS:
+        return
+    if _stamp_buf is None:
+        _stamp_buf = torch.zeros(256, dtype=torch.int64, device=device)
+    _stamp_names.clear()
+
+
+def stamp(name):
+    if not STAMPS or _stamp_buf is None or len(_stamp_names) >= 256:
+        return
+    from . import _capi as C
+    k = len(_stamp_names)
+    _stamp_names.append(name)
+    C.check(C.lib().tsasr_debug_stamp(C.ptr(_stamp_buf[k:k + 1]), C.stream_ptr()), "tsasr_debug_stamp")
+
+
+def stamps_us():
+    """[(name, microseconds since the first stamp)] of the last step that ran (host read)."""
+    if _stamp_buf is None or not _stamp_names:
+        return []
+    t = _stamp_buf[:len(_stamp_names)].cpu().tolist()
+    return [(n, (v - t[0]) / 100.0) for n, v in zip(_stamp_names, t)]

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .. import core, rnnt
+from .. import core, prof, rnnt
 from ..nnet import abs_lengths_round
 
 Stage = core.Stage
@@ -83,8 +83,11 @@ class TSASR(core.Brain):
         return self.modules.speaker_proj(embs), enroll_lens
 
     def _predictor(self, tokens_bos, tokens_bos_lens):
-        embs = self.modules.embedding(tokens_bos)
-        dec_out, _ = self.modules.decoder(embs, lengths=tokens_bos_lens)
+        dec = self.modules.decoder
+        if hasattr(dec, "forward_tokens"):       # embedding + decoder in one call: one-hot tokens never become a [B,U,V-1] tensor
+            dec_out, _ = dec.forward_tokens(tokens_bos, self.modules.embedding, lengths=tokens_bos_lens)
+        else:
+            dec_out, _ = dec(self.modules.embedding(tokens_bos), lengths=tokens_bos_lens)
         return self.modules.decoder_proj(dec_out)
 
     def _side_stream(self):
@@ -98,10 +101,12 @@ class TSASR(core.Brain):
         when the mixture encoder's and front-end's backward have been enqueued on the main stream. Their queued weight gradients
         (three quarters of the step's) are launched there now, as one grouped kernel that runs beside the speaker branch's small,
         latency-bound backward kernels instead of after them; the rest follows in finish_backward. The gradient passes through."""
+        prof.stamp("speaker backward starts [side]")
         arena = getattr(self, "arena", None)
         if arena is not None and arena.in_backward and getattr(arena, "_main_stream", None) is not None:
             with torch.cuda.stream(arena._main_stream):
                 arena.flush_wgrads(hold=True)
+                prof.stamp("early weight gradients done [main]")
         return None
 
     def compute_forward(self, batch, stage):
@@ -126,6 +131,7 @@ class TSASR(core.Brain):
                 spk, enroll_lens = self._speaker_embedding(batch, epoch)
                 spk_ready = torch.cuda.Event()
                 spk_ready.record(side)
+                prof.stamp("speaker forward done [side]")
                 if spk is not None and spk.requires_grad:
                     spk.register_hook(self._flush_main_wgrads)
                 # The predictor follows the speaker branch on the forked stream, in eager and in captured steps alike (one autograd
@@ -135,8 +141,12 @@ class TSASR(core.Brain):
                 # (profiles/r03_notes.md section 1; the library no longer contains such instructions). "2" = speaker branch only.
                 if _OVERLAP_MODE != "2":
                     dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+                    prof.stamp("predictor forward done [side]")
+                    if prof.STAMPS and dec_out.requires_grad:
+                        dec_out.register_hook(lambda g: prof.stamp("predictor backward starts [side]"))
 
             def speaker_embs():
+                prof.stamp("mixture reaches the injection [main]")
                 cur.wait_event(spk_ready)
                 spk.record_stream(cur)
                 return spk
@@ -154,8 +164,14 @@ class TSASR(core.Brain):
         if augment and "augmentation" in self.modules:           # train_librispeechmix_scratch.py:91-94
             feats = self.modules.augmentation(feats)
         feats = self.modules.frontend(feats)
+        prof.stamp("mixture front-end forward done [main]")
+        if prof.STAMPS and feats.requires_grad:
+            feats.register_hook(lambda g: prof.stamp("mixture encoder backward done [main]"))
         enc_out = self.modules.encoder(feats, mixed_lens, speaker_embs, enroll_lens)
         enc_out = self.modules.encoder_proj(enc_out)
+        prof.stamp("mixture encoder forward done [main]")
+        if prof.STAMPS and enc_out.requires_grad:
+            enc_out.register_hook(lambda g: prof.stamp("joint backward done [main]"))
 
         if dec_out is None:
             dec_out = self._predictor(tokens_bos, tokens_bos_lens)
@@ -169,6 +185,7 @@ class TSASR(core.Brain):
         ulen = abs_lengths_round(batch.tokens.lengths.to(self.device), batch.tokens.data.shape[1])
         logits = rnnt.fused_joint_logits(enc_out, dec_out, head.weight, head.bias, self.modules.joiner.nonlinearity.negative_slope,
                                          tlen, ulen)
+        prof.stamp("joint forward done [main]")
         hyps = None
         if stage == Stage.VALID:
             if epoch % getattr(hp, "valid_search_freq", 1) == 0 and hasattr(hp, "greedy_searcher"):
@@ -182,6 +199,7 @@ class TSASR(core.Brain):
         _, mixed_lens = batch.mixed_sig
         tokens, tokens_lens = batch.tokens
         loss = self.hparams.transducer_loss(logits, tokens, mixed_lens, tokens_lens)
+        prof.stamp("loss forward done [main]")
         if hyps is not None:
             self.last_hyps = hyps  # the reference feeds them to its WER/CER statistics (out of scope here)
         return loss
