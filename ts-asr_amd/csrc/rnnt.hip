@@ -259,36 +259,8 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
 
     bf16_t *my_lds = a_lds[wave];
     const bool row_ok = (u0 + r) < U1;
-    // software pipeline over the frames (ldl == 32): frame t+1's dlogits row and enc values are requested before frame t's MFMAs
-    const bool pipe = (ldl == 32);
-    const float *dl0 = dlogits + (((size_t)b * Tn) * U1 + min(u0 + r, U1 - 1)) * 32;
-    float afn[2][8];
-    T en[KB];
-    if (pipe && t_end > t_lo) {
-        load_a_raw32(dl0 + (size_t)t_lo * U1 * 32, h, afn);
-#pragma unroll
-        for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + t_lo) * J + kbc[i] * 32 + r];
-    }
-    for (int t = t_lo; t < t_end; ++t) {
-        bf16x8 a[2];
-        float af[2][8], ev[KB];
-        if (pipe) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) af[s2][j] = afn[s2][j];
-#pragma unroll
-            for (int i = 0; i < KB; ++i) ev[i] = (float)en[i];
-            const int tn = min(t + 1, Tn - 1);
-            load_a_raw32(dl0 + (size_t)tn * U1 * 32, h, afn);
-#pragma unroll
-            for (int i = 0; i < KB; ++i) en[i] = enc[((size_t)b * Tn + tn) * J + kbc[i] * 32 + r];
-            cvt_a(af, row_ok, a);
-        } else {
-            load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
-#pragma unroll
-            for (int i = 0; i < KB; ++i) ev[i] = f.kb[i] >= 0 ? ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r) : 0.f;
-        }
+    // one frame: a = this lane's dlogits fragments (bf16), af = the same values in fp32 (bias-gradient sums), ev = enc[b, t, k] per k-block
+    auto frame = [&](int t, const bf16x8 (&a)[2], const float (&af)[2][8], const float (&ev)[KB]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -334,6 +306,53 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
             }
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], hb[0], wacc[i], 0, 0, 0);
             wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], hb[1], wacc[i], 0, 0, 0);
+        }
+    };
+    if (ldl == 32) {
+        // software pipeline over the frames (a dlogits row is one 128-byte line): the dlogits fragments and enc values of frame t + NP are
+        // requested when frame t's have been converted, NP frames ahead - a frame is ~1 us of issue for the one wave a SIMD holds here,
+        // a round trip to HBM about twice that (one frame ahead left half of every frame waiting: 0.56 ms per launch at configs[1])
+        constexpr int NP = 3;     // measured at configs[1] (ms per step / joint + loss): 2 -> 12.34 / 0.93, 3 -> 12.24 / 0.87, 4 -> 12.27 / 0.89, 6 -> 12.32 / 0.93
+        const float *dl0 = dlogits + (((size_t)b * Tn) * U1 + min(u0 + r, U1 - 1)) * 32;
+        float sa[NP][2][8];
+        T se[NP][KB];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int tt = min(t_lo + s, Tn - 1);
+            load_a_raw32(dl0 + (size_t)tt * U1 * 32, h, sa[s]);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) se[s][i] = enc[((size_t)b * Tn + tt) * J + kbc[i] * 32 + r];
+        }
+        for (int t0 = t_lo; t0 < t_end; t0 += NP) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const int t = t0 + s;
+                if (t < t_end) {          // wave-uniform
+                    bf16x8 a[2];
+                    float af[2][8], ev[KB];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) af[s2][j] = sa[s][s2][j];
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) ev[i] = (float)se[s][i];
+                    const int tn = min(t + NP, Tn - 1);
+                    load_a_raw32(dl0 + (size_t)tn * U1 * 32, h, sa[s]);
+#pragma unroll
+                    for (int i = 0; i < KB; ++i) se[s][i] = enc[((size_t)b * Tn + tn) * J + kbc[i] * 32 + r];
+                    cvt_a(af, row_ok, a);
+                    frame(t, a, af, ev);
+                }
+            }
+        }
+    } else {
+        for (int t = t_lo; t < t_end; ++t) {
+            bf16x8 a[2];
+            float af[2][8], ev[KB];
+            load_a_frags(dlogits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl, row_ok, ldl, h, a, af);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) ev[i] = f.kb[i] >= 0 ? ld1(enc + ((size_t)b * Tn + t) * J + f.kb[i] * 32 + r) : 0.f;
+            frame(t, a, af, ev);
         }
     }
     if (denc_part && h == 0) {   // frames this tile never visited (beyond the utterance, or the tile lies outside the lattice)
