@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
     const int nsteps = Tb + G - 1;
     float prev[K], cur[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) prev[i] = NEG_INF;
+    for (int i = 0; i < K; ++i) prev[i] = cur[i] = NEG_INF;
     float edge = NEG_INF;  // boundary value handed to the neighbour thread
     // The per-step operands (log-probabilities of blank / label for this thread's K columns at its current frame) are requested PF
     // steps ahead, unconditionally (frame index clamped): fetched inside the guarded step they cost one L2 round trip per step,
@@ -652,52 +652,58 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
         };
 #pragma unroll
         for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
-        // a chunk of PF steps; GUARD = false when every thread has a valid frame in every step of the chunk (G-1 <= s < Tb): that
-        // version is straight-line code, so the compiler can count the outstanding prefetches exactly instead of draining them
-        // (s_waitcnt vmcnt(0)) behind every divergent guard
+        // a chunk of PF steps; GUARD = false when every thread has a valid frame in every step of the chunk (G-1 <= s < Tb). The guarded
+        // form is STRAIGHT-LINE code too: a thread outside its frames computes on a clamped frame and keeps its old values by select, and
+        // stores them again at the clamped frame (before its first frame: -inf into alpha(0, u), overwritten in order by the same thread
+        // when it gets there; after its last: alpha(Tb-1, u) once more). With the step inside a divergent guard the compiler drained
+        // every outstanding prefetch behind it (37 x s_waitcnt vmcnt(0)): the 2 x 63 ramp steps of a 313-step lattice cost a memory
+        // round trip each - 0.6 us against 0.2 us for an unguarded step.
         auto chunk = [&](int s0, auto guard_tag) {
             constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
-                if (GUARD && s >= nsteps) break;
                 const int t = s - g;
+                const bool valid = !GUARD || (t >= 0 && t < Tb);
+                const int tc = GUARD ? min(max(t, 0), Tb - 1) : t;
                 float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (NW > 1 && l == 0 && wave > 0) left = edge_lds[(s + 1) & 1][wave - 1];          // written in step s-1
-                if (!GUARD || (t >= 0 && t < Tb)) {
+                float nv[K];
 #pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        const int u = K * g + i;
-                        const float noemit = (t > 0) ? prev[i] + qb[d][i] : NEG_INF;
-                        const float lft = (i == 0) ? left : cur[i > 0 ? i - 1 : 0];
-                        const float emit = (u > 0) ? lft + qe[d][i] : NEG_INF;
-                        float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
-                        if (u > Ub) a = NEG_INF;
-                        cur[i] = a;
-                    }
-                    float *pa = w.alpha + base + (size_t)t * U1P;
-#pragma unroll
-                    for (int i = 0; i < K; ++i) { pa[i] = cur[i]; prev[i] = cur[i]; }
-                    edge = cur[K - 1];
-                    if (NW > 1 && l == 63) edge_lds[s & 1][wave] = edge;
-                    if (GUARD && t == Tb - 1) {
-#pragma unroll
-                        for (int i = 0; i < K; ++i)
-                            if (K * g + i == Ub) {
-                                const float lp = cur[i] + w.lpb[base + (size_t)t * U1P + i];
-                                w.logp[b] = lp;
-                                costs[b] = -lp;
-                            }
-                    }
+                for (int i = 0; i < K; ++i) {
+                    const int u = K * g + i;
+                    const float noemit = (t > 0) ? prev[i] + qb[d][i] : NEG_INF;
+                    const float lft = (i == 0) ? left : nv[i > 0 ? i - 1 : 0];
+                    const float emit = (u > 0) ? lft + qe[d][i] : NEG_INF;
+                    float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
+                    if (u > Ub) a = NEG_INF;
+                    nv[i] = a;
                 }
+                float *pa = w.alpha + base + (size_t)tc * U1P;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    cur[i] = valid ? nv[i] : cur[i];
+                    pa[i] = cur[i];
+                    prev[i] = cur[i];
+                }
+                edge = cur[K - 1];
+                if (NW > 1 && l == 63) edge_lds[s & 1][wave] = edge;
                 fetch(s + PF, qb[d], qe[d]);
                 if (NW > 1) ab_step_barrier();
             }
         };
-        for (int s0 = 0; s0 < nsteps; s0 += PF) {
-            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});   // (t == Tb-1 only occurs in guarded chunks)
+        for (int s0 = 0; s0 < nsteps; s0 += PF) {     // (a last partial chunk runs to its end: the steps past nsteps hold no valid frame)
+            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});
             else chunk(s0, std::true_type{});
         }
+        // the thread that owns column Ub still holds alpha(Tb-1, Ub)
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (K * g + i == Ub) {
+                const float lp = cur[i] + w.lpb[base + (size_t)(Tb - 1) * U1P + i];
+                w.logp[b] = lp;
+                costs[b] = -lp;
+            }
     } else {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
             const int t = min(max(Tb - 1 - (ss - (G - 1 - g)), 0), Tb - 1);
@@ -708,33 +714,37 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
         };
 #pragma unroll
         for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
-        auto chunk = [&](int s0, auto guard_tag) {
+        auto chunk = [&](int s0, auto guard_tag) {       // straight-line in both forms, as in the alpha direction
             constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
                 const int s = s0 + d;
-                if (GUARD && s >= nsteps) break;
                 const int t = Tb - 1 - (s - (G - 1 - g));
+                const bool valid = !GUARD || (t >= 0 && t < Tb);
+                const int tc = GUARD ? min(max(t, 0), Tb - 1) : t;
                 float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
                 if (NW > 1 && l == 63 && wave < NW - 1) right = edge_lds[(s + 1) & 1][wave + 1];
-                if (!GUARD || (t >= 0 && t < Tb)) {
+                float nv[K];
 #pragma unroll
-                    for (int i = K - 1; i >= 0; --i) {
-                        const int u = K * g + i;
-                        const float lb = qb[d][i];
-                        const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
-                        const float rgt = (i == K - 1) ? right : cur[i < K - 1 ? i + 1 : K - 1];
-                        const float emit = (u < Ub) ? rgt + qe[d][i] : NEG_INF;
-                        float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
-                        if (u > Ub) v = NEG_INF;
-                        cur[i] = v;
-                    }
-                    float *pbeta = w.beta + base + (size_t)t * U1P;
-#pragma unroll
-                    for (int i = 0; i < K; ++i) { pbeta[i] = cur[i]; prev[i] = cur[i]; }
-                    edge = cur[0];
-                    if (NW > 1 && l == 0) edge_lds[s & 1][wave] = edge;
+                for (int i = K - 1; i >= 0; --i) {
+                    const int u = K * g + i;
+                    const float lb = qb[d][i];
+                    const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
+                    const float rgt = (i == K - 1) ? right : nv[i < K - 1 ? i + 1 : K - 1];
+                    const float emit = (u < Ub) ? rgt + qe[d][i] : NEG_INF;
+                    float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
+                    if (u > Ub) v = NEG_INF;
+                    nv[i] = v;
                 }
+                float *pbeta = w.beta + base + (size_t)tc * U1P;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    cur[i] = valid ? nv[i] : cur[i];
+                    pbeta[i] = cur[i];
+                    prev[i] = cur[i];
+                }
+                edge = cur[0];
+                if (NW > 1 && l == 0) edge_lds[s & 1][wave] = edge;
                 fetch(s + PF, qb[d], qe[d]);
                 if (NW > 1) ab_step_barrier();
             }
