@@ -137,6 +137,100 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
     }
 }
 
+// The same forward with the head matrix in REGISTERS (J = 16 * NKS known at compile time, bf16 activations): a lane's 16-byte W pieces for
+// all NKS k-steps are loaded once (4 * NKS VGPRs), which (a) removes one of the three LDS reads of every k-step and (b) halves the
+// workgroup's LDS (dec tile + one enc row per wave: 47 KB at J = 640), so two workgroups share a CU and a SIMD holds two waves - the
+// one-wave form left the LDS round trips and the MFMA issue of a frame uncovered (the kernel is bound by the VALU work of
+// h = lrelu(enc + dec), 5.5 operations per lattice cell and joint dimension).
+template <int NKS>
+__global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__restrict__ enc, const bf16_t *__restrict__ dec,
+                                                                const float *__restrict__ W, const float *__restrict__ bias,
+                                                                float *__restrict__ logits, int Tn, int U1, int V, int ldl, float slope) {
+    constexpr int J = 16 * NKS, S = J + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t *d_lds = reinterpret_cast<bf16_t *>(smem);     // [32][S]
+    const int b = blockIdx.z, u0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // the head matrix goes through the (still unused) dec-tile area once: fp32 -> bf16 rows in LDS, from there this lane's NKS pieces
+    // into registers (a direct per-lane fetch of 8 * NKS fp32 values had all of them in flight at once and spilled)
+    for (int i = tid; i < 32 * (J / 8); i += 256) {
+        const int row = i / (J / 8), c = (i % (J / 8)) * 8;
+        float w8[8];
+        ld8(W + (size_t)min(row, V - 1) * J + c, w8);
+        if (row >= V) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = 0.f;
+        }
+        st8(d_lds + row * S + c, w8);
+    }
+    __syncthreads();
+    bf16x8 wreg[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) wreg[s] = *reinterpret_cast<const bf16x8 *>(d_lds + r * S + 8 * h + 16 * s);
+    __syncthreads();
+    for (int i = tid; i < 32 * (J / 8); i += 256) {
+        const int row = i / (J / 8), c = (i % (J / 8)) * 8;
+        uint4 v = *reinterpret_cast<const uint4 *>(dec + ((size_t)b * U1 + min(u0 + row, U1 - 1)) * J + c);
+        if (u0 + row >= U1) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(d_lds + row * S + c) = v;
+    }
+    float *b_lds = reinterpret_cast<float *>(d_lds + 32 * S + 4 * J);     // [32] head bias (0 beyond V): read per frame, not held in 16 registers
+    if (tid < 32) b_lds[tid] = bias[min(tid, V - 1)] * (tid < V ? 1.f : 0.f);
+    __syncthreads();
+    const int tchunk = cdiv_dev(Tn, (int)gridDim.y);
+    const int t_begin = blockIdx.y * tchunk, t_end = min(Tn, t_begin + tchunk);
+    const bf16_t *drow = d_lds + r * S + 8 * h;
+    bf16_t *e_w = d_lds + 32 * S + wave * J;              // [4 waves][J]: the frame's enc row, fetched once per wave, read as broadcasts
+    constexpr int NQ = (J + 511) / 512;                   // 16-byte pieces per lane
+    uint4 stg[NQ];
+    auto request = [&](int t) {
+        const bf16_t *src = enc + ((size_t)b * Tn + min(t, Tn - 1)) * J;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) stg[q] = *reinterpret_cast<const uint4 *>(src + min((q * 64 + lane) * 8, J - 8));
+    };
+    request(t_begin + wave);
+    for (int t = t_begin + wave; t < t_end; t += 4) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (q * 64 + lane) * 8;
+            if (c < J) *reinterpret_cast<uint4 *>(e_w + c) = stg[q];
+        }
+        request(t + 4);
+        __builtin_amdgcn_wave_barrier();
+        const bf16_t *erow = e_w + 8 * h;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            float e8[8], d8[8];
+            ld8(erow + 16 * s, e8);
+            ld8(drow + 16 * s, d8);
+            bf16x8 hb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hb[j] = (bf16_t)lrelu(e8[j] + d8[j], slope);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], hb, acc, 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 2 * NKS LDS reads of a frame (it spilled 149 VGPRs)
+        }
+        __builtin_amdgcn_wave_barrier();                  // this frame's reads of e_w are issued before the next frame's row lands in it
+        if (u0 + r < U1) {
+            float *orow = logits + (((size_t)b * Tn + t) * U1 + u0 + r) * ldl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int v0 = 8 * q + 4 * h;
+                if (v0 < ldl) {
+                    const float4 bq = *reinterpret_cast<const float4 *>(b_lds + v0);
+                    float4 o;
+                    o.x = (v0 + 0 < V) ? acc[4 * q + 0] + bq.x : 0.f;
+                    o.y = (v0 + 1 < V) ? acc[4 * q + 1] + bq.y : 0.f;
+                    o.z = (v0 + 2 < V) ? acc[4 * q + 2] + bq.z : 0.f;
+                    o.w = (v0 + 3 < V) ? acc[4 * q + 3] + bq.w : 0.f;
+                    *reinterpret_cast<float4 *>(orow + v0) = o;
+                }
+            }
+        }
+    }
+}
+
 // ============================================================================================
 // joint backward: shared "masked dh tile" machinery
 // ============================================================================================
@@ -865,6 +959,10 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)joint_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         joint_fwd_kernel<float><<<grid, 256, lds, st>>>((const float *)enc, (const float *)dec, W, bias, logits, T, U1, J, V, ldl, slope);
+    } else if (io_dtype == TSASR_BF16 && J == 640) {      // the TS-ASR joint (joint_dim 640): head matrix in registers, two workgroups per CU
+        const size_t lds_r = (size_t)32 * (J + 8) * sizeof(bf16_t) + (size_t)4 * J * sizeof(bf16_t) + 32 * sizeof(float);
+        while (nut * B * tsplit < 1024 && T / (tsplit * 2) >= 16) tsplit *= 2;      // (512 / 1024 / 2048 workgroups measured equal)
+        joint_fwd_regw_kernel<40><<<dim3(nut, tsplit, B), 256, lds_r, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, V, ldl, slope);
     } else if (io_dtype == TSASR_BF16) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)joint_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
