@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -93,6 +94,18 @@ __device__ __forceinline__ void load8_clamped(const T *__restrict__ row, int d0,
             const float x = ld1(row + min(d0 + j, Dh - 1));
             v[j] = (d0 + j < Dh) ? x : 0.f;
         }
+    }
+}
+
+// The same 8 elements WITHOUT the zeroing of the dims at and beyond Dh (the address is clamped into the row; the caller masks when it
+// consumes the values): load8_clamped's mask overwrites the load's destination, i.e. waits for the load on the spot - a sequence of
+// calls was a sequence of round trips (20 of them at the head of relpos_attn_bwd_q). FAST as a compile-time flag: no branch per call.
+template <typename T, bool FAST>
+__device__ __forceinline__ void load8_raw(const T *__restrict__ row, int d0, int Dh, float (&v)[8]) {
+    if constexpr (FAST) ld8(row + min(d0, Dh - 8), v);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ld1(row + min(d0 + j, Dh - 1));
     }
 }
 
@@ -207,12 +220,17 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
     {
         const bool fast = (Dh % 8) == 0;
         float q8[4][8], u8[4][8], v8[4][8];
+        auto fetch = [&](auto fast_tag) {      // all 12 pieces in flight together (masked below)
+            constexpr bool F = decltype(fast_tag)::value;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            load8_clamped<T>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, fast, q8[s]);
-            load8_clamped<float>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, fast, u8[s]);
-            load8_clamped<float>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
-        }
+            for (int s = 0; s < 4; ++s) {
+                load8_raw<T, F>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, q8[s]);
+                load8_raw<float, F>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, u8[s]);
+                load8_raw<float, F>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, v8[s]);
+            }
+        };
+        if (fast) fetch(std::true_type{});
+        else fetch(std::false_type{});
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -733,20 +751,25 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
     {
         const bool fast = (Dh % 8) == 0;
         float q8[4][8], u8[4][8], v8[4][8], d8[4][8], o8[4][8];
+        auto fetch = [&](auto fast_tag) {      // all 20 pieces in flight together (masked below)
+            constexpr bool F = decltype(fast_tag)::value;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            load8_clamped<T>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, fast, q8[s]);
-            load8_clamped<float>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, fast, u8[s]);
-            load8_clamped<float>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, fast, v8[s]);
-            load8_clamped<T>(dorow, 16 * s + 8 * hh, Dh, fast, d8[s]);
-            load8_clamped<T>(orow, 16 * s + 8 * hh, Dh, fast, o8[s]);
-        }
+            for (int s = 0; s < 4; ++s) {
+                load8_raw<T, F>(q_base + (long long)iqc * row_stride, 16 * s + 8 * hh, Dh, q8[s]);
+                load8_raw<float, F>(bias_u + h * Dh, 16 * s + 8 * hh, Dh, u8[s]);
+                load8_raw<float, F>(bias_v + h * Dh, 16 * s + 8 * hh, Dh, v8[s]);
+                load8_raw<T, F>(dorow, 16 * s + 8 * hh, Dh, d8[s]);
+                load8_raw<T, F>(orow, 16 * s + 8 * hh, Dh, o8[s]);
+            }
+        };
+        if (fast) fetch(std::true_type{});
+        else fetch(std::false_type{});
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool ok = 16 * s + 8 * hh + j < Dh;
-                const float dd = q_ok ? d8[s][j] : 0.f, oo = q_ok ? o8[s][j] : 0.f;
+                const float dd = (q_ok && ok) ? d8[s][j] : 0.f, oo = (q_ok && ok) ? o8[s][j] : 0.f;
                 qu[s][j] = (bf16_t)(ok ? q8[s][j] + u8[s][j] : 0.f);
                 qv[s][j] = (bf16_t)(ok ? q8[s][j] + v8[s][j] : 0.f);
                 dob[s][j] = (bf16_t)dd;
@@ -1029,22 +1052,27 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int c = (tid & 7) * 8, rr0 = tid >> 3;           // staging: 8 column chunks x 32 rows per pass, 2 passes
     const bool fast_d = (Dh % 8) == 0;
-    float bu8[8], bv8[8];
-    load8_clamped<float>(bias_u + h * Dh, c, Dh, fast_d, bu8);
-    load8_clamped<float>(bias_v + h * Dh, c, Dh, fast_d, bv8);
+    float bu8[8], bv8[8];     // (raw pieces: the dims at and beyond Dh are masked where the values are used)
+    if (fast_d) { load8_raw<float, true>(bias_u + h * Dh, c, Dh, bu8); load8_raw<float, true>(bias_v + h * Dh, c, Dh, bv8); }
+    else { load8_raw<float, false>(bias_u + h * Dh, c, Dh, bu8); load8_raw<float, false>(bias_v + h * Dh, c, Dh, bv8); }
     f32x16 dk = {0}, dv = {0};
     // queries that can reach these keys: all of them, or (causal) those at or after the first key of the workgroup
     const int i_begin = causal ? (((j0 / causal) * causal) / 64) * 64 : 0;
     float xpv[2][8], xsv[2][8], dov[2][8], qv8[2][8];
-    auto request = [&](int i0n) {   // always-issued clamped loads; masked at the LDS store
+    auto request_t = [&](int i0n, auto fast_tag) {   // always-issued clamped loads, all 8 in flight together; masked at the LDS store
+        constexpr bool F = decltype(fast_tag)::value;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int ic = min(i0n + rr0 + 32 * it, Tn - 1);
             ld8(pd_base + (long long)ic * Tp + c, xpv[it]);
             ld8(ds_base + (long long)ic * Tp + c, xsv[it]);
-            load8_clamped<T>(do_base + (long long)ic * D, c, Dh, fast_d, dov[it]);
-            load8_clamped<T>(q_base + (long long)ic * row_stride, c, Dh, fast_d, qv8[it]);
+            load8_raw<T, F>(do_base + (long long)ic * D, c, Dh, dov[it]);
+            load8_raw<T, F>(q_base + (long long)ic * row_stride, c, Dh, qv8[it]);
         }
+    };
+    auto request = [&](int i0n) {
+        if (fast_d) request_t(i0n, std::true_type{});
+        else request_t(i0n, std::false_type{});
     };
     if (i_begin < Tn) request(i_begin);
     for (int i0 = i_begin; i0 < Tn; i0 += 64) {
@@ -1059,7 +1087,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
                 const bool ok = live && c + e < Dh;
                 a[e] = ok ? qv8[it][e] + bu8[e] : 0.f;
                 cv[e] = ok ? qv8[it][e] + bv8[e] : 0.f;
-                if (!live) { xpv[it][e] = 0.f; xsv[it][e] = 0.f; dov[it][e] = 0.f; }
+                if (!live) { xpv[it][e] = 0.f; xsv[it][e] = 0.f; }
+                if (!ok) dov[it][e] = 0.f;
             }
             st8(xp + rr * KV2_LD + c, xpv[it]);
             st8(xs + rr * KV2_LD + c, xsv[it]);
@@ -1161,7 +1190,10 @@ __device__ __forceinline__ void dpk_body(const T *__restrict__ ds, const T *__re
             for (int it = 0; it < 2; ++it) {                     // (q + v) rows i0 .. i0+63: 64 x 8 pieces of 8 dims
                 const int e = tid + 256 * it, il = e >> 3, c = (e & 7) * 8;
                 float v8[8];
-                load8_clamped<T>(qrow + (long long)min(i0 + il, Tn - 1) * Dh, c, Dh, (Dh % 8) == 0, v8);
+                if ((Dh % 8) == 0) load8_raw<T, true>(qrow + (long long)min(i0 + il, Tn - 1) * Dh, c, Dh, v8);     // (both pieces of the
+                else load8_raw<T, false>(qrow + (long long)min(i0 + il, Tn - 1) * Dh, c, Dh, v8);                  //  thread in flight together)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v8[q] = (c + q < Dh) ? v8[q] : 0.f;
                 if (i0 + il >= Tn) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v8[q] = 0.f;

@@ -33,6 +33,17 @@ __device__ __forceinline__ void load_glu_tile(const T *__restrict__ y2, const fl
     constexpr int ITEMS = R * (CV_CH / 8), NIT = (ITEMS + 255) / 256;
     float a[NIT][8], g[NIT][8];
     bool live[NIT];
+    // this thread's channel chunk is the same in every pass (256 % 8 == 0): its 8 + 8 bias values are fetched ONCE, with the tile
+    // (read as `b2 ? b2[c + j] : 0` inside the GLU loop they were 48 guarded loads = 48 serialized round trips per workgroup)
+    float ba[8], bg[8];
+    {
+        const int cb = min(c0 + (int)(threadIdx.x & 7) * 8, D - 8);
+        if (b2) { ld8(b2 + cb, ba); ld8(b2 + D + cb, bg); }
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ba[j] = bg[j] = 0.f;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
         const int i = threadIdx.x + u * 256, rr = i >> 3, c = c0 + (i & 7) * 8, t = row0 + rr;
@@ -44,12 +55,12 @@ __device__ __forceinline__ void load_glu_tile(const T *__restrict__ y2, const fl
     }
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
-        const int i = threadIdx.x + u * 256, rr = i >> 3, cl = (i & 7) * 8, c = c0 + cl;
+        const int i = threadIdx.x + u * 256, rr = i >> 3, cl = (i & 7) * 8;
         if (i >= ITEMS) break;
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            o[j] = live[u] ? (a[u][j] + (b2 ? b2[c + j] : 0.f)) * sigmoidf_fast(g[u][j] + (b2 ? b2[D + c + j] : 0.f)) : 0.f;
+            o[j] = live[u] ? (a[u][j] + ba[j]) * sigmoidf_fast(g[u][j] + bg[j]) : 0.f;
         *reinterpret_cast<float4 *>(g_lds + rr * CV_CH + cl) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4 *>(g_lds + rr * CV_CH + cl + 4) = make_float4(o[4], o[5], o[6], o[7]);
     }
@@ -75,13 +86,24 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T *__restrict
     float win[CV_FPT + K - 1];
 #pragma unroll
     for (int j = 0; j < CV_FPT + K - 1; ++j) win[j] = g_lds[(fg * CV_FPT + j) * CV_CH + ch];
+    float outv[CV_FPT];
 #pragma unroll
     for (int s = 0; s < CV_FPT; ++s) {
-        const int t = t0 + fg * CV_FPT + s;
         float acc = bias;
 #pragma unroll
         for (int k = 0; k < K; ++k) acc += w[k] * win[s + k];
-        if (t < Tn) st1(c_out + ((size_t)b * Tn + t) * D + d, acc);
+        outv[s] = acc;
+    }
+    // a whole tile inside the utterance (all but the last time tile) stores without guards: behind a per-frame guard every store was
+    // waited for before the next (one data register, s_waitcnt vmcnt(0) in front of each of the 16) - 16 serialized round trips
+    T *cp = c_out + ((size_t)b * Tn + t0 + fg * CV_FPT) * D + d;
+    if (t0 + CV_TT <= Tn) {
+#pragma unroll
+        for (int s = 0; s < CV_FPT; ++s) st1(cp + (size_t)s * D, outv[s]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < CV_FPT; ++s)
+            if (t0 + fg * CV_FPT + s < Tn) st1(cp + (size_t)s * D, outv[s]);
     }
 }
 
@@ -143,6 +165,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict
             gw[j] = g_lds[(fg * CV_FPT + j) * CV_CH + ch];
             dcw[j] = dc_lds[(fg * CV_FPT + j) * CV_CH + ch];
         }
+        float dav[CV_FPT], dbv[CV_FPT];
 #pragma unroll
         for (int s = 0; s < CV_FPT; ++s) {
             const int tl = fg * CV_FPT + s, t = t0 + tl;
@@ -155,15 +178,28 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const T *__restrict
                 dw[k] += dct * gw[s + k];
                 dg += w[k] * dcw[s + (K - 1) - k];
             }
-            if (t < Tn) {
-                const float a = a_in[s] + ba, sg = sigmoidf_fast(g_in[s] + bb);
-                const float da = dg * sg, db = dg * a * sg * (1.f - sg);
-                T *q = dy2 + ((size_t)b * Tn + t) * 2 * D;
-                st1(q + d, da);
-                st1(q + D + d, db);
-                dba += da;
-                dbb += db;
+            const float a = a_in[s] + ba, sg = sigmoidf_fast(g_in[s] + bb);
+            const float da = t < Tn ? dg * sg : 0.f, db = t < Tn ? dg * a * sg * (1.f - sg) : 0.f;
+            dav[s] = da;
+            dbv[s] = db;
+            dba += da;
+            dbb += db;
+        }
+        // stores without per-frame guards when the whole tile lies inside the utterance (see the forward kernel)
+        T *q = dy2 + ((size_t)b * Tn + t0 + fg * CV_FPT) * 2 * D + d;
+        if (t0 + CV_TT <= Tn) {
+#pragma unroll
+            for (int s = 0; s < CV_FPT; ++s) {
+                st1(q + (size_t)s * 2 * D, dav[s]);
+                st1(q + (size_t)s * 2 * D + D, dbv[s]);
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < CV_FPT; ++s)
+                if (t0 + fg * CV_FPT + s < Tn) {
+                    st1(q + (size_t)s * 2 * D, dav[s]);
+                    st1(q + (size_t)s * 2 * D + D, dbv[s]);
+                }
         }
     }
     __syncthreads();   // tiles are dead: reuse them for the cross-frame-group reduction [fg][NP][64]

@@ -246,18 +246,25 @@ struct BwdFrags {
 __device__ __forceinline__ void load_w_frags(BwdFrags &f, const float *__restrict__ W, int J, int V, int wslot,
                                              int nslots, int r, int h) {
     const int nkb = J / 32;
+    // every element is ALWAYS requested (vocabulary row / k-block clamped into the matrix) and masked afterwards: a guarded load sits in a
+    // basic block of its own and is waited for on the spot - the 48 of them were 48 serialized round trips at the head of every workgroup
+    float wv[KB][2][8];
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
-        const int kb = wslot + i * nslots;
+        const int kb = wslot + i * nslots, kbc = min(kb, nkb - 1);
         f.kb[i] = kb < nkb ? kb : -1;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int v = 16 * s + 8 * h + j;
-                f.wf[i][s][j] = (bf16_t)((kb < nkb && v < V) ? W[(size_t)v * J + kb * 32 + r] : 0.f);
-            }
+            for (int j = 0; j < 8; ++j) wv[i][s][j] = W[(size_t)min(16 * s + 8 * h + j, V - 1) * J + kbc * 32 + r];
     }
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                f.wf[i][s][j] = (bf16_t)((f.kb[i] >= 0 && 16 * s + 8 * h + j < V) ? wv[i][s][j] : 0.f);
 }
 
 // A operand: dlogits[u_r][16s+8h+j] (fp32 -> bf16); rows beyond U1 read as zero
