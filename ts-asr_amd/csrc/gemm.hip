@@ -263,6 +263,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
         __syncthreads();
         bf16_t *Cb = reinterpret_cast<bf16_t *>(Cv);
         const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
+        if (vec && m0 + BM <= M && n0 + BN <= N) {
+            // a tile inside the matrix (all but the last row / column panel) stores without guards: behind the per-chunk guards below
+            // every 16-byte store was waited for before the next one was issued (BM * BN / 2048 serialized round trips per thread)
+#pragma unroll
+            for (int it = 0; it < BM * (BN / 8) / 256; ++it) {
+                const int c = threadIdx.x + it * 256, rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+                *reinterpret_cast<uint4 *>(Cb + (long long)(m0 + rr) * ldc + n0 + cc) = *reinterpret_cast<const uint4 *>(tile + rr * LDT + cc);
+            }
+            return;
+        }
         for (int c = threadIdx.x; c < BM * (BN / 8); c += 256) {
             const int rr = c / (BN / 8), cc = (c % (BN / 8)) * 8;
             const int m = m0 + rr, n = n0 + cc;
@@ -284,6 +294,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / 64][BN / 64], c
         __syncthreads();
         float *Cf = reinterpret_cast<float *>(Cv) + (OUT_MODE == 1 ? (long long)tile_z * slab_stride : 0);
         const bool vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cf) & 15) == 0);
+        if (vec && m0 + BM <= M && n0 + BN <= N) {      // unguarded form (see the bf16 path); OUT_MODE 2 requests all its reads first
+            constexpr int NITF = BM * (BN / 4) / 256;
+            float4 old[OUT_MODE == 2 ? NITF : 1];
+            if (OUT_MODE == 2) {
+#pragma unroll
+                for (int it = 0; it < NITF; ++it) {
+                    const int c = threadIdx.x + it * 256, rr = c / (BN / 4), cc = (c % (BN / 4)) * 4;
+                    old[it] = *reinterpret_cast<const float4 *>(Cf + (long long)(m0 + rr) * ldc + n0 + cc);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NITF; ++it) {
+                const int c = threadIdx.x + it * 256, rr = c / (BN / 4), cc = (c % (BN / 4)) * 4;
+                float4 v = *reinterpret_cast<const float4 *>(tile + rr * LDT + cc);
+                if (OUT_MODE == 2) { v.x += old[it].x; v.y += old[it].y; v.z += old[it].z; v.w += old[it].w; }
+                *reinterpret_cast<float4 *>(Cf + (long long)(m0 + rr) * ldc + n0 + cc) = v;
+            }
+            return;
+        }
         for (int c = threadIdx.x; c < BM * (BN / 4); c += 256) {
             const int rr = c / (BN / 4), cc = (c % (BN / 4)) * 4;
             const int m = m0 + rr, n = n0 + cc;

@@ -14,6 +14,8 @@
 //   the accumulators go through LDS as fp32 half tiles and leave row-major, 8 columns per thread (see the epilogue).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define GBG_BN 256
@@ -128,8 +130,11 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
     const int cc = (threadIdx.x % CPR) * 8, rr0 = threadIdx.x / CPR, n = n0 + cc;   // GBG_THREADS % CPR == 0: one column group per thread
     float bias8[8], csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
+        if (a.bias) ld8(a.bias + n, bias8);     // one guarded block, two 16-byte loads (eight guarded scalar loads were eight round trips)
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = a.bias ? a.bias[n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        }
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -149,6 +154,11 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
                         tile[(32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * GBG_LDF + wn * 64 + 32 * j + r] = acc[i][j][g];
         }
         __syncthreads();
+        // FULL (every row of the half tile inside the matrix: all tiles but the last row panel) stores without per-row guards: behind
+        // an exec-masked guard each of the 8 stores of a pass was waited for before the next pass started (s_waitcnt vmcnt(0) at the
+        // head of every guarded block): 16 serialized store round trips per workgroup
+        auto pass = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rr = rr0 + it * (GBG_THREADS / CPR), m = m0 + half * HR + rr;
@@ -174,12 +184,15 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
                         if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
                         if (a.slope >= 0.f && y_neg && y_nz) t *= a.slope;
                         v[e] = t;
-                        if (m < a.M) csum[e] += t;
+                        if (FULL || m < a.M) csum[e] += t;
                     }
                 }
             }
-            if (m < a.M) st8(a.C + (long long)m * a.ldc + n, v);
+            if (FULL || m < a.M) st8(a.C + (long long)m * a.ldc + n, v);
         }
+        };
+        if (m0 + half * HR + HR <= a.M) pass(std::true_type{});
+        else pass(std::false_type{});
         __syncthreads();
     }
     if (MODE == 2 && a.colpart) {   // column sums of this tile: per-thread partials -> LDS -> one row of colpart (fixed order)
