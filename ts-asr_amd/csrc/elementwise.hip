@@ -698,36 +698,47 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T *__restr
     if (!HW && row >= M) return;
     const bool row_valid = row < M;                    // HW: no early exit, the other half-wave may own a row (loads clamped, stores guarded)
     if (HW && !row_valid) row = M - 1;
-    if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_thr16(p);
-    const DropKey dk = drop_key(seed);
-    const float ks = drop_scale16(thr);
-    const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+    // ONE round trip: every operand - the device seed, the utterance length, the parameters, the row - is requested up front,
+    // unconditionally (optional ones from a stand-in address, columns clamped) and masked afterwards. `if (seed_dev) seed += *seed_dev`,
+    // `valid_lens ? valid_lens[..] : ..` and `if (bias) load` are guarded loads: each was waited for where it stood, three dependent
+    // round trips in front of the row's own.
+    const bool has_bias = bias != nullptr, has_vl = valid_lens != nullptr;
+    const unsigned long long *seed_p = seed_dev ? seed_dev : reinterpret_cast<const unsigned long long *>(gamma);
+    const int32_t *vl_p = has_vl ? valid_lens : reinterpret_cast<const int32_t *>(gamma);
+    const float *bias_p = has_bias ? bias : gamma;
+    const int trows = has_vl ? max(Trows, 1) : 1;
+    const unsigned long long seed_add = *seed_p;
+    const int vl = vl_p[has_vl ? row / trows : 0];
     float v[ITERS][N];
     float gv[ITERS][N], bt[ITERS][N];      // requested with the row, used after the two reductions
+    float xv[ITERS][N], rv[ITERS][N], bv[ITERS][N];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = min((it * LPR + l) * N, D - N);
         ldv<float, N>(gamma + c, gv[it]);
         ldv<float, N>(beta + c, bt[it]);
+        ldv<T, N>(x + row * D + c, xv[it]);
+        ldv<T, N>(res + row * D + c, rv[it]);
+        ldv<float, N>(bias_p + c, bv[it]);
     }
+    if (seed_dev) seed += seed_add;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
+    const bool live = !has_vl || ((int)(row % trows) < vl);
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * LPR + l) * N;
         if (c < D) {
-            float xv[N], rv[N], bv[N];
-            ldv<T, N>(x + row * D + c, xv);
-            ldv<T, N>(res + row * D + c, rv);
-            if (bias) ldv<float, N>(bias + c, bv);   // 16-byte parameter loads, requested together with the row
             const unsigned long long idx = (unsigned long long)row * D + c;
             const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float t = xv[j] + (bias ? bv[j] : 0.f);
+                float t = xv[it][j] + (has_bias ? bv[it][j] : 0.f);
                 if (p > 0.f) t = ((km >> j) & 1u) ? t * ks : 0.f;
                 t = live ? t * alpha : 0.f;
-                t += rv[j];
+                t += rv[it][j];
                 if (sizeof(T) == 2) t = (float)(bf16_t)t;   // statistics of the STORED (rounded) row, as a separate LN would see
                 v[it][j] = t;
                 sum += t;
@@ -795,15 +806,23 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
     // a row slot (wave, or half-wave) walks rows r0 + slot, +RPP, ...: the next row (s, dy, dout, mean, rstd) is requested before this row's reductions
     float sn[ITERS][N], dn[ITERS][N], on[ITERS][N], mu_n = 0.f, rs_n = 0.f;
+    // optional operands are ALWAYS requested, from a stand-in address when absent (and ignored): `if (ptr) load` is a guarded load - it was
+    // waited for on the spot, and drained every other request of the row with it; the same for the utterance length read per row
+    const bool has_dout = dout != nullptr, has_vl = valid_lens != nullptr;
+    const T *dout_p = has_dout ? dout : dy;
+    const int32_t *vl_p = has_vl ? valid_lens : reinterpret_cast<const int32_t *>(mean);
+    const int trows = has_vl ? max(Trows, 1) : 1;
+    int vl_n = 0;
     auto request = [&](long long row) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             ldv<T, N>(s_in + row * D + cc[it], sn[it]);
             ldv<T, N>(dy + row * D + cc[it], dn[it]);
-            if (dout) ldv<T, N>(dout + row * D + cc[it], on[it]);
+            ldv<T, N>(dout_p + row * D + cc[it], on[it]);
         }
         mu_n = mean[row];
         rs_n = rstd[row];
+        vl_n = vl_p[row / trows];
     };
     // HW: both halves of a wave stay in the loop together (the reductions are wave-wide instructions); a half without a row
     // re-reads the last row and contributes nothing
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
         const bool row_valid = row_u < r1;
         const long long row = row_valid ? row_u : r1 - 1;
         const float mu = mu_n, rs = rs_n;
-        const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+        const bool live = !has_vl || ((int)(row % trows) < vl_n);
         float xh[ITERS][N], gd[ITERS][N], dov[ITERS][N];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -829,7 +848,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T *__restr
                 gd[it][j] = g;
                 s1 += g;
                 s2 += g * h;
-                dov[it][j] = dout ? on[it][j] : 0.f;
+                dov[it][j] = has_dout ? on[it][j] : 0.f;
             }
         }
         if (row_w + RPP < r1) request(min(row_u + RPP, r1 - 1));
@@ -1026,18 +1045,25 @@ __global__ __launch_bounds__(256) void add_layernorm2_bwd_kernel(const T *__rest
     }
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
     float sn[ITERS][N], zn[ITERS][N], dn[ITERS][N], on[ITERS][N], mu_n = 0.f, rs_n = 0.f, mu2_n = 0.f, rs2_n = 0.f;
+    // optional operands always requested, from a stand-in address when absent (see add_layernorm_bwd_kernel)
+    const bool has_dy = dy != nullptr, has_dout = dout != nullptr, has_vl = valid_lens != nullptr;
+    const T *dy_p = has_dy ? dy : dz, *dout_p = has_dout ? dout : dz;
+    const int32_t *vl_p = has_vl ? valid_lens : reinterpret_cast<const int32_t *>(mean);
+    const int trows = has_vl ? max(Trows, 1) : 1;
+    int vl_n = 0;
     auto request = [&](long long row) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             ldv<T, N>(s_in + row * D + cc[it], sn[it]);
             ldv<T, N>(dz + row * D + cc[it], zn[it]);
-            if (dy) ldv<T, N>(dy + row * D + cc[it], dn[it]);
-            if (dout) ldv<T, N>(dout + row * D + cc[it], on[it]);
+            ldv<T, N>(dy_p + row * D + cc[it], dn[it]);
+            ldv<T, N>(dout_p + row * D + cc[it], on[it]);
         }
         mu_n = mean[row];
         rs_n = rstd[row];
         mu2_n = mean2[row];
         rs2_n = rstd2[row];
+        vl_n = vl_p[row / trows];
     };
     if (HW ? r0 + (slot & ~1) < r1 : r0 + slot < r1) request(min(r0 + slot, r1 - 1));
     for (long long row_w = r0 + (HW ? (slot & ~1) : slot); row_w < r1; row_w += RPP) {
@@ -1045,7 +1071,7 @@ __global__ __launch_bounds__(256) void add_layernorm2_bwd_kernel(const T *__rest
         const bool row_valid = row_u < r1;
         const long long row = row_valid ? row_u : r1 - 1;
         const float mu = mu_n, rs = rs_n, mu2 = mu2_n, rs2 = rs2_n;
-        const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+        const bool live = !has_vl || ((int)(row % trows) < vl_n);
         float xh[ITERS][N], xh2[ITERS][N], gd[ITERS][N], dov[ITERS][N], dyr[ITERS][N];
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -1065,8 +1091,8 @@ __global__ __launch_bounds__(256) void add_layernorm2_bwd_kernel(const T *__rest
                 gd[it][j] = g2;
                 t1 += g2;
                 t2 += g2 * h2;
-                dov[it][j] = dout ? on[it][j] : 0.f;
-                dyr[it][j] = (dy && use) ? dn[it][j] : 0.f;
+                dov[it][j] = has_dout ? on[it][j] : 0.f;
+                dyr[it][j] = (has_dy && use) ? dn[it][j] : 0.f;
             }
         }
         if (row_w + RPP < r1) request(min(row_u + RPP, r1 - 1));
