@@ -1350,8 +1350,12 @@ static int attn_dpk_isplit(int B, int T, int H, int causal, int G) {
     return (int)std::min<long long>(cdiv(1024, (int)live), nib / 8);
 }
 static int attn_dpk_max_isplit(int T) { return std::max(1, std::min(cdiv(T, 64) / 8, 16)); }
-static int attn_bgroup(int B, int T) {   // utterances per d(pk) workgroup: ~1024 workgroups (four per CU cover each other's round trips)
-    static const int dpk_wgs = 1024;
+// utterances per d(pk) workgroup: ~256 workgroups per layer. The training step runs the passes of 12 (6) layers as ONE grouped launch, which
+// fills the chip anyway; fewer, longer workgroups write a quarter of the partial planes and leave the reduction a quarter to add
+// (configs[1], ms per step at 1024 / 512 / 256 / 128 workgroups per layer: 11.88 / 11.83 / 11.80 / 11.87). A stand-alone launch (one
+// layer, no gradient arena) under-fills the chip with it - the price of keeping both forms bit-identical.
+static int attn_bgroup(int B, int T) {
+    static const int dpk_wgs = 256;
     const int want = std::max(1, dpk_wgs / (4 * cdiv(2 * T - 1, 64)));
     return std::max(1, cdiv(B, std::min(B, want)));
 }
