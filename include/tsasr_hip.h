@@ -261,6 +261,12 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
  * (SB/nnet/attention.py:820-836) without a separate pass over the [M, d_ffn] hidden activation:
  *   epi_mode 1: C = dropout_p(LeakyReLU_slope(A.B + bias[n]));   epi_mode 2 (its backward on the dgrad GEMM):
  *   C = (A.B) * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]) and dbias[n] = column sums of C.  Masks: counter-based, (seed + *seed_dev, m*N+n). */
+/* fp32 GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): the Linear layers of the PARITY mode - the reference's default precision is
+ * fp32 (conformer-t_scratch.yaml:88; SB/nnet/linear.py:64-78, attention.py:549-553, 581-583, 820-836, Conformer.py:76-82, 98), the
+ * benchmarked step computes them in bf16. C[M,N] (+)= op(A) . op(B), operands and sums in fp32, layouts as tsasr_gemm_bf16; accumulate
+ * != 0: C += result. Any shape and stride. */
+int tsasr_gemm_f32(const float *A, const float *B, float *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int transA,
+                   int transB, int accumulate, void *stream);
 /* nbatch products with one shared left operand in ONE launch: C_i [M,N] = A [M,K] . B_i^T, B_i = btab[i] (a DEVICE array of device
  * pointers to bf16 [N,K] matrices, row stride ldb), C_i = C + i * c_batch elements. The 12 + 6 `linear_pos` projections of the one
  * positional table (SB/nnet/attention.py:433, 560: every RelPosMHAXL layer projects the same pos_embs). K % 64 == 0, N % 8 == 0. */

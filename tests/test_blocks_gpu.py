@@ -480,6 +480,51 @@ def test_linear_fn_grad_sink(ops):
         ops.set_grad_sink(None)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 29, 5), (64, 64, 16), (130, 257, 100), (500, 96, 2048)])
+def test_gemm_f32_layouts_vs_float64(ops, M, N, K):
+    """The parity mode's fp32 GEMM (csrc/gemm_f32.hip, fp32 matrix cores): the four operand layouts, padded leading dimensions,
+    accumulate; against the product in float64. Tolerance: fp32 sums of K terms (no operand rounding): 2e-6 * sqrt(K) relative."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    ref = (a.double() @ b.double().t())
+    tol = 2e-6 * max(K, 1) ** 0.5 * float(ref.abs().max() + 1.0)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            A = (a.t().contiguous() if ta else a)
+            Bm = (b.t().contiguous() if tb else b)
+            lda, ldb = A.shape[1] + 3, Bm.shape[1] + 5            # rows padded: strides differ from the row lengths
+            Ap = torch.zeros(A.shape[0], lda).copy_(torch.nn.functional.pad(A, (0, 3))).to(DEV)
+            Bp = torch.zeros(Bm.shape[0], ldb).copy_(torch.nn.functional.pad(Bm, (0, 5))).to(DEV)
+            out = ops.gemm_f32(Ap, Bp, M, N, K, lda, ldb, ta, tb)
+            assert float((out.double().cpu() - ref).abs().max()) <= tol, (ta, tb)
+            acc = torch.full((M, N + 2), 0.5, device=DEV)
+            ops.gemm_f32(Ap, Bp, M, N, K, lda, ldb, ta, tb, out=acc[:, :N], accumulate=True)
+            assert float((acc[:, :N].double().cpu() - 0.5 - ref).abs().max()) <= tol + 1e-6
+            assert float((acc[:, N:] - 0.5).abs().max()) == 0.0      # nothing written beyond N
+
+
+def test_fp32_linear_runs_on_the_hip_gemm_and_equals_the_library(ops, monkeypatch):
+    """ops.matmul_nt / ops.linear with fp32 operands (the parity mode): forward, data and weight gradient on tsasr_gemm_f32; same
+    numbers as the library GEMM within fp32 summation-order noise."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 50, 96, generator=g).to(DEV).requires_grad_()
+    w = torch.randn(40, 96, generator=g).to(DEV).requires_grad_()
+    b = torch.randn(40, generator=g).to(DEV).requires_grad_()
+    dy = torch.randn(3, 50, 40, generator=g).to(DEV)
+    outs = []
+    for hip in (True, False):
+        monkeypatch.setattr(ops, "_F32_HIP_GEMM", hip)
+        for t in (x, w, b):
+            t.grad = None
+        y = ops.linear(x, w, b)
+        assert ("_LinearF32Fn" in type(y.grad_fn).__name__ or "Add" in type(y.grad_fn).__name__) == hip or not hip
+        y.backward(dy)
+        outs.append([y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()])
+    for a_, b_ in zip(*outs):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max() + 1.0)
+
+
 @pytest.mark.parametrize("B,U,H", [(8, 21, 128), (8, 21, 256), (40, 9, 256), (32, 121, 512)])
 def test_lstm_hip_path_vs_oracle(ops, B, U, H):
     """bf16 predictor LSTM vs the oracle's explicit recurrence (oracle/tsasr_ref.lstm), fwd + bwd. H = 128 runs the per-step

@@ -19,7 +19,7 @@ STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
-    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "GLUE(hipBLASLt)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank": "HIP", "sentence_norm": "HIP",
+    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "HIP (gemm_f32: fp32 matrix cores; fwd, dgrad, wgrad)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank": "HIP", "sentence_norm": "HIP",
     "relpos_attention": "HIP (forward; backward = query-major, key-major, d(pk) and partial-sum kernels)",
 }
 
@@ -660,11 +660,62 @@ def ffn_core(x, w1, b1, w2, slope, p, training):
     return matmul_nt(linear(x, w1, b1, slope, p, training), w2)
 
 
+def gemm_f32(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, accumulate=False):
+    """C[M,N] (+)= op(A).op(B) in fp32 on the hand-written fp32-MFMA kernel (csrc/gemm_f32.hip); layouts as gemm_bf16."""
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    with prof.region("gemm_f32", 2.0 * M * N * K):
+        C.check(C.lib().tsasr_gemm_f32(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, out.stride(0), int(trans_a), int(trans_b),
+                                       int(bool(accumulate)), C.stream_ptr()), "tsasr_gemm_f32")
+    return out
+
+
+class _LinearF32Fn(torch.autograd.Function):
+    """y = x . W^T in fp32 (the parity mode): forward, data gradient and weight gradient on tsasr_gemm_f32 - no library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        N, K = weight.shape[0], weight.shape[1]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w2 = weight.detach().reshape(N, K)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        M = x2.shape[0]
+        y = gemm_f32(x2, w2, M, N, K, K, K, 0, 0)
+        ctx.save_for_backward(x2, w2)
+        ctx.wshape, ctx.xshape = weight.shape, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2 = ctx.saved_tensors
+        N, K = w2.shape
+        M = x2.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = gemm_f32(dy2, w2, M, K, N, N, K, 0, 1).view(ctx.xshape) if ctx.needs_input_grad[0] else None      # dy . W
+        dw = gemm_f32(dy2, x2, N, K, M, N, K, 1, 1).view(ctx.wshape) if ctx.needs_input_grad[1] else None      # dy^T . x
+        return dx, dw
+
+
+_F32_HIP_GEMM = True      # fp32 (parity-mode) Linear layers on the hand-written fp32 GEMM; False: the library GEMM (tests compare the two)
+
+
+def _gemm_f32_ok(x, weight):
+    return (_F32_HIP_GEMM and x.dtype == torch.float32 and x.is_cuda and weight.dtype == torch.float32 and weight.is_cuda
+            and (weight.dim() == 2 or (weight.dim() == 3 and weight.shape[2] == 1)) and x.shape[-1] == weight.shape[1] and x.numel() > 0)
+
+
 def matmul_nt(x, weight):
-    """x @ weight^T. bf16 activations: hand-written MFMA GEMM (csrc/gemm.hip); fp32 activations (parity runs): the exact fp32
-    library GEMM through PyTorch-ROCm."""
+    """x @ weight^T. bf16 activations: hand-written MFMA GEMM (csrc/gemm.hip); fp32 activations (parity runs): the hand-written fp32
+    GEMM (csrc/gemm_f32.hip: fp32 matrix cores, operands and sums in fp32)."""
     if _gemm_ok(x, weight):
         return _LinearFn.apply(x, weight)
+    if _gemm_f32_ok(x, weight):
+        return _LinearF32Fn.apply(x, weight)
     if weight.dim() == 3:
         weight = weight.squeeze(-1)
     return F.linear(x, _w(weight, x))
@@ -679,6 +730,8 @@ def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
         if bias is None:
             return matmul_nt(x, weight)
         if not _gemm_ok(x, weight):
+            if _gemm_f32_ok(x, weight):
+                return matmul_nt(x, weight) + bias
             return F.linear(x, _w(weight, x), _w(bias, x))
     if _gemm_ok(x, weight) and _LINEAR_EPILOGUE:
         p = float(dropout_p) if training else 0.0
@@ -1352,6 +1405,9 @@ class _FrontendConvFn(torch.autograd.Function):
             # bias in the GEMM epilogue (mode 1 with no activation, no dropout): no separate pass over the 41 MB outputs
             y1 = gemm_bf16_fused(A, wm, P, Co, 9 * Ci, 9 * Ci, 9 * Ci, 0, 0, 1, bias=_f32(b1).contiguous()).view(B, To, Fo, Co)
             y2 = gemm_bf16_fused(A[:, centre * Ci:], w2m, P, Co, Ci, 9 * Ci, Ci, 0, 0, 1, bias=_f32(b2).contiguous()).view(B, To, Fo, Co)
+        elif xc.dtype == torch.float32 and _F32_HIP_GEMM:   # parity mode: the same two products on the fp32 HIP GEMM
+            y1 = (gemm_f32(A, wm, P, Co, 9 * Ci, 9 * Ci, 9 * Ci, 0, 0) + b1.float()).view(B, To, Fo, Co)
+            y2 = (gemm_f32(A[:, centre * Ci:], w2m, P, Co, Ci, 9 * Ci, Ci, 0, 0) + b2.float()).view(B, To, Fo, Co)
         else:
             Ac = A.view(P, 9, Ci)[:, centre, :]
             y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
@@ -1372,6 +1428,11 @@ class _FrontendConvFn(torch.autograd.Function):
             dw2 = gemm_bf16(g2, A[:, centre * Ci:], Co, Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32).view(w2shape).to(dw2t)
             dA = gemm_bf16(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)                                         # g1 . wm
             dR = gemm_bf16(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
+        elif A.dtype == torch.float32 and _F32_HIP_GEMM:
+            dwm = gemm_f32(g1, A, Co, 9 * Ci, P, Co, 9 * Ci, 1, 1)
+            dw2 = gemm_f32(g2, A[:, centre * Ci:], Co, Ci, P, Co, 9 * Ci, 1, 1).view(w2shape).to(dw2t)
+            dA = gemm_f32(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)
+            dR = gemm_f32(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
         else:
             dwm = g1.t() @ A
             dw2 = (g2.t() @ A.view(P, 9, Ci)[:, centre, :]).view(w2shape).to(dw2t)
