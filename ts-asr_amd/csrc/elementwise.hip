@@ -920,12 +920,16 @@ __global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(const T *__rest
     if (!HW && row >= M) return;
     const bool row_valid = row < M;                    // HW: no early exit (the reductions are wave-wide instructions); stores guarded
     if (HW && !row_valid) row = M - 1;
-    if (seed_dev) seed += *seed_dev;
-    const unsigned thr = drop_thr16(p);
-    const DropKey dk = drop_key(seed);
-    const float ks = drop_scale16(thr);
-    const bool live = valid_lens ? ((int)(row % Trows) < valid_lens[row / Trows]) : true;
+    // one round trip for every operand (see add_layernorm_fwd_kernel): optional ones from a stand-in address, columns clamped
+    const bool has_bias = bias != nullptr, has_vl = valid_lens != nullptr;
+    const unsigned long long *seed_p = seed_dev ? seed_dev : reinterpret_cast<const unsigned long long *>(gamma);
+    const int32_t *vl_p = has_vl ? valid_lens : reinterpret_cast<const int32_t *>(gamma);
+    const float *bias_p = has_bias ? bias : gamma;
+    const int trows = has_vl ? max(Trows, 1) : 1;
+    const unsigned long long seed_add = *seed_p;
+    const int vl = vl_p[has_vl ? row / trows : 0];
     float v[ITERS][N], gv[ITERS][N], bt[ITERS][N], gv2[ITERS][N], bt2[ITERS][N];
+    float xv[ITERS][N], rv[ITERS][N], bv[ITERS][N];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = min((it * LPR + l) * N, D - N);
@@ -933,24 +937,28 @@ __global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(const T *__rest
         ldv<float, N>(beta + c, bt[it]);
         ldv<float, N>(gamma2 + c, gv2[it]);
         ldv<float, N>(beta2 + c, bt2[it]);
+        ldv<T, N>(x + row * D + c, xv[it]);
+        ldv<T, N>(res + row * D + c, rv[it]);
+        ldv<float, N>(bias_p + c, bv[it]);
     }
+    if (seed_dev) seed += seed_add;
+    const unsigned thr = drop_thr16(p);
+    const DropKey dk = drop_key(seed);
+    const float ks = drop_scale16(thr);
+    const bool live = !has_vl || ((int)(row % trows) < vl);
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = (it * LPR + l) * N;
         if (c < D) {
-            float xv[N], rv[N], bv[N];
-            ldv<T, N>(x + row * D + c, xv);
-            ldv<T, N>(res + row * D + c, rv);
-            if (bias) ldv<float, N>(bias + c, bv);
             const unsigned long long idx = (unsigned long long)row * D + c;
             const unsigned km = p > 0.f ? drop_keep_mask<N>((unsigned long long)idx, dk, thr) : ~0u;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float t = xv[j] + (bias ? bv[j] : 0.f);
+                float t = xv[it][j] + (has_bias ? bv[it][j] : 0.f);
                 if (p > 0.f) t = ((km >> j) & 1u) ? t * ks : 0.f;
                 t = live ? t * alpha : 0.f;
-                t += rv[j];
+                t += rv[it][j];
                 if (sizeof(T) == 2) t = (float)(bf16_t)t;
                 v[it][j] = t;
                 sum += t;

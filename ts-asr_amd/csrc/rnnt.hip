@@ -669,9 +669,49 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
     const int sub = threadIdx.x & 7;
     if (row >= (long long)B * Tn * U1) return;  // whole 8-lane groups leave together
     const int u = row % U1, t = (row / U1) % Tn, b = row / ((long long)U1 * Tn);
+    const float *rowp = logits + row * ldl;
+    if (V <= 32) {
+        // the benchmark's case (V = 29): ONE round trip - lengths, the cell's row (one float4 per lane) and its label are requested
+        // together, blank / label log-probabilities are picked out of the lanes' registers (a select + the same three DPP steps as the
+        // sums) instead of being re-read from the row after the label has arrived (lengths -> row -> label -> row[label]: four
+        // dependent round trips before)
+        const int tl = tlen[b], ul = ulen[b];
+        const int c = sub * 4;
+        const float4 x = *reinterpret_cast<const float4 *>(rowp + min(c, ldl - 4));
+        const int lab = targets[(size_t)b * ldt + min(u, max(ldt - 1, 0))];
+        const int Tb = min(max(tl, 1), Tn), Ub = min(max(ul, 0), U1 - 1);
+        if (t >= Tb || u > Ub) return;
+        const float xs[4] = {c + 0 < V ? x.x : NEG_INF, c + 1 < V ? x.y : NEG_INF, c + 2 < V ? x.z : NEG_INF, c + 3 < V ? x.w : NEG_INF};
+        float m = fmaxf(fmaxf(xs[0], xs[1]), fmaxf(xs[2], xs[3]));
+        m = fmaxf(m, dpp_mov<0xB1>(m));
+        m = fmaxf(m, dpp_mov<0x4E>(m));
+        m = fmaxf(m, dpp_mov<0x141>(m));
+        const int kl = min(max(lab, 0), V - 1);
+        float s = 0.f, vb = 0.f, vl = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j < V) s += __expf(xs[j] - m);
+            vb += (c + j == blank) ? xs[j] : 0.f;
+            vl += (c + j == kl) ? xs[j] : 0.f;
+        }
+        s += dpp_mov<0xB1>(s);   vb += dpp_mov<0xB1>(vb);   vl += dpp_mov<0xB1>(vl);
+        s += dpp_mov<0x4E>(s);   vb += dpp_mov<0x4E>(vb);   vl += dpp_mov<0x4E>(vl);
+        s += dpp_mov<0x141>(s);  vb += dpp_mov<0x141>(vb);  vl += dpp_mov<0x141>(vl);
+        if (sub == 0) {
+            const float lse = m + __logf(s);
+            const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+            w.lse[o] = lse;
+            w.lpb[o] = vb - lse;
+            if (u < Ub) {
+                const float e = vl - lse;
+                w.lpe_out[o] = e;
+                w.lpe_in[o + 1] = e;
+            }
+        }
+        return;
+    }
     const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
     if (t >= Tb || u > Ub) return;
-    const float *rowp = logits + row * ldl;
     float m = NEG_INF;
     for (int c = sub * 4; c < V; c += 32) {
         const float4 x = *reinterpret_cast<const float4 *>(rowp + c);
