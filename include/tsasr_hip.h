@@ -273,9 +273,14 @@ int tsasr_gemm_f32(const float *A, const float *B, float *C, int M, int N, int K
 int tsasr_gemm_bf16_nt_batched(const void *A, const void *const *btab, void *C, int M, int N, int K, long long lda, long long ldb,
                                long long ldc, long long c_batch, int nbatch, void *stream);
 size_t tsasr_gemm_bf16_fused_workspace_bytes(int M, int N);
+/* `mask` (may be NULL; only where tsasr_gemm_bf16_fused_mask_ok(M, N, K) and transA = transB = 0): uint16 [M][N/8], one word per 8
+ * consecutive outputs - bits 0-7 the dropout keep-bits, bits 8-15 "the stored activation is negative". The mode-1 call writes it; the
+ * mode-2 call given the same words reads them INSTEAD of y and of re-hashing the keep-bits (y must still be passed): M*N/4 bytes read
+ * instead of 2*M*N. Same results bit for bit. */
+int tsasr_gemm_bf16_fused_mask_ok(int M, int N, int K);
 int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                           int transA, int transB, int epi_mode, const float *bias, const void *y, long long ldy, float slope, float p,
-                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *workspace,
+                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *mask, void *workspace,
                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------

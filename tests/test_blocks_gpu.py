@@ -685,6 +685,35 @@ def test_fused_ffn_core(ops, p, M):
         assert float((outs[0][0] - ref).norm() / ref.norm()) < 6e-3
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("M", [3999, 7995])
+def test_ffn_mask_words_give_the_same_bits(ops, monkeypatch, p, M):
+    """The FFN's data gradient reading the forward epilogue's mask words (keep-bits + sign of the stored activation, uint16 per 8
+    outputs) instead of the saved activation and a re-hash of the keep-bits: every output and gradient bit-identical to the form without
+    them. The words need the arena's transposed weight shadow (the k-contiguous backward GEMM): provided by hand here."""
+    D, F1 = 256, 2048
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    w1, b1 = torch.randn(F1, D, generator=g) / D ** 0.5, torch.randn(F1, generator=g) * 0.1
+    w2 = torch.randn(D, F1, generator=g) / F1 ** 0.5
+    do = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    outs = []
+    for masks in (True, False):
+        monkeypatch.setattr(ops, "_FFN_MASK", masks)
+        xs = x.to(DEV).requires_grad_()
+        ps = [t.to(DEV).requires_grad_() for t in (w1, b1, w2)]
+        ps[2]._bf16 = ps[2].detach().to(torch.bfloat16)
+        ps[2]._bf16_t = ps[2]._bf16.t().contiguous()
+        ps[2]._bf16_ver = ps[2]._version
+        assert ops.fused_mask_ok(M, F1, D) and ops._bf16_weight_t(ps[2]) is not None
+        ops._seed_counter[0] = 100
+        o = ops.ffn_core(xs, ps[0], ps[1], ps[2], 0.01, p, True)
+        o.backward(do.to(DEV))
+        outs.append([o.detach(), xs.grad] + [t.grad for t in ps])
+    for a, b_, name in zip(outs[0], outs[1], ("out", "dx", "dw1", "db1", "dw2")):
+        assert torch.equal(a, b_), name
+
+
 # ---------------------------------------------------------------------------------------------- augmenters (compute_forward, TRAIN)
 def _sa_table(g, key, B, nf, nt, dev=DEV):
     """Device draw table (layout of include/tsasr_hip.h) from the reference draws stored in the fixture."""

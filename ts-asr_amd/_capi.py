@@ -85,7 +85,8 @@ _PROTOS = {
     "tsasr_gemm_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p]),
     "tsasr_gemm_bf16_nt_batched": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 4 + [c_int, c_void_p]),
     "tsasr_gemm_bf16_fused_workspace_bytes": (c_size_t, [c_int] * 2),
-    "tsasr_gemm_bf16_fused": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_float, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_gemm_bf16_fused": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p, c_void_p, c_ll, c_float, c_float, c_ull, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tsasr_gemm_bf16_fused_mask_ok": (c_int, [c_int] * 3),
     "tsasr_gemm_bf16": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_lstm_step_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "tsasr_lstm_step_bwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

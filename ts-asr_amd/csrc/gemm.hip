@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__re
 int tsasr_gemm_big_bm(int M, int N, int K);
 int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int mode,
                           const float *bias, const void *y, long long ldy, float slope, float p, unsigned long long seed,
-                          const unsigned long long *seed_dev, float *colpart, hipStream_t st);
+                          const unsigned long long *seed_dev, float *colpart, void *mask, hipStream_t st);
 
 static int g_use_ring = 1;   // 0: never, 1: long K or small tiles, 2: always
 
@@ -963,7 +963,7 @@ int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, 
             gemm_slab_reduce_kernel<<<(unsigned)cdiv((int)((ss + 3) / 4), 256), 256, 0, st>>>((const float *)workspace, (float *)C, M, N, ldc, p.splits, ss, accumulate != 0);
     } else if (out_dtype == TSASR_BF16) {
         if (!transA && !transB && g_force_tile < 0 && ldc % 8 == 0 &&
-            tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, 0, nullptr, nullptr, 0, -1.f, 0.f, 0, nullptr, nullptr, st) == 0) {
+            tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, 0, nullptr, nullptr, 0, -1.f, 0.f, 0, nullptr, nullptr, nullptr, st) == 0) {
             TSASR_CHECK_LAUNCH("tsasr_gemm_bf16");
             return 0;
         }
@@ -999,14 +999,18 @@ size_t tsasr_gemm_bf16_fused_workspace_bytes(int M, int N) { return align_up((si
  *   epi_mode 1: C = dropout_p(LeakyReLU_slope(op(A).op(B) + bias[n]))           (slope < 0: no activation; bias may be NULL)
  *   epi_mode 2: C = (op(A).op(B)) * keep(m,n)/(1-p) * LeakyReLU'(y[m,n]); dbias[n] = column sums of C (dbias may be NULL)
  * y [M,N] bf16 (row stride ldy) is the saved output of the mode-1 call with the same (p, seed): the mask is regenerated. */
+/* 1 when the mode-1 AND mode-2 calls of this shape (transA = transB = 0) keep the epilogue mask words (see `mask` below) */
+int tsasr_gemm_bf16_fused_mask_ok(int M, int N, int K) { return (g_force_tile < 0 && tsasr_gemm_big_bm(M, N, K)) ? 1 : 0; }
+
 int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
                           int transA, int transB, int epi_mode, const float *bias, const void *y, long long ldy, float slope, float p,
-                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *workspace,
+                          unsigned long long seed, const unsigned long long *seed_dev, float *dbias, void *mask, void *workspace,
                           size_t workspace_bytes, void *stream) {
     TSASR_CHECK_ARG(A && B && C, "tsasr_gemm_bf16_fused: null pointer");
     TSASR_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && ldc % 8 == 0, "tsasr_gemm_bf16_fused: N and ldc must be multiples of 8");
     TSASR_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && (transA ? M : K) % 8 == 0 && (transB ? N : K) % 8 == 0, "tsasr_gemm_bf16_fused: rows must be multiples of 8 bf16");
     TSASR_CHECK_ARG(epi_mode == 1 || (epi_mode == 2 && y && ldy % 8 == 0), "tsasr_gemm_bf16_fused: bad epilogue mode %d", epi_mode);
+    TSASR_CHECK_ARG(!mask || (!transA && !transB && tsasr_gemm_bf16_fused_mask_ok(M, N, K)), "tsasr_gemm_bf16_fused: no mask words for this shape (ask tsasr_gemm_bf16_fused_mask_ok)");
     TSASR_CHECK_ARG(p >= 0.f && p < 1.f, "tsasr_gemm_bf16_fused: bad dropout %f", p);
     TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
     GemmPlan pl = plan(M, N, K, 0);
@@ -1017,7 +1021,7 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     if (!transA && !transB && g_force_tile < 0) {
         const int bm = tsasr_gemm_big_bm(M, N, K);
         float *colpart = (epi_mode == 2 && dbias) ? (float *)workspace : nullptr;
-        if (bm && tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, epi_mode, bias, y, ldy, slope, p, seed, seed_dev, colpart, st) == 0) {
+        if (bm && tsasr_gemm_big_launch(A, B, C, M, N, K, lda, ldb, ldc, epi_mode, bias, y, ldy, slope, p, seed, seed_dev, colpart, mask, st) == 0) {
             if (colpart) tsasr_reduce_submit(colpart, dbias, N, cdiv(M, bm), N, 0, st);
             TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_fused");
             return 0;

@@ -37,6 +37,10 @@ struct BigArgs {
     unsigned long long seed;
     const unsigned long long *seed_dev;
     float *colpart;   // [tiles_m][N]
+    // one 16-bit word per 8 consecutive outputs, [M][N/8]: bits 0-7 = dropout keep-bits, bits 8-15 = "stored activation is negative".
+    // Mode 1 writes it (when given); mode 2 reads it INSTEAD of the saved activation y and of re-hashing the keep-bits: 4 MB instead of
+    // 32.8 MB read per FFN backward launch at configs[1], no hash (tools/gemm_bench.py: the mode-2 epilogue was 13 us of a 33 us launch)
+    unsigned short *mask;
 };
 
 __device__ __forceinline__ void gbg_dma16(const bf16_t *gsrc, unsigned lds_dst) {
@@ -45,7 +49,7 @@ __device__ __forceinline__ void gbg_dma16(const bf16_t *gsrc, unsigned lds_dst) 
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int BM, int MODE>
+template <int BM, int MODE, bool MASK = false>   // MASK: the epilogue's mask words are written (mode 1) / read instead of y and the hash (mode 2)
 __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
     constexpr int A_BYTES = BM * GBG_ROW, B_BYTES = GBG_BN * GBG_ROW, SLOT = A_BYTES + B_BYTES;
     constexpr int A_PCS = A_BYTES / 1024 / 8, B_PCS = B_BYTES / 1024 / 8;   // 1 KiB DMA pieces per wave per k-tile
@@ -138,11 +142,19 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        uint4 yraw[NIT];
+        constexpr bool use_mask = MODE == 2 && MASK;
+        uint4 yraw[use_mask ? 1 : NIT];
+        unsigned short mraw[use_mask ? NIT : 1];
         if (MODE == 2) {   // requested before the accumulators go through LDS
+            if constexpr (use_mask) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-                yraw[it] = *reinterpret_cast<const uint4 *>(a.y + (long long)min(m0 + half * HR + rr0 + it * (GBG_THREADS / CPR), a.M - 1) * a.ldy + n);
+                for (int it = 0; it < NIT; ++it)
+                    mraw[it] = a.mask[((long long)min(m0 + half * HR + rr0 + it * (GBG_THREADS / CPR), a.M - 1) * a.N + n) >> 3];
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    yraw[it] = *reinterpret_cast<const uint4 *>(a.y + (long long)min(m0 + half * HR + rr0 + it * (GBG_THREADS / CPR), a.M - 1) * a.ldy + n);
+            }
         }
         if (wm == half) {
 #pragma unroll
@@ -165,14 +177,33 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
             const float4 v_lo = *reinterpret_cast<const float4 *>(tile + rr * GBG_LDF + cc), v_hi = *reinterpret_cast<const float4 *>(tile + rr * GBG_LDF + cc + 4);
             float v[8] = {v_lo.x, v_lo.y, v_lo.z, v_lo.w, v_hi.x, v_hi.y, v_hi.z, v_hi.w};
             if (MODE != 0) {
-                const unsigned km = a.p > 0.f ? drop_keep_mask<8>((unsigned long long)m * a.N + n, dk, thr) : ~0u;
+                unsigned km;
+                if constexpr (use_mask) km = (unsigned)mraw[it];
+                else km = a.p > 0.f ? drop_keep_mask<8>((unsigned long long)m * a.N + n, dk, thr) : ~0u;
                 if (MODE == 1) {
+                    unsigned neg = 0;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = v[e] + bias8[e];
                         if (a.slope >= 0.f) t = lrelu(t, a.slope);
                         if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
                         v[e] = t;
+                        if constexpr (MASK) {
+                            const unsigned short yb = __builtin_bit_cast(unsigned short, (bf16_t)t);     // the value as it is stored
+                            neg |= (((yb >> 15) & 1u) & (unsigned)((yb & 0x7fffu) != 0)) << e;
+                        }
+                    }
+                    if constexpr (MASK) {
+                        if (FULL || m < a.M) a.mask[((long long)m * a.N + n) >> 3] = (unsigned short)((km & 0xffu) | (neg << 8));
+                    }
+                } else if constexpr (use_mask) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = v[e];
+                        if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
+                        if (a.slope >= 0.f && ((km >> (8 + e)) & 1u)) t *= a.slope;
+                        v[e] = t;
+                        if (FULL || m < a.M) csum[e] += t;
                     }
                 } else {
                     const unsigned yw[4] = {yraw[it].x, yraw[it].y, yraw[it].z, yraw[it].w};
@@ -226,15 +257,19 @@ size_t tsasr_gemm_big_colpart_rows(int M, int N, int K) {
 
 int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int mode,
                           const float *bias, const void *y, long long ldy, float slope, float p, unsigned long long seed,
-                          const unsigned long long *seed_dev, float *colpart, hipStream_t st) {
+                          const unsigned long long *seed_dev, float *colpart, void *mask, hipStream_t st) {
     const int bm = tsasr_gemm_big_bm(M, N, K);
     if (!bm) return 1;
-    BigArgs a{(const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, mode, bias, (const bf16_t *)y, ldy, slope, p, seed, seed_dev, colpart};
+    BigArgs a{(const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, mode, bias, (const bf16_t *)y, ldy, slope, p, seed, seed_dev, colpart,
+              (unsigned short *)mask};
     const int grid = cdiv(M, bm) * (N / GBG_BN);
     constexpr int LDS256 = 128 * GBG_LDF * 4 > 2 * (256 + GBG_BN) * GBG_ROW ? 128 * GBG_LDF * 4 : 2 * (256 + GBG_BN) * GBG_ROW;   // fp32 half tile 130 KiB
     constexpr int LDS128 = 2 * (128 + GBG_BN) * GBG_ROW;   // 96 KiB >= the 64 x 260 fp32 half tile
     void (*kern)(BigArgs) = nullptr;
-    if (bm == 256) kern = mode == 0 ? gemm_big_kernel<256, 0> : mode == 1 ? gemm_big_kernel<256, 1> : gemm_big_kernel<256, 2>;
+    if (mask && mode != 0) {
+        if (bm == 256) kern = mode == 1 ? gemm_big_kernel<256, 1, true> : gemm_big_kernel<256, 2, true>;
+        else kern = mode == 1 ? gemm_big_kernel<128, 1, true> : gemm_big_kernel<128, 2, true>;
+    } else if (bm == 256) kern = mode == 0 ? gemm_big_kernel<256, 0> : mode == 1 ? gemm_big_kernel<256, 1> : gemm_big_kernel<256, 2>;
     else kern = mode == 0 ? gemm_big_kernel<128, 0> : mode == 1 ? gemm_big_kernel<128, 1> : gemm_big_kernel<128, 2>;
     const int lds = bm == 256 ? LDS256 : LDS128;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

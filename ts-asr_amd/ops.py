@@ -587,15 +587,23 @@ def _wgrad_into(sink, weight, grad2d, dy2, x2):
     sink.mark_ready(weight)
 
 
-def gemm_bf16_fused(a, b, M, N, K, lda, ldb, trans_a, trans_b, mode, bias=None, y=None, slope=-1.0, p=0.0, seed=0, dbias=None):
+def gemm_bf16_fused(a, b, M, N, K, lda, ldb, trans_a, trans_b, mode, bias=None, y=None, slope=-1.0, p=0.0, seed=0, dbias=None, mask=None):
+    """``mask`` (uint16 [M, N/8], only where fused_mask_ok): written by the mode-1 call, read by the mode-2 call instead of y / the hash."""
     out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     ws = _ws(C.lib().tsasr_gemm_bf16_fused_workspace_bytes(M, N), a.device) if dbias is not None else None
     with prof.region(f"gemm_bf16_fused<{mode}>", 2.0 * M * N * K):
         C.check(C.lib().tsasr_gemm_bf16_fused(C.ptr(a), C.ptr(b), C.ptr(out), M, N, K, lda, ldb, N, int(trans_a), int(trans_b), int(mode),
                                               C.ptr(bias), C.ptr(y), 0 if y is None else y.stride(0), float(slope), float(p), seed,
-                                              C.ptr(seed_state(a.device)), C.ptr(dbias), C.ptr(ws), 0 if ws is None else ws.numel(),
+                                              C.ptr(seed_state(a.device)), C.ptr(dbias), C.ptr(mask), C.ptr(ws), 0 if ws is None else ws.numel(),
                                               C.stream_ptr()), "tsasr_gemm_bf16_fused")
     return out
+
+
+def fused_mask_ok(M, N, K):
+    return bool(C.lib().tsasr_gemm_bf16_fused_mask_ok(int(M), int(N), int(K)))
+
+
+_FFN_MASK = True      # (tests switch it off: the data gradient then re-reads the activation and re-hashes the keep-bits - same bits)
 
 
 class _FFNFn(torch.autograd.Function):
@@ -614,15 +622,21 @@ class _FFNFn(torch.autograd.Function):
         M = x2.shape[0]
         w1h, w2h = _bf16_weight(w1).contiguous(), _bf16_weight(w2).contiguous()
         b1f = None if b1 is None else _f32(b1).contiguous()
-        h = gemm_bf16_fused(x2, w1h, M, F1, D, D, D, 0, 0, 1, bias=b1f, slope=slope, p=p, seed=seed)
+        # the epilogue's mask words (keep-bits + sign of the stored activation, 2 bits per element) are kept for the backward when both of
+        # its GEMMs take them: the data gradient then reads M*F1/4 bytes instead of the whole activation (2*M*F1) and hashes nothing
+        mask = None
+        if _FFN_MASK and (slope >= 0 or p > 0) and F1 % 8 == 0 and fused_mask_ok(M, F1, D) and fused_mask_ok(M, F1, w2.shape[0]) \
+                and _bf16_weight_t(w2) is not None:
+            mask = torch.empty(M, F1 // 8, dtype=torch.int16, device=x2.device)
+        h = gemm_bf16_fused(x2, w1h, M, F1, D, D, D, 0, 0, 1, bias=b1f, slope=slope, p=p, seed=seed, mask=mask)
         o = gemm_bf16(h, w2h, M, w2.shape[0], F1, F1, F1, 0, 0)
-        ctx.save_for_backward(x2, h, w1h, w2h)
+        ctx.save_for_backward(x2, h, w1h, w2h, mask)
         ctx.cfg = (float(slope), float(p), seed, (w1, b1, w2), x.shape)
         return o.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
     def backward(ctx, do):
-        x2, h, w1h, w2h = ctx.saved_tensors
+        x2, h, w1h, w2h, mask = ctx.saved_tensors
         slope, p, seed, (w1, b1, w2), xshape = ctx.cfg
         F1, D = w1.shape
         Dout = w2.shape[0]
@@ -635,7 +649,7 @@ class _FFNFn(torch.autograd.Function):
         # dh_pre = (do . W2) * dropout/activation backward, + column sums -> db1
         w2t = _bf16_weight_t(w2)
         if w2t is not None:   # W2^T [F1, Dout]: k-contiguous operand
-            dh = gemm_bf16_fused(do2, w2t, M, F1, Dout, Dout, Dout, 0, 0, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
+            dh = gemm_bf16_fused(do2, w2t, M, F1, Dout, Dout, Dout, 0, 0, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1, mask=mask)
         else:
             dh = gemm_bf16_fused(do2, w2h, M, F1, Dout, Dout, F1, 0, 1, 2, y=h, slope=slope, p=p, seed=seed, dbias=db1)
         dx = _dgrad(dh, w1, w1h, M, F1, D).view(xshape) if ctx.needs_input_grad[0] else None
