@@ -121,6 +121,10 @@ def direct_capture_probe(device, world, rank, group=None):
     return bool(agree(ok))      # second agreement: the replayed value was right everywhere
 
 
+def _pad8(n):
+    return (int(n) + 7) // 8 * 8
+
+
 class GradArena:
     def __init__(self, modules, world_size=1, bucket_bytes=None, group=None):
         if bucket_bytes is None:    # 32 MiB buckets (6-7 per step at 51 M parameters); TSASR_BUCKET_MB for tests with small models
@@ -143,9 +147,12 @@ class GradArena:
         self.direct = bool(world_size > 1 and direct_rccl_init(world_size, dist.get_rank() if is_initialized() else 0, params[0].device))
         self.comm_stream = None
         self.device = params[0].device
-        self.numel = sum(p.numel() for p in params)
+        # every parameter starts at a multiple of 8 elements: its bf16 shadow (and transposed copy) is then 16-byte aligned - what the
+        # GEMMs' 16-byte operand pieces and the vectorised transpose want (a 29-element bias early in the arena used to shift every
+        # weight behind it off that alignment). The pad words stay zero (parameters and gradients alike).
+        self.numel = sum(_pad8(p.numel()) for p in params)
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
-        self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=self.device)
+        self.flat_params = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         # bf16 shadow of every parameter (MFMA GEMM operand copy); the fused optimizer rewrites it in the same pass
         self.flat_params16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device) if self.device.type == "cuda" else None
         self.in_backward = False
@@ -180,7 +187,7 @@ class GradArena:
         new_off, off = {}, 0
         for p in params:
             new_off[id(p)] = off
-            off += p.numel()
+            off += _pad8(p.numel())
         if first:
             for p in params:
                 o, n = new_off[id(p)], p.numel()
@@ -188,6 +195,7 @@ class GradArena:
         else:
             for buf in [self.flat_params] + self.companions:
                 old = buf.clone()
+                buf.zero_()              # (the pad words between parameters stay zero)
                 for p in params:
                     o, n, oo = new_off[id(p)], p.numel(), self.offset[id(p)]
                     buf[o:o + n].copy_(old[oo:oo + n])
