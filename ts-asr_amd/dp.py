@@ -121,8 +121,11 @@ def direct_capture_probe(device, world, rank, group=None):
     return bool(agree(ok))      # second agreement: the replayed value was right everywhere
 
 
+_PAD = 64     # elements: 128-byte lines of the bf16 shadow, 256 bytes of the fp32 arena (ms per step at 8 / 64 / 128: 11.47 / 11.39 / 11.40)
+
+
 def _pad8(n):
-    return (int(n) + 7) // 8 * 8
+    return (int(n) + _PAD - 1) // _PAD * _PAD
 
 
 class GradArena:
@@ -147,7 +150,7 @@ class GradArena:
         self.direct = bool(world_size > 1 and direct_rccl_init(world_size, dist.get_rank() if is_initialized() else 0, params[0].device))
         self.comm_stream = None
         self.device = params[0].device
-        # every parameter starts at a multiple of 8 elements: its bf16 shadow (and transposed copy) is then 16-byte aligned - what the
+        # every parameter starts at a multiple of _PAD (64) elements: its bf16 shadow (and transposed copy) is then line-aligned - what the
         # GEMMs' 16-byte operand pieces and the vectorised transpose want (a 29-element bias early in the arena used to shift every
         # weight behind it off that alignment). The pad words stay zero (parameters and gradients alike).
         self.numel = sum(_pad8(p.numel()) for p in params)
