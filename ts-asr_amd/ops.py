@@ -207,15 +207,18 @@ _WG_EARLY_WGS = -1
 _WG_EARLY_SLOTS = 0      # (2: the launch made beside another stream's kernels uses 64 KB of LDS - measured equal)
 
 
-def wgrad_queue(weight, grad2d, dy2, x2):
-    """Queue grad2d [N, K] (fp32 view of weight.grad) += dy2[M, N]^T . x2[M, K]; False when the shapes do not fit the grouped kernel."""
+def wgrad_queue(weight, grad2d, dy2, x2, key=None):
+    """Queue grad2d [N, K] (fp32 view of weight.grad) += dy2[M, N]^T . x2[M, K]; False when the shapes do not fit the grouped kernel.
+    ``key``: what identifies the OUTPUT tiles (default: the weight) - two gradients into disjoint column ranges of one weight (the `cat`
+    injection's projection) pass distinct keys and share a launch; two into the same tiles are ordered by a flush."""
+    key = id(weight) if key is None else key
     N, K = grad2d.shape
     M = dy2.shape[0]
     if not _WG_ENABLED or _WG["ring"] is None or N % 8 or K % 8 or N < 8 or K < 8 or dy2.stride(1) != 1 or x2.stride(1) != 1 \
             or dy2.stride(0) % 8 or x2.stride(0) % 8 or dy2.data_ptr() % 16 or x2.data_ptr() % 16 or grad2d.stride(1) != 1 \
             or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or grad2d.dtype != torch.float32:
         return False
-    if id(weight) in _WG["ids"] or C.lib().tsasr_wgrad_pending() >= _WG_MAX_JOBS:   # a second gradient into the same tiles: order them
+    if key in _WG["ids"] or C.lib().tsasr_wgrad_pending() >= _WG_MAX_JOBS:   # a second gradient into the same tiles: order them
         # through the arena: the queue is shared by every stream of the step, so the launch has to be ordered after all of them and the
         # operands have to outlive the streams' join (GradArena.flush_wgrads, hold) - a bare launch on the current stream is neither
         sink = _GRAD_SINK
@@ -225,7 +228,7 @@ def wgrad_queue(weight, grad2d, dy2, x2):
             wgrad_flush()
     C.check(C.lib().tsasr_wgrad_queue(C.ptr(dy2), C.ptr(x2), C.ptr(grad2d), N, K, M, dy2.stride(0), x2.stride(0), grad2d.stride(0)),
             "tsasr_wgrad_queue")
-    _WG["ids"].add(id(weight))
+    _WG["ids"].add(key)
     _WG["keep"] += [dy2, x2]
     _WG["params"].append(weight)
     _WG["tiles"] = _WG.get("tiles", 0) + ((N + 255) // 256) * ((K + 255) // 256)
@@ -438,6 +441,62 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw
 
 
+class _LinearColsFn(torch.autograd.Function):
+    """y = x . W[:, c0:c0+n]^T (+ bias): a Linear over a COLUMN RANGE of a weight - the two halves of the `cat` injection's projection
+    (models/conformer.py:254-262: Linear(2D -> D) applied to [src | spk]; here src and spk are multiplied separately). Works on the
+    Parameter itself: the operand is a strided view of its bf16 shadow (no cast of a slice), the weight gradient goes into the same
+    columns of its slot in the gradient arena, queued with the other weight gradients (no slice-backward, no separate GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, c0, n):
+        N, Kf = weight.shape
+        x2 = x.reshape(-1, n)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w16 = _bf16_weight(weight)[:, c0:c0 + n]
+        M = x2.shape[0]
+        if bias is not None:
+            y = gemm_bf16_fused(x2, w16, M, N, n, n, w16.stride(0), 0, 0, 1, bias=_f32(bias).contiguous())
+        else:
+            y = gemm_bf16(x2, w16, M, N, n, n, w16.stride(0), 0, 0)
+        ctx.save_for_backward(x2, w16)
+        ctx.weight, ctx.bias, ctx.cols, ctx.xshape = weight, bias, (int(c0), int(n)), x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16 = ctx.saved_tensors
+        weight, bias, (c0, n) = ctx.weight, ctx.bias, ctx.cols
+        N, Kf = weight.shape
+        M = x2.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        db = _pgrad(bias, colsum(dy2)) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dx = gemm_bf16(dy2, w16, M, n, N, N, w16.stride(0), 0, 1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = _GRAD_SINK
+            if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
+                    and weight.grad.is_contiguous()):
+                _wgrad_into(sink, weight, weight.grad.view(N, Kf)[:, c0:c0 + n], dy2, x2, key=(id(weight), c0))
+            else:
+                dw = torch.zeros(N, Kf, dtype=torch.float32, device=dy2.device)
+                gemm_bf16(dy2, x2, N, n, M, N, n, 1, 1, out=dw[:, c0:c0 + n], ldc=Kf)
+                dw = dw.to(weight.dtype)
+        return dx, dw, db, None, None
+
+
+def linear_cols_ok(x, weight, c0, n):
+    return (x.dtype == torch.bfloat16 and x.is_cuda and weight.dim() == 2 and weight.is_contiguous() and x.shape[-1] == n
+            and n % 8 == 0 and c0 % 8 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and c0 + n <= weight.shape[1])
+
+
+def linear_cols(x, weight, bias, c0, n):
+    """x . W[:, c0:c0+n]^T (+ bias) on the HIP GEMM (see _LinearColsFn)."""
+    return _LinearColsFn.apply(x, weight, bias, int(c0), int(n))
+
+
 _PTR_TABLES = {}     # device arrays of weight-shadow addresses for the batched projections, by the tuple of addresses
 
 
@@ -571,12 +630,12 @@ class _LinearEpiFn(torch.autograd.Function):
         return dx, dw, (None if db is None else _pgrad(bias, db)), None, None, None
 
 
-def _wgrad_into(sink, weight, grad2d, dy2, x2):
+def _wgrad_into(sink, weight, grad2d, dy2, x2, key=None):
     """grad2d [N, K] += dy2 [M, N]^T . x2 [M, K]: queued for the arena's grouped launch (csrc/wgrad.hip) when it collects them,
     else one split-K GEMM now."""
     N, K = grad2d.shape
     M = dy2.shape[0]
-    if getattr(sink, "collect_wgrads", False) and wgrad_queue(weight, grad2d, dy2, x2):
+    if getattr(sink, "collect_wgrads", False) and wgrad_queue(weight, grad2d, dy2, x2, key):
         _WG["flops"] = _WG.get("flops", 0.0) + 2.0 * M * N * K
         _WG["bytes"] = _WG.get("bytes", 0.0) + 2.0 * M * (N + K) + 8.0 * N * K   # dy and x (bf16) read once, the fp32 gradient read and written
         sink.wgrad_queued(weight)
