@@ -230,6 +230,13 @@ int tsasr_relpos_dpk_pending(void);
 size_t tsasr_relpos_dpk_table_bytes(int max_jobs);
 int tsasr_relpos_dpk_flush(void *table_host, void *table_dev, size_t table_bytes, void *stream);
 void tsasr_relpos_dpk_discard(void);
+/* Dropout keep-bits handed from the forward to the backward (an optimisation of the pair above, not a change of their results): with
+ * bits = tsasr_relpos_attn_keepbits_bytes(B, T, H) > 0 bytes of device memory set by tsasr_relpos_attn_keepbits right before
+ * tsasr_relpos_attn_fwd[_ws] (bf16, Dh = 64, 2 <= T <= 256, pdrop > 0) the forward stores the mask bits it hashed, and set again right
+ * before the matching tsasr_relpos_attn_bwd the backward reads them (one 16-byte load per query row) instead of hashing every element
+ * again. The setting is consumed by the next forward / backward call; without it both hash - the same bits. */
+size_t tsasr_relpos_attn_keepbits_bytes(int B, int T, int H);
+void tsasr_relpos_attn_keepbits(void *bits);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093

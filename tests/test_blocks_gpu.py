@@ -384,6 +384,37 @@ def test_fused_attention_dropout_consistency(ops):
     assert float((out3 - out.detach()).abs().max()) > 1e-2
 
 
+@pytest.mark.parametrize("Tn,causal,ragged", [(250, False, True), (96, True, False), (33, False, True), (256, False, False)])
+def test_attention_keepbits_from_the_forward_give_the_same_gradients(ops, Tn, causal, ragged):
+    """Short bf16 sequences: the forward stores the dropout keep-bits it hashed and the backward reads them
+    (tsasr_relpos_attn_keepbits). Every gradient must equal, bit for bit, the one of a backward that hashes the mask again."""
+    B, H, Dh = 3, 4, 64
+    D = H * Dh
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(DEV, torch.bfloat16)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(DEV, torch.bfloat16)
+    u, v = (torch.randn(Dh, H, generator=g) * 0.3).to(DEV), (torch.randn(Dh, H, generator=g) * 0.3).to(DEV)
+    dout = torch.randn(B, Tn, D, generator=g).to(DEV, torch.bfloat16)
+    lens = torch.tensor([Tn, max(1, Tn - 37), max(1, Tn // 2 + 1)], dtype=torch.int32, device=DEV) if ragged else None
+    fn = ops._RelPosAttnFn
+    assert ops.C.lib().tsasr_relpos_attn_keepbits_bytes(B, Tn, H) == B * H * Tn * 32
+    grads = {}
+    prev = ops._ATTN_KEEPBITS
+    try:
+        for on in (True, False):
+            ops._ATTN_KEEPBITS = on
+            leaves = [t.clone().requires_grad_() for t in (qkv, pk, u, v)]
+            out = fn.apply(leaves[0], leaves[1], leaves[2], leaves[3], lens, H, 1.0 / D ** 0.5, causal, 0.1, 4321)
+            assert (out.grad_fn.keepbits is not None) == on
+            out.backward(dout)
+            grads[on] = [out.detach()] + [t.grad for t in leaves]
+    finally:
+        ops._ATTN_KEEPBITS = prev
+    for a, b_, name in zip(grads[True], grads[False], ("out", "dqkv", "dpk", "du", "dv")):
+        assert torch.isfinite(a.float()).all(), name
+        assert torch.equal(a, b_), name
+
+
 def test_fused_clip_adamw_vs_torch():
     """csrc/optim.hip vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (the reference's optimizer step)."""
     opt_mod = importlib.import_module("ts-asr_amd.optim")

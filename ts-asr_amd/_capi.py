@@ -76,6 +76,8 @@ _PROTOS = {
     "tsasr_relpos_dpk_table_bytes": (c_size_t, [c_int]),
     "tsasr_relpos_dpk_flush": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tsasr_relpos_dpk_discard": (None, []),
+    "tsasr_relpos_attn_keepbits_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_relpos_attn_keepbits": (None, [c_void_p]),
     "tsasr_accumulate_many": (c_int, [c_void_p, c_int, c_void_p]),
     "tsasr_clip_adamw_workspace_bytes": (c_size_t, []),
     "tsasr_clip_adamw_step": (c_int, [c_void_p] * 8 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),

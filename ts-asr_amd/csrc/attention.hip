@@ -484,7 +484,8 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
                                                                        const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
                                                                        float *__restrict__ lse, int Tn, int H, float scale, int causal,
                                                                        float pdrop, unsigned long long seed,
-                                                                       const unsigned long long *__restrict__ seed_dev) {
+                                                                       const unsigned long long *__restrict__ seed_dev,
+                                                                       unsigned short *__restrict__ keepbits /*[B*H*T][2][8] or NULL*/) {
     constexpr int Dh = 64, NQB = QH / 32, NKP = 8 / NQB, TPAD = 2 * QH, KP = TPAD / NKP, NB = QH + TPAD;   // NB band rows staged
     constexpr int K_OFF = 0, V_OFF = TPAD * 128, P_OFF = 2 * TPAD * 128, G_OFF = P_OFF + NB * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -620,6 +621,10 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
             const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
 #pragma unroll
             for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+            // the 16 keep-bits of this lane's keys of the 32-key sub-block, kept for the backward (tsasr_relpos_attn_keepbits): it then
+            // reads one 16-byte word per query row instead of hashing again (the hashes are ~5 us of its 52 us at T' = 250)
+            if (keepbits && iq < Tn)
+                keepbits[(((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + (jb >> 5)] = (unsigned short)(km[0] | (km[1] << 4) | (km[2] << 8) | (km[3] << 12));
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -722,7 +727,8 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                                                                 float *__restrict__ slab_uv, int Tp,
                                                                 int Bn, int Tn, int H, int Dh, float scale, int causal, float pdrop,
                                                                 unsigned long long seed, const unsigned long long *__restrict__ seed_dev,
-                                                                int nparts, int part_keys, float *__restrict__ dq_part) {
+                                                                int nparts, int part_keys, float *__restrict__ dq_part,
+                                                                const unsigned short *__restrict__ keepbits /*forward's keep-bits or NULL*/) {
     // nparts > 1: blockIdx.x = query block * nparts + key part (see relpos_attn_fwd_kernel); a part leaves its share of dQ in fp32 in
     // dq_part (summed by relpos_attn_dq_merge_kernel) and its own row of pos_bias partial sums; P_d / dS columns are disjoint anyway
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -778,6 +784,10 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
     }
     delta += other_half(delta);
     const float lse_i = lse[((long long)b * H + h) * Tn + iqc];
+    // forward's keep-bits of this lane's query row: 8 sub-blocks x 16 bits, one unconditional 16-byte load (a stand-in address without them)
+    const bool has_kb = keepbits != nullptr;
+    const uint4 kbw = *reinterpret_cast<const uint4 *>(has_kb ? reinterpret_cast<const char *>(keepbits + (((size_t)(b * H + h) * Tn + iqc) * 2 + hh) * 8)
+                                                             : reinterpret_cast<const char *>(qkv));
     f32x16 dqu[2], dqv[2];
     dqu[0] = dqu[1] = dqv[0] = dqv[1] = (f32x16){0};
     const unsigned thr = drop_thr16(pdrop);
@@ -866,9 +876,17 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
             for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
             unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
             if (pdrop > 0.f) {
-                const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+                if (has_kb) {       // workgroup-uniform; jb >> 5 is wave-uniform
+                    const int sb = jb >> 5;
+                    const unsigned pair = (sb >> 1) == 0 ? kbw.x : (sb >> 1) == 1 ? kbw.y : (sb >> 1) == 2 ? kbw.z : kbw.w;
+                    const unsigned w16 = (sb & 1) ? (pair >> 16) : (pair & 0xffffu);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+                    for (int q = 0; q < 4; ++q) km[q] = (w16 >> (4 * q)) & 0xfu;
+                } else {
+                    const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+                }
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -1366,6 +1384,7 @@ static size_t attn_part_bytes(int B, int T, int H) {
 
 static std::vector<DpkJob> g_dpk_jobs;
 static int g_dpk_defer = 0;
+static void *g_attn_keepbits = nullptr;     // tsasr_relpos_attn_keepbits: the next forward writes / the next backward reads them
 
 __global__ void attn_zero_kernel(uint4 *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1392,6 +1411,8 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, used);
     }
     const size_t lds_q = tsasr_relpos_attn_lds_bytes();
+    const unsigned short *kbq = (Tn <= 256 && sizeof(T) == 2) ? (const unsigned short *)g_attn_keepbits : nullptr;    // one-shot
+    g_attn_keepbits = nullptr;
     // A/B knob TSASR_ATTN_BWD_KG=2: two key groups per workgroup (8 waves, two per SIMD). Measured at T' = 250, B = 32 (one workgroup per
     // CU): 13.07 vs 13.06 ms per step with the tile prefetch dropped to fit 256 registers, 13.61 with it (76 spilled VGPRs) - the kernel
     // is bound by the CU's VALU / LDS instruction throughput, not by latency a second wave could cover. Off.
@@ -1401,12 +1422,12 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_q));
         relpos_attn_bwd_q_kernel<T, 2><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), 2 * AT_TH, 2 * lds_q, st>>>(
             (const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
-            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part);
+            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part, kbq);
     } else {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         relpos_attn_bwd_q_kernel<T, 1><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), AT_TH, lds_q, st>>>(
             (const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
-            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part);
+            causal, pdrop, seed, seed_dev, nparts, part_keys, dq_part, kbq);
     }
     if (nparts > 1)
         relpos_attn_dq_merge_kernel<T><<<(unsigned)(((long long)B * H * Tn * 16 + 255) / 256), 256, 0, st>>>(dq_part, key_lens, (T *)dqkv, B, Tn, H, Dh, causal,
@@ -1457,17 +1478,19 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
     dim3 grid(cdiv(T, AT_QB), H, B);
     hipStream_t st = (hipStream_t)stream;
     static const int use_short = 1;
+    unsigned short *kb = (unsigned short *)g_attn_keepbits;     // one-shot (tsasr_relpos_attn_keepbits); only the short-sequence kernel writes them
+    g_attn_keepbits = nullptr;
     if (use_short && io_dtype == TSASR_BF16 && Dh == 64 && T <= 256 && T >= 2) {
         if (T > 128) {
             constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 4096;   // K, V (256 rows), band (384 rows), 8 fp16 G tiles
             (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
             relpos_attn_fwd_short_kernel<128><<<dim3(cdiv(T, 128), H, B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
-                                                                                        (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev);
+                                                                                        (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev, kb);
         } else {
             constexpr int LDSS = (2 * 128 + 64 + 128) * 128 + 8 * 4096;
             (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
             relpos_attn_fwd_short_kernel<64><<<dim3(cdiv(T, 64), H, B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
-                                                                                      (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev);
+                                                                                      (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev, kb);
         }
         TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
         return 0;
@@ -1547,6 +1570,11 @@ int tsasr_relpos_dpk_defer(int on) {
 int tsasr_relpos_dpk_pending(void) { return (int)g_dpk_jobs.size(); }
 size_t tsasr_relpos_dpk_table_bytes(int max_jobs) { return (size_t)max_jobs * sizeof(DpkJob); }
 void tsasr_relpos_dpk_discard(void) { g_dpk_jobs.clear(); g_dpk_defer = 0; }
+/* One-shot side channel for the dropout keep-bits of the short-sequence kernels (bf16, Dh = 64, T <= 256; tsasr_relpos_attn_keepbits_bytes):
+ * set before tsasr_relpos_attn_fwd*, the forward stores them there; set to the same buffer before tsasr_relpos_attn_bwd, the backward
+ * reads them instead of hashing the mask again. NULL (or never called): both hash - same bits either way. */
+void tsasr_relpos_attn_keepbits(void *bits) { g_attn_keepbits = bits; }
+size_t tsasr_relpos_attn_keepbits_bytes(int B, int T, int H) { return (T >= 2 && T <= 256) ? (size_t)B * H * T * 16 * sizeof(unsigned short) : 0; }
 
 /* Runs every queued d(pk) pass: ONE launch for the passes, one for the sums of their partials (per io dtype present). table_host: PINNED
  * host memory, table_dev: device memory, both >= tsasr_relpos_dpk_table_bytes(tsasr_relpos_dpk_pending()); copied host -> device on `stream`

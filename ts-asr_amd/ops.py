@@ -1625,6 +1625,9 @@ def frontend_convs(x, w1, b1, w2, b2, padding):
 
 
 # ---------------------------------------------------------------------------------------------------------
+_ATTN_KEEPBITS = os.environ.get("TSASR_ATTN_KEEPBITS", "1") != "0"     # A/B: 0 = the backward hashes the attention dropout mask again
+
+
 class _RelPosAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed, dpk_deferrable=False):
@@ -1640,12 +1643,19 @@ class _RelPosAttnFn(torch.autograd.Function):
         lse = torch.empty(B, H, T, dtype=torch.float32, device=qkvc.device)
         ws_bytes = C.lib().tsasr_relpos_attn_fwd_workspace_bytes(B, T, H)   # > 0: long sequence, small batch - keys split across workgroups
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkvc.device) if ws_bytes else None   # consumed in stream order by the merge launch
+        # short sequences: the forward leaves its dropout keep-bits for the backward (32 bytes per query row and head) instead of both hashing
+        kb_bytes = (C.lib().tsasr_relpos_attn_keepbits_bytes(B, T, H)
+                    if _ATTN_KEEPBITS and pdrop > 0 and Dh == 64 and qkvc.dtype == torch.bfloat16 and ctx.needs_input_grad[0] else 0)
+        kb = torch.empty(kb_bytes, dtype=torch.uint8, device=qkvc.device) if kb_bytes else None
+        if kb is not None:
+            C.lib().tsasr_relpos_attn_keepbits(C.ptr(kb))
         with prof.region("relpos_attn_fwd"):
             C.check(C.lib().tsasr_relpos_attn_fwd_ws(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(lse),
                                                      B, T, H, Dh, float(scale), int(causal), float(pdrop), seed,
                                                      C.ptr(seed_state(qkvc.device)), C.io_dtype(qkvc),
                                                      C.ptr(ws), ws_bytes, C.stream_ptr()), "tsasr_relpos_attn_fwd")
         ctx.save_for_backward(qkvc, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
+        ctx.keepbits = kb
         ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed)
         return out
 
@@ -1676,6 +1686,8 @@ class _RelPosAttnFn(torch.autograd.Function):
         if _DPK["on"] and not defer:      # this call launches its own pass (queued ones first: the switch refuses to go off over a queue)
             dpk_flush()
             C.check(C.lib().tsasr_relpos_dpk_defer(0), "tsasr_relpos_dpk_defer")
+        if ctx.keepbits is not None:
+            C.lib().tsasr_relpos_attn_keepbits(C.ptr(ctx.keepbits))
         with prof.region("relpos_attn_bwd"):
             C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkvc), C.ptr(pkc), C.ptr(u), C.ptr(v), C.ptr(key_lens), C.ptr(out), C.ptr(dout),
                                                   C.ptr(lse), C.ptr(dqkv), C.ptr(dpk), C.ptr(du), C.ptr(dv), B, T, H, Dh, scale, int(causal),
