@@ -61,6 +61,15 @@ __device__ __forceinline__ float pin(float x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// The same for a whole batch of reads: ONE point where all of them must exist, so they are issued back to back and waited for once
+// (pin() on each read in turn made each one a round trip of its own: ds_read / s_waitcnt lgkmcnt(0) pairs in the ISA).
+__device__ __forceinline__ void pin_all(float (&a)[8]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+__device__ __forceinline__ void pin_all(float (&a)[16]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
 
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
@@ -321,7 +330,8 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             float sc[16], bdv[16];
             float mx = -INFINITY;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
+            for (int g = 0; g < 16; ++g) bdv[g] = g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r];   // unconditional, back to back
+            pin_all(bdv);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -598,8 +608,9 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
 #pragma unroll
         for (int g = 0; g < 16; ++g) {   // all 16 skewed reads issued back to back, unconditionally
             const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh, rowq = jl - r + 31;
-            bdv[g] = pin((float)g_lds[(((rowq >> 5) ^ sub) & 1) * 1024 + (rowq & 31) * 32 + r]);
+            bdv[g] = (float)g_lds[(((rowq >> 5) ^ sub) & 1) * 1024 + (rowq & 31) * 32 + r];
         }
+        pin_all(bdv);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
@@ -795,6 +806,8 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
     const DropKey dkey = drop_key(seed);
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
+    // last key this lane's query attends (-1: a row beyond the sequence - its P_d, dS and everything derived from them are zero)
+    const int j_max = q_ok ? min(len - 1, causal ? causal_limit(iq, causal) : 0x3fffffff) : -1;
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);
     int j_begin = part * part_keys;
@@ -873,7 +886,8 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
             AT_STAMP(2);   // S, dP, G MFMAs + G tile to LDS
             float ds[16], pdv[16], bdv[16];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) bdv[g] = pin(g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r]);   // unconditional, back to back
+            for (int g = 0; g < 16; ++g) bdv[g] = g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r];   // unconditional, back to back
+            pin_all(bdv);
             unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
             if (pdrop > 0.f) {
                 if (has_kb) {       // workgroup-uniform; jb >> 5 is wave-uniform
@@ -893,12 +907,11 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
                 const float bd = bdv[g];
                 const int j = jb + jl;
-                const bool masked = (j >= len) || (causal && j > causal_limit(iq, causal));
-                const float p = masked ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);
+                const float p = j > j_max ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);    // one compare: key length, look-ahead mask and "no such query"
                 float keep = 1.f;
                 if (pdrop > 0.f) keep = ((km[g >> 2] >> (g & 3)) & 1u) ? keep_scale : 0.f;
-                pdv[g] = q_ok ? p * keep : 0.f;
-                ds[g] = q_ok ? p * (dpd[g] * keep - delta) * scale : 0.f;
+                pdv[g] = p * keep;
+                ds[g] = p * (dpd[g] * keep - delta) * scale;
             }
             // P_d and scale*dS of this lane's query, 4 consecutive keys per store: the key-major pass (dK, dV) and d(pk) read them
             if (q_ok) {
@@ -940,7 +953,8 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                 bf16x8 dgb;
                 float dgv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dgv[e] = pin(g_lds[(16 * sp + 8 * hh + e) * 32 + r]);   // unconditional reads, masked afterwards (see pin())
+                for (int e = 0; e < 8; ++e) dgv[e] = g_lds[(16 * sp + 8 * hh + e) * 32 + r];   // unconditional reads, masked afterwards (see pin())
+                pin_all(dgv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int rl = 16 * sp + 8 * hh + e, jl = rl + r - 31;
