@@ -998,28 +998,57 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                 dqv[db][g] += xch[(32 + db * 16 + g) * 64 + lane];
             }
     }
-    // ---- dQ = dQ_ac + dQ_bd ; partial sums over queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd)
+    // ---- dQ = dQ_ac + dQ_bd, four consecutive head dims per store (the three cases are workgroup-uniform: no per-store branches)
     T *dq = dqkv + ((long long)b * Tn + iqc) * row_stride + (long long)h * 3 * Dh;
-    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * AT_NW + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
+    if (nparts > 1) {
+        if (q_ok && ntile > 0) {
+            float *dqp = dq_part + ((((size_t)b * H + h) * Tn + iq) * nparts + part) * AT_DP;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
-            if ((g & 3) == 0 && q_ok && nparts > 1) {
-                if (ntile > 0)
-                    *reinterpret_cast<float4 *>(dq_part + ((((size_t)b * H + h) * Tn + iq) * nparts + part) * AT_DP + d) =
+                for (int g = 0; g < 16; g += 4)
+                    *reinterpret_cast<float4 *>(dqp + 32 * db + 8 * (g >> 2) + 4 * hh) =
                         make_float4(dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
-            } else if ((g & 3) == 0 && q_ok) {   // four consecutive head dims per store
-                if (d + 4 <= Dh && (Dh % 4) == 0)
-                    st4(dq + d, dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2], dqu[db][g + 3] + dqv[db][g + 3]);
-                else
-                    for (int e = 0; e < 4; ++e)
-                        if (d + e < Dh) st1(dq + d + e, dqu[db][g + e] + dqv[db][g + e]);
-            }
-            const float su = half_sum(q_ok ? dqu[db][g] : 0.f, hh), sv = half_sum(q_ok ? dqv[db][g] : 0.f, hh);
-            if (r == 0) { slab[d] = su; slab[64 + d] = sv; }
         }
+    } else if (Dh == AT_DP) {
+        if (q_ok) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 16; g += 4)
+                    st4(dq + 32 * db + 8 * (g >> 2) + 4 * hh, dqu[db][g] + dqv[db][g], dqu[db][g + 1] + dqv[db][g + 1], dqu[db][g + 2] + dqv[db][g + 2],
+                        dqu[db][g + 3] + dqv[db][g + 3]);
+        }
+    } else if (q_ok) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int d = 32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                if (d < Dh) st1(dq + d, dqu[db][g] + dqv[db][g]);
+            }
+    }
+    // ---- partial sums over this wave's 32 queries for d(pos_bias_u) (= sum dQ_ac) and d(pos_bias_v) (= sum dQ_bd): the accumulators go
+    // through the wave's scratch as [dim][query] and lane d adds up row d, starting at column d so that the lanes of a read fall into
+    // different banks (64 DPP reductions with a guarded store each were 2,800 instructions = 15 % of this kernel's cycles). Rows beyond the
+    // sequence hold exact zeros (j_max = -1 above): nothing to mask.
+    float *slab = slab_uv + (((long long)(b * gridDim.x + blockIdx.x) * AT_NW + wave) * H + h) * 128;   // part = ((b, qtile), wave); row = [h][u 64 | v 64]
+    float colsum[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) g_lds[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = which ? dqv[db][g] : dqu[db][g];
+        __builtin_amdgcn_wave_barrier();
+        float part_sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 32; ++k) part_sum[k & 3] += g_lds[lane * 32 + ((k + lane) & 31)];
+        colsum[which] = (part_sum[0] + part_sum[1]) + (part_sum[2] + part_sum[3]);
+    }
+    slab[lane] = colsum[0];
+    slab[64 + lane] = colsum[1];
 #ifdef AT_PROFILE
     AT_STAMP(6);   // epilogue
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64)
