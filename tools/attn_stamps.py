@@ -81,7 +81,7 @@ def run(L, label, B, T, pdrop, H=4, Dh=64, iters=50, prof=False):
         f = lse.view(-1)[:14].view(torch.int64).cpu().tolist()
         bwd()
         torch.cuda.synchronize()
-        b_ = ws[:56].view(torch.int64).cpu().tolist()
+        b_ = ws[H * 512:H * 512 + 56].view(torch.int64).cpu().tolist()      # wave 1's row of the partial-sum slab
         for title, names, vals in (("forward (short kernel)", FWD_PHASES, f), ("backward query-major pass", BWD_PHASES, b_)):
             tot = max(1, sum(vals))
             print(f"  {title}: {tot} cycles in workgroup (0,0,0), wave 1")

@@ -73,10 +73,13 @@ __device__ __forceinline__ void pin_all(float (&a)[16]) {
 
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
-__device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) {
-    bf16x4 o;
-    o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
-    *reinterpret_cast<bf16x4 *>(p) = o;
+// two floats -> one register of two bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: element-wise `(bf16_t)x` casts came out as one
+// conversion per element plus a v_perm to pack each pair in these kernels
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2)); }
+__device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<uint2 *>(p) = make_uint2(pk_bf16(a, b), pk_bf16(c, d)); }
+__device__ __forceinline__ bf16x8 bf16x8_of(unsigned a, unsigned b, unsigned c, unsigned d) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(bf16x8, (u32x4){a, b, c, d});
 }
 // sum over the 32 lanes of this lane's half of the wave (hh = lane >> 5): DPP inside the 16-lane rows, two readlanes per half
 __device__ __forceinline__ float half_sum(float v, int hh) {
@@ -806,8 +809,26 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
     const DropKey dkey = drop_key(seed);
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
+    // dG^T fragment masks: element (band row rl = 16 sp + 8 hh + e, query r) of a 32-key sub-block exists iff 0 <= rl + r - 31 < 32; as bf16-pair
+    // bit masks (one AND per converted pair instead of a compare-select per element)
+    unsigned dgmask[4][4];
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jl0 = 16 * sp + 8 * hh + 2 * k + r - 31;
+            dgmask[sp][k] = ((jl0 >= 0 && jl0 < 32) ? 0xffffu : 0u) | ((jl0 + 1 >= 0 && jl0 + 1 < 32) ? 0xffff0000u : 0u);
+        }
+    // this lane's row of P_d / dS, at its first key of a sub-block
+    T *const prow0 = pd_out + (((long long)b * H + h) * Tn + iqc) * Tp + 4 * hh;
+    T *const srow0 = ds_out + (((long long)b * H + h) * Tn + iqc) * Tp + 4 * hh;
+    const unsigned ks_bits = __float_as_uint(keep_scale);
     // last key this lane's query attends (-1: a row beyond the sequence - its P_d, dS and everything derived from them are zero)
     const int j_max = q_ok ? min(len - 1, causal ? causal_limit(iq, causal) : 0x3fffffff) : -1;
+    int j_all = j_max;      // ... and the last key EVERY query of this wave attends: sub-blocks up to it need no mask at all
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) j_all = min(j_all, __shfl_xor(j_all, o));
+    j_all = __builtin_amdgcn_readfirstlane(j_all);
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);
     int j_begin = part * part_keys;
@@ -888,39 +909,40 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
 #pragma unroll
             for (int g = 0; g < 16; ++g) bdv[g] = g_lds[((g & 3) + 8 * (g >> 2) + 4 * hh - r + 31) * 32 + r];   // unconditional, back to back
             pin_all(bdv);
-            unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
+            unsigned kw = 0xffffu;   // keep-bits of this lane's 16 keys (bit g = accumulator element g)
             if (pdrop > 0.f) {
                 if (has_kb) {       // workgroup-uniform; jb >> 5 is wave-uniform
                     const int sb = jb >> 5;
                     const unsigned pair = (sb >> 1) == 0 ? kbw.x : (sb >> 1) == 1 ? kbw.y : (sb >> 1) == 2 ? kbw.z : kbw.w;
-                    const unsigned w16 = (sb & 1) ? (pair >> 16) : (pair & 0xffffu);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) km[q] = (w16 >> (4 * q)) & 0xfu;
+                    kw = (sb & 1) ? (pair >> 16) : (pair & 0xffffu);
                 } else {
                     const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+                    kw = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+                    for (int q = 0; q < 4; ++q) kw |= drop_keep4(idx0 + 8 * q, dkey, thr) << (4 * q);
                 }
             }
+            auto probs = [&](auto full_tag) {       // full: every key of the sub-block exists for every query of the wave
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
-                const float bd = bdv[g];
-                const int j = jb + jl;
-                const float p = j > j_max ? 0.f : __expf((s_acc[g] + bd) * scale - lse_i);    // one compare: key length, look-ahead mask and "no such query"
-                float keep = 1.f;
-                if (pdrop > 0.f) keep = ((km[g >> 2] >> (g & 3)) & 1u) ? keep_scale : 0.f;
-                pdv[g] = p * keep;
-                ds[g] = p * (dpd[g] * keep - delta) * scale;
-            }
+                for (int g = 0; g < 16; ++g) {
+                    const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                    float p = __expf((s_acc[g] + bdv[g]) * scale - lse_i);
+                    if (!FULL) p = j > j_max ? 0.f : p;     // one compare: key length, look-ahead mask and "no such query"
+                    // dropout factor: the element's keep-bit spread over a word (v_bfe_i32) ANDed with the bits of 1 / (1 - p)
+                    const float keep = pdrop > 0.f ? __uint_as_float((unsigned)((int)(kw << (31 - g)) >> 31) & ks_bits) : 1.f;
+                    pdv[g] = p * keep;
+                    ds[g] = p * (dpd[g] * keep - delta) * scale;
+                }
+            };
+            if (jb + 31 <= j_all) probs(std::true_type{});
+            else probs(std::false_type{});
             // P_d and scale*dS of this lane's query, 4 consecutive keys per store: the key-major pass (dK, dV) and d(pk) read them
             if (q_ok) {
-                T *prow = pd_out + (((long long)b * H + h) * Tn + iq) * Tp + jb + 4 * hh;
-                T *srow = ds_out + (((long long)b * H + h) * Tn + iq) * Tp + jb + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    st4(prow + 8 * q, pdv[4 * q], pdv[4 * q + 1], pdv[4 * q + 2], pdv[4 * q + 3]);
-                    st4(srow + 8 * q, ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
+                    st4(prow0 + jb + 8 * q, pdv[4 * q], pdv[4 * q + 1], pdv[4 * q + 2], pdv[4 * q + 3]);
+                    st4(srow0 + jb + 8 * q, ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -930,8 +952,11 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
             for (int g = 0; g < 16; ++g) {
                 const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
                 g_lds[(jl - r + 31) * 32 + r] = ds[g];
-                dsb[g >> 3][g & 7] = (bf16_t)ds[g];
             }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                dsb[s2] = bf16x8_of(pk_bf16(ds[8 * s2], ds[8 * s2 + 1]), pk_bf16(ds[8 * s2 + 2], ds[8 * s2 + 3]), pk_bf16(ds[8 * s2 + 4], ds[8 * s2 + 5]),
+                                    pk_bf16(ds[8 * s2 + 6], ds[8 * s2 + 7]));
             __builtin_amdgcn_wave_barrier();
             AT_STAMP(3);   // skewed read, p, dS, inverse skew
             // dQ_ac^T += K^T . dSs^T   (A = K^T through the transposing read; k order of dsb = accumulator row order)
@@ -950,16 +975,11 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
             // dQ_bd^T += Pband^T . dG^T   (natural k order: band rows 16s' + 8hh + e), predicate = "this (r,i) has a key"
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) {
-                bf16x8 dgb;
                 float dgv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dgv[e] = g_lds[(16 * sp + 8 * hh + e) * 32 + r];   // unconditional reads, masked afterwards (see pin())
-                pin_all(dgv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int rl = 16 * sp + 8 * hh + e, jl = rl + r - 31;
-                    dgb[e] = (bf16_t)((jl >= 0 && jl < 32) ? dgv[e] : 0.f);
-                }
+                for (int e = 0; e < 8; ++e) dgv[e] = g_lds[(16 * sp + 8 * hh + e) * 32 + r];   // unconditional reads; elements without a key are masked after the conversion
+                const bf16x8 dgb = bf16x8_of(pk_bf16(dgv[0], dgv[1]) & dgmask[sp][0], pk_bf16(dgv[2], dgv[3]) & dgmask[sp][1],
+                                             pk_bf16(dgv[4], dgv[5]) & dgmask[sp][2], pk_bf16(dgv[6], dgv[7]) & dgmask[sp][3]);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16_t *a0 = p_lds + (base + 16 * sp + 8 * hh + q4) * AT_LD + 32 * db + 16 * mhalf + 4 * p4;
@@ -1052,7 +1072,7 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
 #ifdef AT_PROFILE
     AT_STAMP(6);   // epilogue
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 64)
-        for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(slab_uv)[i] = acc_t[i];
+        for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(slab)[i] = acc_t[i];     // over this wave's own partial sums (row 1 * H of the slab)
 #endif
 }
 
