@@ -574,6 +574,12 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
     const DropKey dkey = drop_key(seed);
     const int lim_q = causal ? causal_limit(iq, causal) : 0x3fffffff;
     const int lim_blk = causal ? causal_limit(min(i0 + 32 * qb + 31, Tn - 1), causal) : 0x3fffffff;   // last key any query of this wave attends
+    const int j_lim = min(len - 1, lim_q);      // last key this lane's query attends ...
+    int j_all = j_lim;                          // ... and the last one EVERY query of the wave attends
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) j_all = min(j_all, __shfl_xor(j_all, o));
+    j_all = __builtin_amdgcn_readfirstlane(j_all);
+    const unsigned ks_bits = __float_as_uint(keep_scale);
     const char *k_lds = smem + K_OFF, *v_lds = smem + V_OFF, *p_lds = smem + P_OFF;
     _Float16 *g_lds = reinterpret_cast<_Float16 *>(smem + G_OFF + wave * 4096);   // two slots of [32 band rows][32 queries]
     const int fr_swz = (r >> 1) & 7;   // fragment rows are 32-aligned + r: the swizzle term of a b128 fragment read is the lane's own
@@ -614,39 +620,57 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
             bdv[g] = (float)g_lds[(((rowq >> 5) ^ sub) & 1) * 1024 + (rowq & 31) * 32 + r];
         }
         pin_all(bdv);
+        // full: every key of this sub-block exists for every query of the wave (all but the last sub-block of an unmasked sequence):
+        // no key mask, and the running maximum is finite
+        const bool full = jb + 31 <= j_all;
+        auto scores = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int jl = (g & 3) + 8 * (g >> 2) + 4 * hh;
-            const float bd = bdv[g];
-            const int j = jb + jl;
-            float x = (s_acc[g] + bd) * scale;
-            if (j >= len || j > lim_q) x = -INFINITY;
-            sc[g] = x;
-            mx = fmaxf(mx, x);
-        }
+            for (int g = 0; g < 16; ++g) {
+                const int j = jb + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                float x = (s_acc[g] + bdv[g]) * scale;
+                if (!FULL && j > j_lim) x = -INFINITY;
+                sc[g] = x;
+                mx = fmaxf(mx, x);
+            }
+        };
+        if (full) scores(std::true_type{});
+        else scores(std::false_type{});
         __builtin_amdgcn_wave_barrier();
         mx = fmaxf(mx, other_half(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
         float psum = 0.f;
         bf16x8 pb[2];
-        unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
+        unsigned kw = 0xffffu;   // keep-bits of this lane's 16 keys (bit g = accumulator element g)
         if (pdrop > 0.f) {
             const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+            kw = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
-            // the 16 keep-bits of this lane's keys of the 32-key sub-block, kept for the backward (tsasr_relpos_attn_keepbits): it then
-            // reads one 16-byte word per query row instead of hashing again (the hashes are ~5 us of its 52 us at T' = 250)
-            if (keepbits && iq < Tn)
-                keepbits[(((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + (jb >> 5)] = (unsigned short)(km[0] | (km[1] << 4) | (km[2] << 8) | (km[3] << 12));
+            for (int q = 0; q < 4; ++q) kw |= drop_keep4(idx0 + 8 * q, dkey, thr) << (4 * q);
+            // kept for the backward (tsasr_relpos_attn_keepbits): it then reads one 16-byte word per query row instead of hashing again
+            // (the hashes are ~5 us of its 52 us at T' = 250)
+            if (keepbits && iq < Tn) keepbits[(((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + (jb >> 5)] = (unsigned short)kw;
         }
+        float pf[16];
+        auto probs = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            float p = (m_new == -INFINITY) ? 0.f : __expf(sc[g] - m_new);
-            psum += p;
-            if (pdrop > 0.f) p = ((km[g >> 2] >> (g & 3)) & 1u) ? p * keep_scale : 0.f;
-            pb[g >> 3][g & 7] = (bf16_t)p;
-        }
+            for (int g = 0; g < 16; ++g) {
+                float p = __expf(sc[g] - m_new);
+                if (!FULL) p = (m_new == -INFINITY) ? 0.f : p;
+                psum += p;
+                // dropout: the element's keep-bit spread over a word (v_bfe_i32) ANDed with the bits of 1 / (1 - p)
+                if (pdrop > 0.f) p *= __uint_as_float((unsigned)((int)(kw << (31 - g)) >> 31) & ks_bits);
+                pf[g] = p;
+            }
+        };
+        if (full) probs(std::true_type{});
+        else probs(std::false_type{});
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            pb[s2] = bf16x8_of(pk_bf16(pf[8 * s2], pf[8 * s2 + 1]), pk_bf16(pf[8 * s2 + 2], pf[8 * s2 + 3]), pk_bf16(pf[8 * s2 + 4], pf[8 * s2 + 5]),
+                               pk_bf16(pf[8 * s2 + 6], pf[8 * s2 + 7]));
         psum += other_half(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
