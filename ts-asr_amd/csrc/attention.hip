@@ -73,9 +73,6 @@ __device__ __forceinline__ void pin_all(float (&a)[16]) {
 
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
-// two floats -> one register of two bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: element-wise `(bf16_t)x` casts came out as one
-// conversion per element plus a v_perm to pack each pair in these kernels
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2)); }
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<uint2 *>(p) = make_uint2(pk_bf16(a, b), pk_bf16(c, d)); }
 __device__ __forceinline__ bf16x8 bf16x8_of(unsigned a, unsigned b, unsigned c, unsigned d) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -181,19 +181,21 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
                 if constexpr (use_mask) km = (unsigned)mraw[it];
                 else km = a.p > 0.f ? drop_keep_mask<8>((unsigned long long)m * a.N + n, dk, thr) : ~0u;
                 if (MODE == 1) {
-                    unsigned neg = 0;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = v[e] + bias8[e];
                         if (a.slope >= 0.f) t = lrelu(t, a.slope);
-                        if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
+                        // dropout: the keep-bit spread over a word (v_bfe_i32) ANDed into the scaled value (a dropped element is +0)
+                        if (a.p > 0.f) t = __uint_as_float(__float_as_uint(t * ks) & (unsigned)((int)(km << (31 - e)) >> 31));
                         v[e] = t;
-                        if constexpr (MASK) {
-                            const unsigned short yb = __builtin_bit_cast(unsigned short, (bf16_t)t);     // the value as it is stored
-                            neg |= (((yb >> 15) & 1u) & (unsigned)((yb & 0x7fffu) != 0)) << e;
-                        }
                     }
-                    if constexpr (MASK) {
+                    if constexpr (MASK) {     // sign bits of the values AS STORED (bf16, pair-converted; -0 counts as not negative)
+                        unsigned neg = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned w = pk_bf16(v[2 * q], v[2 * q + 1]);
+                            neg |= ((w & 0xffffu) > 0x8000u ? 1u : 0u) << (2 * q) | (w > 0x80000000u ? 1u : 0u) << (2 * q + 1);
+                        }
                         if (FULL || m < a.M) a.mask[((long long)m * a.N + n) >> 3] = (unsigned short)((km & 0xffu) | (neg << 8));
                     }
                 } else if constexpr (use_mask) {
