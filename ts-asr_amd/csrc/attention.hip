@@ -74,10 +74,6 @@ __device__ __forceinline__ void pin_all(float (&a)[16]) {
 // four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
 __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
 __device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<uint2 *>(p) = make_uint2(pk_bf16(a, b), pk_bf16(c, d)); }
-__device__ __forceinline__ bf16x8 bf16x8_of(unsigned a, unsigned b, unsigned c, unsigned d) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(bf16x8, (u32x4){a, b, c, d});
-}
 // sum over the 32 lanes of this lane's half of the wave (hh = lane >> 5): DPP inside the 16-lane rows, two readlanes per half
 __device__ __forceinline__ float half_sum(float v, int hh) {
     v += dpp_mov<0xB1>(v);

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
 // workgroup's LDS (dec tile + one enc row per wave: 47 KB at J = 640), so two workgroups share a CU and a SIMD holds two waves - the
 // one-wave form left the LDS round trips and the MFMA issue of a frame uncovered (the kernel is bound by the VALU work of
 // h = lrelu(enc + dec), 5.5 operations per lattice cell and joint dimension).
-template <int NKS>
+// S01: 0 <= slope <= 1 (checked by the launcher; LeakyReLU's 0.01): lrelu(x) = max(x, slope * x), two operations instead of three - the same
+// values (x > 0: x >= slope * x; x <= 0: slope * x >= x).
+template <int NKS, bool S01>
 __global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__restrict__ enc, const bf16_t *__restrict__ dec,
                                                                 const float *__restrict__ W, const float *__restrict__ bias,
                                                                 float *__restrict__ logits, int Tn, int U1, int V, int ldl, float slope) {
@@ -205,9 +207,13 @@ __global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__
             float e8[8], d8[8];
             ld8(erow + 16 * s, e8);
             ld8(drow + 16 * s, d8);
-            bf16x8 hb;
+            float hv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) hb[j] = (bf16_t)lrelu(e8[j] + d8[j], slope);
+            for (int j = 0; j < 8; ++j) {
+                const float x = e8[j] + d8[j];
+                hv[j] = S01 ? fmaxf(x, x * slope) : lrelu(x, slope);
+            }
+            const bf16x8 hb = bf16x8_of(pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3]), pk_bf16(hv[4], hv[5]), pk_bf16(hv[6], hv[7]));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], hb, acc, 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 2 * NKS LDS reads of a frame (it spilled 149 VGPRs)
         }
@@ -393,14 +399,20 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f.wf[i][1], D, 0, 0, 0);
             bf16x8 hb[2];
             float esum = 0.f;   // sum of dh over this tile's 16 u rows of the lane: the tile's share of denc[b, t, k]
+            float hv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float x = e + dv[i][g];
-                const float dh = (x > 0.f) ? D[g] : slope * D[g];
+                const float fct = x > 0.f ? 1.f : slope;      // one select serves the activation and its derivative (x * 1 and D * 1 are exact)
+                const float dh = D[g] * fct;
                 dacc[i][g] += dh;
                 esum += dh;
-                hb[g >> 3][g & 7] = (bf16_t)lrelu(x, slope);
+                hv[g] = x * fct;
             }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                hb[s2] = bf16x8_of(pk_bf16(hv[8 * s2], hv[8 * s2 + 1]), pk_bf16(hv[8 * s2 + 2], hv[8 * s2 + 3]), pk_bf16(hv[8 * s2 + 4], hv[8 * s2 + 5]),
+                                   pk_bf16(hv[8 * s2 + 6], hv[8 * s2 + 7]));
             if (denc_part) {    // dh is in registers here anyway: the separate denc pass recomputed every one of these tiles
                 esum += other_half(esum);
                 if (h == 0) denc_part[(((size_t)ut * nb + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
@@ -1009,7 +1021,10 @@ int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const floa
     } else if (io_dtype == TSASR_BF16 && J == 640) {      // the TS-ASR joint (joint_dim 640): head matrix in registers, two workgroups per CU
         const size_t lds_r = (size_t)32 * (J + 8) * sizeof(bf16_t) + (size_t)4 * J * sizeof(bf16_t) + 32 * sizeof(float);
         while (nut * B * tsplit < 1024 && T / (tsplit * 2) >= 16) tsplit *= 2;      // (512 / 1024 / 2048 workgroups measured equal)
-        joint_fwd_regw_kernel<40><<<dim3(nut, tsplit, B), 256, lds_r, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, V, ldl, slope);
+        if (slope >= 0.f && slope <= 1.f)
+            joint_fwd_regw_kernel<40, true><<<dim3(nut, tsplit, B), 256, lds_r, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, V, ldl, slope);
+        else
+            joint_fwd_regw_kernel<40, false><<<dim3(nut, tsplit, B), 256, lds_r, st>>>((const bf16_t *)enc, (const bf16_t *)dec, W, bias, logits, T, U1, V, ldl, slope);
     } else if (io_dtype == TSASR_BF16) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)joint_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
