@@ -1300,14 +1300,24 @@ __device__ __forceinline__ void dpk_body(const T *__restrict__ ds, const T *__re
             }
             __syncthreads();
             {   // A tile: thread = (band row rl, 16 consecutive queries)
+                // All 16 reads are issued together and masked afterwards by a bit mask: written as `valid ? raw[..] : 0` with the four-term
+                // validity test, each read sat in its own exec-masked block behind ~50 instructions of branches and was waited for on the
+                // spot - 16 serialized LDS round trips per tile for 4 MFMAs. Without a look-ahead mask the valid elements of a thread are a
+                // contiguous range of q (j = jlo + rl + il0 + q in [0, len), i0 + il0 + q < Tn).
                 const int rl = tid >> 2, il0 = (tid & 3) * 16;
                 float v16[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int il = il0 + q, i = i0 + il, j = jlo + rl + il;
-                    const float x = (float)raw[il * SH_LD + off + rl + il];
-                    v16[q] = (i < Tn && j >= 0 && j < len && !(causal && j > causal_limit(i, causal))) ? x : 0.f;
+                for (int q = 0; q < 16; ++q) v16[q] = (float)raw[(il0 + q) * SH_LD + off + rl + il0 + q];     // always inside the 64 x 136 rectangle
+                pin_all(v16);
+                const int jq0 = jlo + rl + il0;                                                   // key of q = 0
+                const int q_lo = min(max(-jq0, 0), 16), q_hi = min(max(min(len - jq0, Tn - i0 - il0), 0), 16);
+                unsigned vm = q_hi > q_lo ? (0xffffu >> (16 - q_hi)) & (0xffffu << q_lo) : 0u;
+                if (causal) {       // workgroup-uniform
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) vm &= ~((jq0 + q > causal_limit(i0 + il0 + q, causal) ? 1u : 0u) << q);
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v16[q] = __uint_as_float(__float_as_uint(v16[q]) & (unsigned)((int)(vm << (31 - q)) >> 31));
                 st8(a_tile + rl * DPK_LD + il0, *reinterpret_cast<float(*)[8]>(&v16[0]));
                 st8(a_tile + rl * DPK_LD + il0 + 8, *reinterpret_cast<float(*)[8]>(&v16[8]));
             }
