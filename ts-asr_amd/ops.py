@@ -1625,7 +1625,7 @@ def frontend_convs(x, w1, b1, w2, b2, padding):
 
 
 # ---------------------------------------------------------------------------------------------------------
-_ATTN_KEEPBITS = os.environ.get("TSASR_ATTN_KEEPBITS", "1") != "0"     # A/B: 0 = the backward hashes the attention dropout mask again
+_ATTN_KEEPBITS = True     # False (tests): the backward hashes the attention dropout mask again instead of reading the forward's keep-bits
 
 
 class _RelPosAttnFn(torch.autograd.Function):
