@@ -1012,6 +1012,7 @@ int tsasr_gemm_bf16_fused(const void *A, const void *B, void *C, int M, int N, i
     TSASR_CHECK_ARG(epi_mode == 1 || (epi_mode == 2 && y && ldy % 8 == 0), "tsasr_gemm_bf16_fused: bad epilogue mode %d", epi_mode);
     TSASR_CHECK_ARG(!mask || (!transA && !transB && tsasr_gemm_bf16_fused_mask_ok(M, N, K)), "tsasr_gemm_bf16_fused: no mask words for this shape (ask tsasr_gemm_bf16_fused_mask_ok)");
     TSASR_CHECK_ARG(p >= 0.f && p < 1.f, "tsasr_gemm_bf16_fused: bad dropout %f", p);
+    TSASR_CHECK_ARG(!(mask && slope > 1.f), "tsasr_gemm_bf16_fused: mask words need a LeakyReLU slope in [0, 1] (or none), got %f", slope);
     TSASR_CHECK_ARG(!(epi_mode == 2 && dbias) || (workspace && workspace_bytes >= tsasr_gemm_bf16_fused_workspace_bytes(M, N)), "tsasr_gemm_bf16_fused: workspace too small");
     GemmPlan pl = plan(M, N, K, 0);
     hipStream_t st = (hipStream_t)stream;
