@@ -130,6 +130,7 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
     const unsigned thr = drop_thr16(a.p);
     const float ks = drop_scale16(thr);
     const float ks_eff = a.p > 0.f ? ks : 1.f, slope_eff = a.slope >= 0.f ? a.slope : 1.f;     // (the launcher refuses slopes above 1)
+    const unsigned ks_bits = __float_as_uint(ks_eff), ks_slope_bits = __float_as_uint(ks_eff * slope_eff);
     const DropKey dk = drop_key(seed);
     constexpr int HR = BM / 2, CPR = GBG_BN / 8, NIT = HR * CPR / GBG_THREADS;   // rows per half, 16-byte chunks per row, chunks per thread
     const int cc = (threadIdx.x % CPR) * 8, rr0 = threadIdx.x / CPR, n = n0 + cc;   // GBG_THREADS % CPR == 0: one column group per thread
@@ -203,24 +204,25 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
                         }
                         if (FULL || m < a.M) a.mask[((long long)m * a.N + n) >> 3] = (unsigned short)((km & 0xffu) | (neg << 8));
                     }
-                } else if constexpr (use_mask) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float t = v[e];
-                        if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
-                        if (a.slope >= 0.f && ((km >> (8 + e)) & 1u)) t *= a.slope;
-                        v[e] = t;
-                        if (FULL || m < a.M) csum[e] += t;
-                    }
                 } else {
-                    const unsigned yw[4] = {yraw[it].x, yraw[it].y, yraw[it].z, yraw[it].w};
+                    // mode 2: keep-bits (0 .. 7) and "the stored activation was negative" bits (8 .. 15) of the 8 elements - the forward's mask
+                    // word, or the same word rebuilt from the hash and the saved activation; ONE arithmetic path for both (they must give
+                    // the same bits). Per element: the factor ks or ks * slope picked by the sign bit (v_bfe_i32 + v_bfi_b32), one
+                    // multiply, the keep-bit ANDed in (a dropped element is +0).
+                    unsigned kw = km & 0xffu;
+                    if constexpr (use_mask) kw = km;
+                    else {
+                        const unsigned yw[4] = {yraw[it].x, yraw[it].y, yraw[it].z, yraw[it].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)       // sign bit of a bf16 activation that is not a zero
+                            kw |= (((yw[q] & 0xffffu) > 0x8000u ? 1u : 0u) << (8 + 2 * q)) | ((yw[q] > 0x80000000u ? 1u : 0u) << (9 + 2 * q));
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const bool y_neg = (yw[e >> 1] >> ((e & 1) ? 31 : 15)) & 1u;   // sign bit of the bf16 activation
-                        const bool y_nz = ((yw[e >> 1] >> ((e & 1) ? 16 : 0)) & 0x7fffu) != 0;
-                        float t = v[e];
-                        if (a.p > 0.f) t = ((km >> e) & 1u) ? t * ks : 0.f;
-                        if (a.slope >= 0.f && y_neg && y_nz) t *= a.slope;
+                        const unsigned ng = (unsigned)((int)(kw << (23 - e)) >> 31);            // the activation was negative: all ones
+                        float t = v[e] * __uint_as_float((ng & ks_slope_bits) | (~ng & ks_bits));
+                        t = __uint_as_float(__float_as_uint(t) & (unsigned)((int)(kw << (31 - e)) >> 31));
+                        asm("" : "+v"(t));      // the ROUNDED product joins the column sum in every instantiation (no contraction into an fma here and not there)
                         v[e] = t;
                         if (FULL || m < a.M) csum[e] += t;
                     }
