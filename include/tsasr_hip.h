@@ -49,6 +49,15 @@ int tsasr_device_ok(void);
 int tsasr_joint_fwd(const void *enc, const void *dec, const float *W, const float *bias, float *logits,
                     int B, int T, int U1, int J, int V, int ldl, int io_dtype, float slope, void *stream);
 
+/* The same joint + head in EXACT fp32 arithmetic (csrc/joint_f32.hip: no matrix cores, no bf16 rounding of h, W or dlogits): the
+ * `compute_dtype: fp32` parity mode. fp32 storage only; V <= 32, J <= 768; dW / dbias through the deferrable batched reduction. */
+int tsasr_joint_f32_fwd(const float *enc, const float *dec, const float *W, const float *bias, float *logits, int B, int T, int U1, int J, int V,
+                        int ldl, float slope, void *stream);
+size_t tsasr_joint_f32_bwd_workspace_bytes(int B, int U1, int J);
+int tsasr_joint_f32_bwd(const float *dlogits, const float *enc, const float *dec, const float *W, float *denc, float *ddec, float *dW,
+                        float *dbias, const int32_t *tlen, const int32_t *ulen, int B, int T, int U1, int J, int V, int ldl, float slope,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 size_t tsasr_joint_bwd_workspace_bytes(int B, int T, int U1, int J);
 /* Backward of the above: denc[b,t,:], ddec[b,u,:] (io_dtype), dW[V,J], dbias[V] (fp32, OVERWRITTEN; while tsasr_reduce_defer(1)
  * is in force the two are parameter-gradient outputs like the others: written by tsasr_reduce_flush, workspace kept until then).
@@ -260,6 +269,7 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
  *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
  * ------------------------------------------------------------------------------------------ */
 void tsasr_gemm_set_ring(int on);                 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: whenever K % 64 == 0; 0: register-staged loop (A/B tests) */
+void tsasr_gemm_set_nn128(int stages, int wavek, int floor_mode);   /* tuning / lab: main loop of the 128x64 bf16 tile (csrc/gemm.hip gemm_nn128x64_kernel); 0,0,0 = default */
 void tsasr_gemm_set_plan(int tile, int splits);   /* A/B tests only: force macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64, -1 = automatic) and split-K */
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
@@ -393,6 +403,12 @@ void tsasr_wgrad_next_flush_wgs(int wgs);
 int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_mean_pool_bwd(const void *dout, const float *rel, void *dx, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_abs_lengths(const float *const *rel, int *const *out, const int *dim, const int *mode, int n, int B, void *stream);
+/* Speaker-embedding injection modes `sum` / `prod` (models/conformer.py:247-253; mode 0 / 1): out [B,T,D] = src [B,T,D] (+ | *) spk [B,1,D],
+ * D % 8 == 0; backward in one pass over dout: dsrc [B,T,D], dspk [B,1,D] (sums over t in a fixed order). (`cat` = column ranges of
+ * tsasr_gemm_bf16*, `cross_attention` = tsasr_attn_f32_* between GEMMs.) */
+int tsasr_inject_fwd(const void *src, const void *spk, void *out, int B, int T, int D, int mode, int io_dtype, void *stream);
+int tsasr_inject_bwd(const void *dout, const void *src, const void *spk, void *dsrc, void *dspk, int B, int T, int D, int mode, int io_dtype,
+                     void *stream);
 /* ------------------------------------------------------------------------------------------
  * Greedy transducer search on the device (SB/decoders/transducer.py:138-218, transducer_greedy_decode): one launch decodes the batch,
  * one persistent workgroup per utterance; predictor = embedding table -> one-layer LSTM -> Linear, joiner = LeakyReLU(enc + pn) -> Linear
@@ -405,21 +421,6 @@ int tsasr_greedy_decode(const void *enc, const float *emb, const void *w_ih, con
                         const void *w_proj, const float *b_proj, const void *w_head, const float *b_head, int *preds, float *logp_sum,
                         int B, int T, int J, int H, int E, int V, int blank, float slope, int io_dtype, int wdtype, void *stream);
 
-/* TEST AID (tests / tools only): overwrite the whole LDS of every CU with a 32-bit pattern, so that a kernel reading LDS it never wrote
- * sees the pattern instead of whatever the previous kernel left there. */
-int tsasr_debug_fill_lds(unsigned pattern, void *stream);
-/* TEST AID: LDS canary (tools/lds_canary.py): wgs workgroups hold lds_bytes of LDS each and verify a pattern iters times while other
- * streams' kernels run beside them; *errors (DEVICE uint) += corrupted words, first_bad (DEVICE uint[4] or NULL) describes one. */
-int tsasr_debug_lds_canary(int wgs, int lds_bytes, int iters, void *errors, void *first_bad, void *stream);
-/* TEST AID: barrier canary: wgs workgroups x rounds of {every wave writes a quarter of an LDS table, barrier, every lane reads words of
- * all four waves}; *errors (DEVICE uint[2]) += words that were not yet visible behind the barrier. */
-int tsasr_debug_barrier_canary(int wgs, int rounds, void *errors, void *first_bad, void *stream);
-/* TEST AID: register canary: wgs x 256 lanes keep 48 VGPRs each and verify them iters times; *errors (DEVICE uint) += changed registers. */
-int tsasr_debug_vgpr_canary(int wgs, int iters, void *errors, void *first_bad, void *stream);
-/* TEST AID: nwords 32-bit words at p <- pattern (poisoning the captured step's free pool memory between replays). */
-int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream);
-/* tool aid: *out (uint64, device) = the device wall clock (100 MHz ticks) when a one-thread kernel reaches the head of `stream` */
-int tsasr_debug_stamp(void *out, void *stream);
 int tsasr_count_nonfinite(const float *x, int n, int *counter, void *stream);
 
 /* Direct RCCL gradient all-reduce over xGMI (csrc/comm.hip): replaces the NCCL calls behind the reference's per-module
@@ -481,6 +482,44 @@ int tsasr_resample_fwd(const float *x, float *y, const float *weights, const int
 size_t tsasr_colsum_workspace_bytes(long long M, int N);
 int tsasr_colsum(const void *x, float *out, long long M, int N, int accumulate, int io_dtype, void *workspace, size_t workspace_bytes,
                  void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention in EXACT fp32 arithmetic (csrc/attention_f32.hip; no matrix cores, no bf16 rounding of operands): the `compute_dtype: fp32`
+ * parity mode of RelPosMHAXL (same reference lines as tsasr_relpos_attn_*: SB/nnet/attention.py:586-633, rel_shift :468-483) and, with
+ * pk == NULL and Tq != Tk, the core of torch.nn.MultiheadAttention for the `cross_attention` speaker injection (models/conformer.py:263-266).
+ * q / k / v are strided views: strides[9] (HOST, in elements) = {q batch, q row, q head, k batch, k row, k head, v batch, v row, v head}
+ * (RelPosMHAXL's interleaved qkv [B,T,H,3*Dh]: {T*3D, 3D, 3Dh} with k = qkv + Dh, v = qkv + 2*Dh). pk [2*Tk-1, H*Dh] or NULL,
+ * bias_u / bias_v fp32 [H*Dh] or NULL; key_lens int32 [B] or NULL; causal as tsasr_relpos_attn_fwd (C > 1: block-causal extension).
+ * out [B,Tq,H*Dh] (io_dtype), lse fp32 [B,H,Tq]. Dropout bit of element ((b*H+h)*Tq+i)*Tk+j from (seed + *seed_dev). Dh <= 64.
+ * Backward: dq / dk / dv through dstrides[9] (same meaning), dpk [2*Tk-1, H*Dh] when pk != NULL, d_bias_u / d_bias_v fp32 [H*Dh] or NULL
+ * (queued while tsasr_reduce_defer(1) is in force, like every parameter-gradient output). Three deterministic passes, no atomics;
+ * the workspace holds two fp32 [B,H,Tq,Tk] planes.
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_attn_f32_fwd(const void *q, const void *k, const void *v, const long long *strides, const void *pk, const float *bias_u,
+                       const float *bias_v, const int32_t *key_lens, void *out, float *lse, int B, int Tq, int Tk, int H, int Dh, float scale,
+                       int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, int io_dtype, void *stream);
+size_t tsasr_attn_f32_bwd_workspace_bytes(int B, int Tq, int Tk, int H, int Dh);
+int tsasr_attn_f32_bwd(const void *q, const void *k, const void *v, const long long *strides, const void *pk, const float *bias_u,
+                       const float *bias_v, const int32_t *key_lens, const void *out, const void *dout, const float *lse, void *dq, void *dk,
+                       void *dv, const long long *dstrides, void *dpk, float *d_bias_u, float *d_bias_v, int B, int Tq, int Tk, int H, int Dh,
+                       float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, int io_dtype,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LibriSpeechMix mixture on the device (csrc/dataio.hip): the arithmetic of the reference's `audio_pipeline`
+ * (train_librispeechmix_scratch.py:356-386), which the reference runs per utterance in DataLoader workers on the host.
+ * src = the utterance's sources back to back (fp32, device); host_off [nsrc+1] (HOST) their element offsets; host_delay [nsrc] (HOST)
+ * ceil(delay_j * sample_rate) in samples; rescale != 0 (gain_nontarget != 0): every non-target source is multiplied by
+ * sqrt(ratio * mean(target^2) / mean(src_j^2)), ratio = (float)10^(gain_nontarget/10), each operation in fp32 as the reference's 0-dim
+ * tensor expression (:361-369; the mean powers are fp64 sums rounded once - the reference's fp32 cascade sum depends on the host's SIMD
+ * width); sources are shifted right by their delay, zero-padded to the longest and summed LEFT TO RIGHT in fp32 (:372-377);
+ * out [tsasr_mix_sources_out_len(...)] = mixture[start : start + duration] (both in samples; clipped to the mixture as a Python slice).
+ * workspace: tsasr_mix_sources_workspace_bytes() (the mean powers), only read when rescale != 0. At most 8 sources.
+ * ------------------------------------------------------------------------------------------ */
+size_t tsasr_mix_sources_workspace_bytes(void);
+long long tsasr_mix_sources_out_len(const long long *host_off, const int *host_delay, int nsrc, long long start, long long duration);
+int tsasr_mix_sources(const float *src, const long long *host_off, const int *host_delay, int nsrc, int target, float ratio, int rescale,
+                      long long start, long long duration, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ def pytest_configure(config):
 # step (hipGraph replay, recipe loops, process groups, stress repeats) last - so that with `-x` one failure in the runtime cannot hide
 # the parity contract (round 2's verdict: 43 parity tests unreached behind one graph-replay failure).
 _ORDER = ["test_rnnt_oracle", "test_oracle_golden", "test_host_cpu", "test_rnnt_gpu", "test_blocks_gpu", "test_frontend_block_gpu",
-          "test_wgrad_gpu", "test_variants_gpu", "test_longform_gpu", "test_model_gpu", "test_hygiene_gpu", "test_recipe_gpu",
+          "test_wgrad_gpu", "test_dataio_gpu", "test_variants_gpu", "test_longform_gpu", "test_model_gpu", "test_hygiene_gpu", "test_recipe_gpu",
           "test_dist_gpu", "test_determinism_gpu"]
 _RUNTIME_WORDS = ("hip_graph", "graph_", "determinis", "stress", "replay")
 

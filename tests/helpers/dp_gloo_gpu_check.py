@@ -4,9 +4,9 @@ two ranks on one device): every rank runs the HIP path on its half of the config
 buckets, and after three SGD steps (no clipping: the weight change IS the averaged gradient times the step size) all ranks must hold the same weights,
 equal - to rounding - to ONE process training on the whole batch. `--graph`: the same with the step captured into a hipGraph (gloo
 collectives cannot be captured: they run between the replay and the optimizer). Checks bucketing, averaging, parameter broadcast and stream joins of
-dp.GradArena with device tensors; it does NOT exercise RCCL or xGMI. usage: python tools/dp_gloo_gpu_check.py            (parent)"""
+dp.GradArena with device tensors; it does NOT exercise RCCL or xGMI. usage: python tests/helpers/dp_gloo_gpu_check.py            (parent)"""
 import functools, importlib, os, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 STEPS, LR = 3, 3e-4
@@ -20,9 +20,12 @@ def train(rank, world, out):
     dp = importlib.import_module(entry.PKG + ".dp")
     bm = importlib.import_module(entry.PKG + ".batch")
     from oracle.golden_recipe import CFG1, golden_inputs, load_det_weights
-    run_opts = {"device": "cuda:0", "compute_dtype": "bf16"}
+    rccl = os.environ.get("TSASR_DP_CHECK_RCCL") == "1"      # >= 2 GPUs: one rank per GPU, RCCL ("nccl") over xGMI, direct communicator
+    dev = f"cuda:{rank}" if (rccl and world > 1) else "cuda:0"
+    torch.cuda.set_device(dev)
+    run_opts = {"device": dev, "compute_dtype": "bf16"}
     if world > 1:
-        run_opts.update(distributed_launch=True, distributed_backend="gloo")
+        run_opts.update(distributed_launch=True, distributed_backend="nccl" if rccl else "gloo")
         dp.ddp_init_group(run_opts)
     c = CFG1
     ov = dict(d_model=c["d_model"], nhead=c["nhead"], encoder_num_layers=c["encoder_num_layers"], speaker_num_layers=c["speaker_num_layers"],
@@ -46,7 +49,7 @@ def train(rank, world, out):
         "id": [str(int(i)) for i in idx],
         "mixed_sig": bm.PaddedData(T("mixed_sig"), T("mixed_lens")), "enroll_sig": bm.PaddedData(T("enroll_sig"), T("enroll_lens")),
         "tokens_bos": bm.PaddedData(T("tokens_bos"), T("tokens_bos_lens")), "tokens": bm.PaddedData(T("tokens"), T("tokens_lens")),
-    }).to("cuda:0")
+    }).to(dev)
     brain.modules.train()
     steps = STEPS
     if os.environ.get("TSASR_DP_CHECK_ACCUM"):           # gradient accumulation: no_sync micro-steps, collectives on the stepping one only
@@ -58,7 +61,8 @@ def train(rank, world, out):
     losses = [float(brain.fit_batch(batch)) for _ in range(steps)]
     torch.cuda.synchronize()
     sd = {f"{n}.{k}": v.detach().float().cpu() for n, m in brain.modules.items() if isinstance(m, torch.nn.Module) for k, v in m.state_dict().items()}
-    torch.save({"sd": sd, "losses": losses, "buckets": len(brain.arena.buckets), "sent": len(brain.arena.sent_log)}, out)
+    torch.save({"sd": sd, "losses": losses, "buckets": len(brain.arena.buckets), "sent": len(brain.arena.sent_log),
+                "direct_ranks": int(dp._DIRECT["ranks"]), "graph_comm": bool(brain._graph_comm()) if brain._graph is not None else False}, out)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -76,9 +80,12 @@ if __name__ == "__main__":
         os.environ["TSASR_DP_CHECK_ACCUM"] = "2"
     if "--bf16-payload" in sys.argv:
         os.environ["TSASR_ALLREDUCE_DTYPE"] = "bf16"
+    rccl = "--rccl" in sys.argv          # two GPUs, one rank each, bucket all-reduces through the direct RCCL communicator (csrc/comm.hip)
+    if rccl:
+        os.environ["TSASR_DP_CHECK_RCCL"] = "1"
     d = tempfile.mkdtemp()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), WORLD_SIZE="2",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", TSASR_RCCL_DIRECT="0", TSASR_BUCKET_MB="4")   # 24 MB of gradients -> several buckets
+               HSA_ENABLE_IPC_MODE_LEGACY="0", TSASR_RCCL_DIRECT="1" if rccl else "0", TSASR_BUCKET_MB="4")   # 24 MB of gradients -> several buckets
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), "2", os.path.join(d, f"r{r}.pt")],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
@@ -104,4 +111,10 @@ if __name__ == "__main__":
     assert r0["buckets"] >= 3
     if os.environ.get("TSASR_DP_CHECK_GRAPH") != "1":
         assert r0["sent"] == r0["buckets"]      # (captured step over gloo: one all-reduce of the whole arena after the replay instead)
-    print("two-rank data parallel on one GPU (gloo) OK")
+    if rccl:
+        assert r0["direct_ranks"] == 2 and r1["direct_ranks"] == 2, (r0["direct_ranks"], r1["direct_ranks"])
+        if os.environ.get("TSASR_DP_CHECK_GRAPH") == "1":
+            assert r0["graph_comm"] and r1["graph_comm"], "the captured step does not carry its RCCL collectives"
+        print("two-rank data parallel on two GPUs (direct RCCL) OK")
+    else:
+        print("two-rank data parallel on one GPU (gloo) OK")

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Does any kernel's result depend on uninitialised memory? Every torch.empty / empty_like on the GPU is filled with NaN (0xFF bytes
 for integer workspaces) before use, then the eager training step (configs[0] model, ragged batch) must give bit-identical losses and
-gradients to the unpoisoned run. usage: python tools/poison_empty.py [accum]"""
+gradients to the unpoisoned run. usage: python tests/helpers/poison_empty.py [accum]"""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import torch
 entry = importlib.import_module("__graft_entry__")
 from oracle.golden_recipe import golden_inputs

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Exercise the multi-rank code path with REAL RCCL on one GPU: a one-rank communicator made through the C-ABI (csrc/comm.hip; RCCL
-refuses two ranks on one device, so tools/ddp_rehearsal.sh uses gloo), the gradient arena told there are two ranks so that every
+refuses two ranks on one device, so the two-rank rehearsal on one GPU uses gloo), the gradient arena told there are two ranks so that every
 collective of the step is issued: bucketed all-reduces from the gradient hooks / the grouped weight-gradient flushes in the eager warm-up, then the SAME
 collectives captured inside the step's hipGraph (RCCL kernels as graph nodes on the communication stream, joined before the fused
 optimizer) and replayed; last run: the form a failed capture probe falls back to (dp.direct_capture_probe: nothing captured, one
@@ -9,7 +9,7 @@ the parameter-gradient reductions run per bucket instead of batched). Third run:
 N > 1 ranks are NOT validated by this (no multi-GPU box in the development loop): it proves capture + replay of real RCCL nodes."""
 import importlib
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29544"), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
 import numpy as np
 import torch

@@ -26,6 +26,14 @@ def ops():
     return importlib.import_module("ts-asr_amd.ops")
 
 
+@pytest.fixture
+def mfma_fp32(monkeypatch):
+    """fp32 STORAGE through the MFMA kernels (operands rounded to bf16 inside): what fp32 tensors reached before the exact-fp32 attention /
+    joint kernels became the fp32 path (ops.ATTN_F32_EXACT, rnnt.JOINT_F32_EXACT); these instantiations stay covered."""
+    monkeypatch.setattr(importlib.import_module("ts-asr_amd.ops"), "ATTN_F32_EXACT", False)
+    monkeypatch.setattr(importlib.import_module("ts-asr_amd.rnnt"), "JOINT_F32_EXACT", False)
+
+
 def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
@@ -283,7 +291,7 @@ def test_relpos_mha_vs_reference(nn_, golden, tag, use_lens, causal):
 
 
 @pytest.mark.parametrize("tag,use_lens,causal", [("mha_nomask", False, False), ("mha_kpm", True, False), ("mha_kpm_causal", True, True)])
-def test_fused_attention_kernel_vs_reference(nn_, golden, tag, use_lens, causal):
+def test_fused_attention_kernel_vs_reference(nn_, golden, tag, use_lens, causal, mfma_fp32):
     """return_attn_weights=False routes through the fused HIP kernel (Dh = 36 here: padded head dim path)."""
     g, x, lens, probe = block_inputs(golden)
     m = load_det_weights(nn_.RelPosMHAXL(144, 4, dropout=0.0, mask_pos_future=causal), "blk.mha.").to(DEV)
@@ -301,7 +309,7 @@ def test_fused_attention_kernel_vs_reference(nn_, golden, tag, use_lens, causal)
 @pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 125, 4, 64), (1, 333, 2, 64), (2, 40, 4, 36)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
-def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
+def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal, mfma_fp32):
     """HIP kernel vs the fp32 formula (oracle/tsasr_ref.relpos_mha's core) on bf16-rounded operands."""
     D = H * Dh
     g = torch.Generator().manual_seed(Tn + Dh)
@@ -332,7 +340,7 @@ def test_fused_attention_full_width(ops, B, Tn, H, Dh, dtype, causal):
 @pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 70, 4, 36), (1, 200, 2, 64), (1, 1100, 2, 36), (2, 1500, 1, 64)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
-def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
+def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal, mfma_fp32):
     """HIP backward (dQ/dK/dV, d pos_bias_u/v, d pk) vs autograd through the ORACLE's attention (oracle/tsasr_ref.py relpos_core, the
     function the reference-generated golden vectors pin through relpos_mha) - not through product code. The two T > 1000 shapes take
     the long-sequence paths: keys split over workgroups in the forward and in the query-major backward (fp32 dQ shares + merge), query
@@ -356,6 +364,88 @@ def test_fused_attention_backward_full_width(ops, B, Tn, H, Dh, dtype, causal):
     for a, r_, name in zip(dev, leaf, ("dqkv", "dpk", "du", "dv")):
         rel = float((a.grad.float().cpu() - r_.grad).norm() / r_.grad.norm())
         assert rel < (1.5e-2 if dtype == torch.float32 else 2.5e-2), (name, rel)   # bf16 MFMA operands incl. P and dS
+
+
+@pytest.mark.parametrize("B,Tn,H,Dh", [(3, 250, 4, 64), (2, 70, 4, 36), (1, 333, 2, 64), (2, 40, 1, 8)])
+@pytest.mark.parametrize("causal", [0, 1, 16])
+def test_attention_exact_fp32_vs_oracle(ops, B, Tn, H, Dh, causal):
+    """The fp32 parity path (csrc/attention_f32.hip: no matrix cores, no operand rounding) against autograd through the ORACLE's
+    attention (oracle/tsasr_ref.relpos_core, pinned by the reference-generated golden vectors) on UN-rounded fp32 inputs: output and
+    every gradient (dqkv, d pk, d pos_bias_u / v) to 2e-5 relative L2 - three orders tighter than the bf16-operand kernels allow. Ragged
+    key lengths, look-ahead mask, the block-causal extension (C = 16), a padded head dim (36) and a tiny one (8)."""
+    D = H * Dh
+    g = torch.Generator().manual_seed(Tn * 5 + Dh + causal)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g)
+    pk = torch.randn(2 * Tn - 1, D, generator=g)
+    u, v = torch.randn(Dh, H, generator=g) * 0.3, torch.randn(Dh, H, generator=g) * 0.3
+    dout = torch.randn(B, Tn, D, generator=g)
+    lens = torch.tensor([Tn, max(1, Tn // 2), max(1, Tn - 7)][:B], dtype=torch.int32)
+    scale = 1.0 / D ** 0.5
+    leaf = [t.double().clone().requires_grad_() for t in (qkv, pk, u, v)]
+    R = importlib.import_module("oracle.tsasr_ref")
+    pad = torch.arange(Tn)[None, :] >= lens[:, None].long()
+    ref, _ = R.relpos_core(leaf[0], leaf[1], leaf[2], leaf[3], H, scale, pad, causal)
+    ref.backward(dout.double())
+    dev = [t.to(DEV).requires_grad_() for t in (qkv, pk, u, v)]
+    assert ops.ATTN_F32_EXACT
+    out, _ = ops.relpos_attention(dev[0], dev[1], dev[2], dev[3], lens.to(DEV), H, scale, causal, 0.0, False)
+    out.backward(dout.to(DEV))
+    rel = float((out.detach().double().cpu() - ref.detach()).norm() / ref.detach().norm())
+    assert rel < 2e-6, ("out", rel)
+    for a, r_, name in zip(dev, leaf, ("dqkv", "dpk", "du", "dv")):
+        rel = float((a.grad.double().cpu() - r_.grad).norm() / r_.grad.norm())
+        assert rel < 2e-5, (name, rel)
+
+
+def test_attention_exact_fp32_dropout_and_cross_shapes(ops):
+    """(1) dropout: the backward regenerates the forward's mask - out is linear in V for a fixed mask, so <dout, out(V + dV) - out(V)> must
+    equal <grad_V, dV>; the kept fraction is 1 - p to sampling error. (2) cross-attention shapes (Tq != Tk, no positions, separate q and
+    kv tensors: the `cross_attention` speaker injection, models/conformer.py:263-266) against torch's formula in float64, values and
+    gradients, with ragged key lengths."""
+    B, Tn, H, Dh = 2, 96, 2, 64
+    D = H * Dh
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(DEV)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(DEV)
+    u, v = (torch.randn(Dh, H, generator=g) * 0.3).to(DEV), (torch.randn(Dh, H, generator=g) * 0.3).to(DEV)
+    dout = torch.randn(B, Tn, D, generator=g).to(DEV)
+
+    def run(x, seed):
+        Bx, Tx, D3 = x.shape
+        view = lambda off: x.as_strided((Bx, Tx, D), (Tx * D3, D3, 1), x.storage_offset() + off)   # noqa: E731
+        return ops._AttnF32Fn.apply(view(0), view(Dh), view(2 * Dh), pk, u, v, None, H, 1.0 / D ** 0.5, 0, 0.3, seed, 3 * Dh, 3 * Dh, 3 * Dh)
+    x = qkv.clone().requires_grad_()
+    out = run(x, 1234)
+    out.backward(dout)
+    dV = torch.zeros_like(qkv)
+    dV.view(B, Tn, H, 3 * Dh)[..., 2 * Dh:] = torch.randn(B, Tn, H, Dh, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out2 = run(qkv + dV, 1234)
+    lhs = float(((out2 - out.detach()).double() * dout.double()).sum())
+    rhs = float((x.grad.double() * dV.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    ones = torch.zeros_like(qkv)
+    ones.view(B, Tn, H, 3 * Dh)[..., 2 * Dh:] = 1.0           # V = 1: out = sum of the dropped probabilities = kept fraction / (1 - p) on average
+    kept = float(run(ones, 77).mean())
+    assert abs(kept - 1.0) < 0.05, kept
+    # cross-attention
+    Tq, Tk = 50, 31
+    q = torch.randn(B, Tq, D, generator=g)
+    kv = torch.randn(B, Tk, 2 * D, generator=g)
+    do = torch.randn(B, Tq, D, generator=g)
+    lens = torch.tensor([Tk, 17], dtype=torch.int32)
+    qd, kvd = q.double().requires_grad_(), kv.double().requires_grad_()
+    qh = qd.view(B, Tq, H, Dh).transpose(1, 2)
+    kh, vh = kvd[..., :D].view(B, Tk, H, Dh).transpose(1, 2), kvd[..., D:].view(B, Tk, H, Dh).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2) / Dh ** 0.5
+    sc = sc.masked_fill((torch.arange(Tk)[None, :] >= lens[:, None].long()).view(B, 1, 1, Tk), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, Tq, D)
+    ref.backward(do.double())
+    qg, kvg = q.to(DEV).requires_grad_(), kv.to(DEV).requires_grad_()
+    o = ops.attention_f32(qg, kvg[..., :D], kvg[..., D:], H, 1.0 / Dh ** 0.5, lens.to(DEV), False, 0.0)
+    o.backward(do.to(DEV))
+    for got, want, name in ((o, ref, "out"), (qg.grad, qd.grad, "dq"), (kvg.grad, kvd.grad, "dkv")):
+        rel = float((got.detach().double().cpu() - want.detach()).norm() / want.detach().norm())
+        assert rel < 2e-5, (name, rel)
 
 
 def test_fused_attention_dropout_consistency(ops):
@@ -507,6 +597,43 @@ def test_linear_fn_grad_sink(ops):
         ref_dw = dy.float().reshape(-1, 512).t() @ x.detach().float().reshape(-1, 256)
         close(lin.weight.grad, ref_dw, 2e-2, 1e-3)
         assert lin.weight.grad.data_ptr() == arena.grads[arena.offset[id(lin.weight)]:].data_ptr()
+    finally:
+        ops.set_grad_sink(None)
+
+
+@pytest.mark.parametrize("collect", [True, False])
+def test_linear_cols_weight_gradient_lands_in_its_columns(ops, collect):
+    """The `cat` injection's projection as two column ranges of ONE weight (models/conformer.py:254-262): both halves' weight gradients
+    go into their own columns of the weight's arena slot - through the grouped launch (collect_wgrads on) and through the split-K GEMM
+    fallback, whose output is a strided view (row stride 2D, not D) - against the fp32 product of the same bf16 operands."""
+    dp = importlib.import_module("ts-asr_amd.dp")
+    D = 256
+    lin = torch.nn.Linear(2 * D, D, bias=True).to(DEV)
+    guard = torch.nn.Linear(D, 8, bias=False).to(DEV)          # the arena slot right behind the weight: must stay untouched
+    mods = torch.nn.ModuleDict({"l": lin, "g": guard})
+    arena = dp.GradArena(mods)
+    arena.collect_wgrads = collect
+    ops.set_grad_sink(arena)
+    try:
+        g = torch.Generator().manual_seed(11)
+        src = torch.randn(4, 50, D, generator=g).to(DEV).to(torch.bfloat16).requires_grad_()
+        spk = torch.randn(4, 1, D, generator=g).to(DEV).to(torch.bfloat16).requires_grad_()
+        assert ops.linear_cols_ok(src, lin.weight, 0, D) and ops.linear_cols_ok(spk, lin.weight, D, D)
+        arena.begin_backward(False)
+        y = ops.linear_cols(src, lin.weight, None, 0, D) + ops.linear_cols(spk, lin.weight, lin.bias, D, D)
+        dy = torch.randn(y.shape, generator=g).to(DEV).to(torch.bfloat16)
+        y.backward(dy)
+        arena.finish_backward()
+        torch.cuda.synchronize()
+        w16 = lin.weight.detach().to(torch.bfloat16).float()
+        ref = src.detach().float() @ w16[:, :D].t() + spk.detach().float() @ w16[:, D:].t() + lin.bias.detach().float()
+        close(y, ref, 6e-2, 2e-2)
+        dyf = dy.float()
+        ref_dw = torch.cat([dyf.reshape(-1, D).t() @ src.detach().float().reshape(-1, D),
+                            dy.sum(1).float().t() @ spk.detach().float().reshape(-1, D)], dim=1)   # autograd's broadcast sum is rounded to bf16 once
+        close(lin.weight.grad, ref_dw, 2e-2, 2e-3)
+        assert float(guard.weight.grad.abs().max()) == 0.0
+        close(src.grad, dyf @ w16[:, :D], 6e-2, 2e-2)
     finally:
         ops.set_grad_sink(None)
 

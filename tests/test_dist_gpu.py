@@ -1,5 +1,5 @@
 """Multi-rank machinery on the one-GPU box. Real RCCL: a one-rank "nccl" group with the arena told there are two ranks, so that the
-bucketed all-reduces are issued during backward, CAPTURED into the step's hipGraph and replayed (tools/rccl_single_rank_check.py, run
+bucketed all-reduces are issued during backward, CAPTURED into the step's hipGraph and replayed (tests/helpers/rccl_single_rank_check.py, run
 as a child process: a process group per run, never a re-exec of a process that touched the GPU). N > 1 is covered by the gloo tests
 of tests/test_host_cpu.py and stays unmeasured on hardware until a multi-GPU node runs bench.py --gpus N."""
 import importlib
@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 def test_rccl_collectives_captured_in_graph_and_replayed():
     env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py")], env=env, capture_output=True, text=True, timeout=420)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_single_rank_check.py")], env=env, capture_output=True, text=True, timeout=420)
     sys.stdout.write(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "RCCL single-rank path OK" in r.stdout
@@ -27,16 +27,52 @@ def test_rccl_collectives_captured_in_graph_and_replayed():
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_two_ranks_on_one_gpu_over_gloo_equal_single_process(graph):
-    """Data parallel with device tensors: two ranks share the GPU, gloo carries the bucket all-reduces (tools/dp_gloo_gpu_check.py):
+    """Data parallel with device tensors: two ranks share the GPU, gloo carries the bucket all-reduces (tests/helpers/dp_gloo_gpu_check.py):
     ranks end with identical weights, equal to one process on the whole batch up to bf16 rounding - eagerly (bucket collectives from the
     gradient hooks, overlapped with backward) and with the step captured (one all-reduce between replay and optimizer: gloo cannot be
     captured). RCCL / xGMI are not exercised."""
     env = dict(os.environ, MASTER_PORT=str(29900 + os.getpid() % 90 + (7 if graph else 0)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_gloo_gpu_check.py")] + (["--graph"] if graph else []), env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "dp_gloo_gpu_check.py")] + (["--graph"] if graph else []), env=env,
                        capture_output=True, text=True, timeout=900)
     sys.stdout.write(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "two-rank data parallel on one GPU (gloo) OK" in r.stdout
+
+
+# ---- N > 1 on real hardware: these arm themselves the day the box has two GPUs (none has had so far: SCALE_r01-r03 were skipped) --------
+_TWO_GPUS = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible MI355X (one rank per GPU over RCCL / xGMI)")
+
+
+@_TWO_GPUS
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_gpus_direct_rccl_equal_single_process(graph):
+    """One rank per GPU, bucket all-reduces through the direct RCCL communicator (csrc/comm.hip; replaces the reference's per-module
+    DDP reducers, SB/core.py:1464-1484, SB/utils/distributed.py:123-201): ranks end bit-identical, equal to ONE process on the whole batch
+    to bf16 rounding - eagerly (collectives from the gradient hooks, overlapped with backward) and with the step captured into a
+    hipGraph that CARRIES the bucket collectives (graph_comm on both ranks)."""
+    env = dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 90 + (11 if graph else 0)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "dp_gloo_gpu_check.py"), "--rccl"] + (["--graph"] if graph else []),
+                       env=env, capture_output=True, text=True, timeout=900)
+    sys.stdout.write(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "two-rank data parallel on two GPUs (direct RCCL) OK" in r.stdout
+
+
+@_TWO_GPUS
+def test_bench_gpus2_reports_direct_rccl_in_the_graph():
+    """`python bench.py --gpus 2` (it spawns its own ranks): the JSON line must say the gradient path ran on a 2-rank direct RCCL
+    communicator with the collectives inside the captured step - not a gloo rehearsal, not an all-reduce outside the graph."""
+    import json
+    env = dict(os.environ, MASTER_PORT=str(29800 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TSASR_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "4", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64
+    comm = line["comm"]
+    assert comm["backend"] == "nccl" and comm["rccl_direct_ranks"] == 2 and comm["collectives_in_graph"] and not comm["rehearsal_on_one_gpu"], comm
+    assert comm["allreduce_busbw_GBps"] > 0
 
 
 def test_speed_perturbation_varies_under_hip_graph():

@@ -11,19 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(tool, *args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", tool), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
     sys.stdout.write(r.stdout[-1500:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
 
 def test_training_step_does_not_depend_on_uninitialised_memory():
-    """tools/poison_empty.py: every torch.empty / empty_like on the GPU is filled with NaN (0xFF for byte workspaces) - six eager steps of
+    """tests/helpers/poison_empty.py: every torch.empty / empty_like on the GPU is filled with NaN (0xFF for byte workspaces) - six eager steps of
     the configs[0] model on the ragged golden batch (gradient accumulation 2) give bit-identical losses and parameter gradients."""
     assert "OK: nothing reads uninitialised memory" in _run("poison_empty.py", "2")
 
 
 def test_training_step_does_not_depend_on_leftover_lds():
-    """tools/lds_garbage.py: all LDS of every CU is overwritten (NaN bits, 3.4e38, ones) before every C-ABI launch - losses and gradients
+    """tests/helpers/lds_garbage.py: all LDS of every CU is overwritten (NaN bits, 3.4e38, ones) before every C-ABI launch - losses and gradients
     stay bit-identical."""
     assert "OK: no kernel depends on leftover LDS contents" in _run("lds_garbage.py", "2")

@@ -18,6 +18,12 @@ def rn():
     return importlib.import_module("ts-asr_amd.rnnt")
 
 
+@pytest.fixture
+def mfma_fp32(monkeypatch):
+    """fp32 STORAGE through the MFMA joint kernels (h, W, dlogits rounded to bf16 inside) - the fp32 path proper is csrc/joint_f32.hip."""
+    monkeypatch.setattr(importlib.import_module("ts-asr_amd.rnnt"), "JOINT_F32_EXACT", False)
+
+
 def bf(x):
     return x.to(torch.bfloat16).float()
 
@@ -43,7 +49,7 @@ def make(B, T, U1, J, V, seed, dtype=torch.float32):
 
 @pytest.mark.parametrize("B,T,U1,J,V", [(4, 50, 21, 160, 29), (2, 7, 33, 64, 5), (1, 1, 1, 32, 32), (3, 130, 70, 640, 29)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_joint_forward(rn, B, T, U1, J, V, dtype):
+def test_joint_forward(rn, B, T, U1, J, V, dtype, mfma_fp32):
     enc, dec, W, b, _ = make(B, T, U1, J, V, 1, dtype)
     out = rn.fused_joint_logits(enc.to(DEV, dtype), dec.to(DEV, dtype), W.to(DEV), b.to(DEV))
     assert out.shape == (B, T, U1, V) and out.stride(-2) == 32
@@ -120,7 +126,7 @@ def test_loss_rejects_bad_arguments(rn):
                                                    (2, 19, 40, 64, 9, [19, 8], [39, 3]),
                                                    (2, 70, 121, 640, 29, [70, 66], [120, 77])])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_joint_loss_backward_chain(rn, B, T, U1, J, V, tlen, ulen, dtype):
+def test_joint_loss_backward_chain(rn, B, T, U1, J, V, tlen, ulen, dtype, mfma_fp32):
     """enc/dec/head gradients of mean RNN-T loss through the fused joint: HIP vs oracle (autograd through the
     bf16-operand-emulating joint + C oracle loss)."""
     enc, dec, W, b, tg = make(B, T, U1, J, V, 3, dtype)
@@ -152,6 +158,35 @@ def test_joint_loss_backward_chain(rn, B, T, U1, J, V, tlen, ulen, dtype):
     for a, r in ((eg.grad, eo.grad), (dg.grad, do_.grad), (Wg.grad, Wo.grad)):
         rel = (a.float().cpu() - r).norm() / r.norm()
         assert rel < (6e-3 if dtype == torch.float32 else 1.2e-2), rel
+
+
+@pytest.mark.parametrize("B,T,U1,J,V,tlen,ulen", [(4, 50, 21, 160, 29, [50, 45, 40, 35], [20, 18, 15, 10]),
+                                                   (2, 19, 40, 64, 9, [19, 8], [39, 3]),
+                                                   (2, 70, 121, 640, 29, [70, 66], [120, 77]),
+                                                   (1, 3, 5, 36, 32, [3], [4])])
+def test_joint_exact_fp32_chain(rn, B, T, U1, J, V, tlen, ulen):
+    """The fp32 parity path (csrc/joint_f32.hip: no matrix cores, nothing rounded to bf16): logits against the UN-rounded oracle
+    (oracle/tsasr_ref.joint_logits) to 1e-5, and enc / dec / head gradients of the mean RNN-T loss against autograd through that oracle +
+    the C oracle loss to 5e-5 relative L2 (the MFMA kernels with fp32 storage are held to 6e-3 above)."""
+    assert rn.JOINT_F32_EXACT
+    enc, dec, W, b, tg = make(B, T, U1, J, V, 4, torch.float32)
+    eo, do_, Wo, bo = (t.clone().requires_grad_() for t in (enc, dec, W, b))
+    logits_o = R.joint_logits(eo, do_, {"w.weight": Wo, "w.bias": bo}, "")
+    tl_t, ul_t = torch.tensor(tlen, dtype=torch.int32), torch.tensor(ulen, dtype=torch.int32)
+    loss_o = RR.RnntLossRefFn.apply(logits_o, tg, tl_t, ul_t, 0).mean()
+    loss_o.backward()
+    eg, dg = enc.to(DEV).requires_grad_(), dec.to(DEV).requires_grad_()
+    Wg, bg = W.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    logits = rn.fused_joint_logits(eg, dg, Wg, bg, 0.01, tl_t.to(DEV), ul_t.to(DEV))
+    torch.testing.assert_close(logits.detach().cpu(), logits_o.detach(), atol=1e-5, rtol=1e-5)
+    full = logits.as_strided((B, T, U1, 32), (T * U1 * 32, U1 * 32, 32, 1))
+    assert torch.all(full[..., V:] == 0)
+    loss = rn.rnnt_costs(logits, tg.to(DEV), tl_t.to(DEV), ul_t.to(DEV), 0).mean()
+    loss.backward()
+    assert loss.item() == pytest.approx(loss_o.item(), rel=2e-6)
+    for a, r, name in ((eg.grad, eo.grad, "denc"), (dg.grad, do_.grad, "ddec"), (Wg.grad, Wo.grad, "dW"), (bg.grad, bo.grad, "dbias")):
+        rel = float((a.float().cpu() - r).norm() / r.norm())
+        assert rel < 5e-5, (name, rel)     # fp32 sums over T * U1 lattice cells (measured 2.7e-5 on denc)
 
 
 def test_full_size_properties(rn):

@@ -86,7 +86,7 @@ def poison_pool():
         for b in seg["blocks"]:
             a = b.get("address", addr)
             if b["state"] == "inactive" and b["size"] >= 4:
-                capi.check(capi.lib().tsasr_debug_fill(ctypes.c_void_p(a), 0x7FC07FC0, b["size"] // 4, capi.stream_ptr()), "tsasr_debug_fill")
+                assert capi.lab().tsasr_lab_fill(ctypes.c_void_p(a), 0x7FC07FC0, b["size"] // 4, capi.stream_ptr()) == 0
                 n += b["size"]
             addr += b["size"]
     return n

@@ -12,7 +12,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python
 cd $R
 db=$(find $O/prof -name "*.db" | head -1)
 python tools/trace_summary.py $db --steps 17 --top 80 > $O/trace_summary.txt
-python tools/stream_timeline.py $db > $O/timeline.txt 2>&1 || true
+python tools/stream_timeline.py $db --names > $O/timeline.txt 2>&1 || true
 rm -rf $O/prof
 echo "trace done"
 cd /tmp

@@ -13,6 +13,9 @@ dump = None
 if "--dump" in argv:   # --dump t0_ms t1_ms: every kernel of the step starting in that window (start, duration, gap to the previous kernel of its queue)
     i = argv.index("--dump"); dump = (float(argv[i + 1]), float(argv[i + 2])); del argv[i:i + 3]
     sys.argv = [sys.argv[0]] + argv
+names = "--names" in argv
+if names:
+    argv.remove("--names"); sys.argv = [sys.argv[0]] + argv
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
 starts = [i for i, r in enumerate(rows) if "seed_advance" in r[0]]
@@ -44,7 +47,7 @@ if grep:
     for n, s, e, q in hits:
         others = [short(n2) for n2, s2, e2, q2 in step if q2 != q and s2 < e and e2 > s]
         print("    %7.3f-%7.3f ms q%d %-40s beside %d kernels of other queues%s" % ((s - t0) / 1e6, (e - t0) / 1e6, q, short(n), len(others), (": " + ", ".join(sorted(set(others))[:3])) if others else ""))
-if "--names" in sys.argv or dump:   # launches and summed duration per kernel name in this one step
+if names or dump:   # launches and summed duration per kernel name in this one step
     cnt = collections.defaultdict(lambda: [0, 0.0])
     for n, s_, e, q in step:
         c = cnt[short(n)]; c[0] += 1; c[1] += (e - s_) / 1e3

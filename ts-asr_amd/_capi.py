@@ -32,6 +32,9 @@ _PROTOS = {
     "tsasr_version": (c_int, []),
     "tsasr_device_ok": (c_int, []),
     "tsasr_joint_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_float, c_void_p]),
+    "tsasr_joint_f32_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
+    "tsasr_joint_f32_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_joint_f32_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float, c_void_p, c_size_t, c_void_p]),
     "tsasr_joint_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_joint_bwd": (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "tsasr_rnnt_loss_workspace_bytes": (c_size_t, [c_int] * 3),
@@ -83,6 +86,7 @@ _PROTOS = {
     "tsasr_clip_adamw_step": (c_int, [c_void_p] * 8 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_gemm_set_plan": (None, [c_int, c_int]),
     "tsasr_gemm_set_ring": (None, [c_int]),
+    "tsasr_gemm_set_nn128": (None, [c_int, c_int, c_int]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_gemm_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p]),
     "tsasr_gemm_bf16_nt_batched": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 4 + [c_int, c_void_p]),
@@ -118,13 +122,9 @@ _PROTOS = {
     "tsasr_mean_pool_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "tsasr_mean_pool_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "tsasr_abs_lengths": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "tsasr_inject_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "tsasr_inject_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "tsasr_greedy_decode": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_float, c_int, c_int, c_void_p]),
-    "tsasr_debug_fill_lds": (c_int, [ctypes.c_uint, c_void_p]),
-    "tsasr_debug_lds_canary": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "tsasr_debug_barrier_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "tsasr_debug_vgpr_canary": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "tsasr_debug_fill": (c_int, [c_void_p, ctypes.c_uint, c_size_t, c_void_p]),
-    "tsasr_debug_stamp": (c_int, [c_void_p, c_void_p]),
     "tsasr_count_nonfinite": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "tsasr_allreduce_load": (c_int, [ctypes.c_char_p]),
     "tsasr_allreduce_unique_id": (c_int, [c_void_p]),
@@ -145,6 +145,12 @@ _PROTOS = {
     "tsasr_specaug_apply": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_resample_out_len": (c_ll, [c_ll, c_int, c_int]),
     "tsasr_resample_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "tsasr_attn_f32_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p]),
+    "tsasr_attn_f32_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
+    "tsasr_attn_f32_bwd": (c_int, [c_void_p] * 18 + [c_int] * 5 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "tsasr_mix_sources_workspace_bytes": (c_size_t, []),
+    "tsasr_mix_sources_out_len": (c_ll, [c_void_p, c_void_p, c_int, c_ll, c_ll]),
+    "tsasr_mix_sources": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_ll, c_ll, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 
@@ -167,6 +173,25 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_lab = None
+LAB_PATH = os.path.join(_HERE, "lib", "libtsasr_lab.so")
+
+
+def lab():
+    """Lab equipment (include/tsasr_lab.h: LDS / memory fills, wall-clock stamp) for tests/helpers, tools and prof's TSASR_STAMPS mode -
+    a separate library; the product path never loads it."""
+    global _lab
+    if _lab is None:
+        if not os.path.exists(LAB_PATH):
+            raise TsasrHipMissing(f"{LAB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}`")
+        L = ctypes.CDLL(LAB_PATH)
+        L.tsasr_lab_fill_lds.argtypes, L.tsasr_lab_fill_lds.restype = [ctypes.c_uint, c_void_p], c_int
+        L.tsasr_lab_fill.argtypes, L.tsasr_lab_fill.restype = [c_void_p, ctypes.c_uint, c_size_t, c_void_p], c_int
+        L.tsasr_lab_stamp.argtypes, L.tsasr_lab_stamp.restype = [c_void_p, c_void_p], c_int
+        _lab = L
+    return _lab
 
 
 def check(rc, what=""):

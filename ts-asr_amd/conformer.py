@@ -48,6 +48,10 @@ class _SpeakerAttention(nn.Module):
         w, b = self.att.in_proj_weight, self.att.in_proj_bias
         q = ops.linear(src, w[:D], b[:D]).view(B, T, H, D // H).transpose(1, 2)
         kv = ops.linear(_cd(spk), w[D:], b[D:]).view(B, S, 2, H, D // H)
+        if D // H <= 64:    # scores, softmax, dropout, .V in one HIP kernel each way (csrc/attention_f32.hip, exact fp32 arithmetic)
+            qf, kvf = q.transpose(1, 2).reshape(B, T, D), kv.view(B, S, 2 * D)
+            o = ops.attention_f32(qf, kvf[..., :D], kvf[..., D:], H, 1.0 / (D // H) ** 0.5, key_lens, False, self.dropout if self.training else 0.0)
+            return ops.linear(o, self.att.out_proj.weight, self.att.out_proj.bias)
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         s = torch.matmul(q, k.transpose(-1, -2)).float() / (D // H) ** 0.5
         if key_lens is not None:
@@ -161,10 +165,10 @@ class ConformerEncoder(nn.Module):
 
     def _inject_speaker_emb(self, src, spk, spk_len):
         spk = _cd(spk)
-        if self.injection_mode == "prod":
-            return src * spk
-        if self.injection_mode == "sum":
-            return src + spk
+        if self.injection_mode in ("prod", "sum"):
+            if ops.inject_ok(src, spk):
+                return ops.inject(src, spk, self.injection_mode)     # one HIP launch each way
+            return src * spk if self.injection_mode == "prod" else src + spk   # (shapes the kernel does not take: D % 8 != 0)
         if self.injection_mode == "cat":
             D = self.d_model
             w, b = self.cat_proj.w.weight, self.cat_proj.w.bias

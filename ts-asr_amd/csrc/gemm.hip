@@ -440,36 +440,87 @@ struct RingTile {
 };
 
 #define RING_STAGES 3
+#define RING_THREADS 512
+// WAVE SPECIALISATION (round 4): every ring kernel runs 8 waves - waves 0-3 compute (fragment reads + MFMA + the epilogue), waves 4-7 do
+// nothing but issue the LDS-DMA ring. A wave that issues a DMA into a full vector-memory queue sits in the issue stage until older
+// requests drain, and with one stream per wave the MFMAs behind that DMA in program order wait with it: lab floors of the 4-wave form at
+// 8000 x 256 x 2048 (tools/gemm_bench.py --nn128, profiles/r04_notes.md): DMA ring alone 11.4 us, fragment reads + MFMA alone 8.8 -
+// 10.9 us, together 16.1 - 17.4 us whatever the compute part costs; with loader waves 13.0 us (K = 768: 8.7 -> 6.9, K = 256: 5.5 -> 4.8).
+// Protocol per k-tile: loaders wait (counted vmcnt) until their pieces of tile kt have landed, ALL waves meet at one raw s_barrier (tile kt
+// visible to the compute waves, which are done with tile kt - 1), loaders issue tile kt + STAGES - 1 into the slot of tile kt - 1.
+// After the loop the loader waves end; s_barrier counts only waves that have not terminated, so the epilogue's barriers are among waves 0-3.
+__device__ __forceinline__ void ring_wait_landed(int younger_tiles, int lpt) {
+    // at most `younger_tiles` k-tiles' DMA instructions of this wave (lpt each, lpt <= 8) may still be outstanding
+    const int n = younger_tiles * lpt;
+    if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// the loader waves' whole life: fill the ring for k-tiles [0, nk)
+template <typename TA, typename TB>
+__device__ __forceinline__ void ring_loader(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, long long lda, long long ldb, int m0, int M,
+                                            int n0, int N, int kbeg, int nk, char *smem, int cw, int lane) {
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;
+    static_assert(LPT <= 8, "ring_wait_landed covers up to 8 DMA instructions per wave and k-tile");
+    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+    TA::src_ptrs(A, lda, m0, M, kbeg, cw, lane, ga);
+    TB::src_ptrs(B, ldb, n0, N, kbeg, cw, lane, gb);
+    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+#pragma unroll
+    for (int t = 0; t < RING_STAGES - 1; ++t)
+        if (t < nk) {
+            TA::issue_at(ga, t * a_step, smem + t * SLOT, cw);
+            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, cw);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        ring_wait_landed(min(RING_STAGES - 2, nk - 1 - kt), LPT);
+        __builtin_amdgcn_s_barrier();
+        if (kt + RING_STAGES - 1 < nk) {
+            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
+            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, cw);
+            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, cw);
+        }
+    }
+}
+
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
+__global__ __launch_bounds__(RING_THREADS, 1) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
                                                                 long long slab_stride, int nsplit, EpiArgs ep) {
     using TA = RingTile<BM, AT>;
     using TB = RingTile<BN, BT>;
     constexpr int SLOT = TA::BYTES + TB::BYTES;
-    constexpr int LPT = TA::INSTR + TB::INSTR;       // LDS-DMA instructions per wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RB = BM / 64, CB = BN / 64;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3, wm = wave >> 1, wn = wave & 1;
     int tx, ty, tz;
     tile_coords((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit, tx, ty, tz);
     const int m0 = ty * BM, n0 = tx * BN;
     const int kbeg = tz * kchunk, kend = min(K, kbeg + kchunk);
     const int nk = (kend - kbeg) / GB_K;
-    f32x16 acc[RB][CB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
     const bf16_t *Bm = B;
     if (ep.btab) {      // workgroup-uniform
         Bm = reinterpret_cast<const bf16_t *>(ep.btab[blockIdx.y]);
         Cv = reinterpret_cast<bf16_t *>(Cv) + (long long)blockIdx.y * ep.c_batch;
     }
-    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
-    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
-    TB::src_ptrs(Bm, ldb, n0, N, kbeg, wave, lane, gb);
-    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    if (wave8 >= 4) {
+        ring_loader<TA, TB>(A, Bm, lda, ldb, m0, M, n0, N, kbeg, nk, smem, wave, lane);
+        __builtin_amdgcn_s_barrier();     // pairs with the compute waves' barrier in front of the epilogue
+        return;
+    }
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
     int a_off[RB][GB_K / 16][TA::NFO], b_off[CB][GB_K / 16][TB::NFO];
 #pragma unroll
     for (int s = 0; s < GB_K / 16; ++s) {
@@ -478,37 +529,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
 #pragma unroll
         for (int j = 0; j < CB; ++j) TB::frag_offsets(wn * (BN / 2) + 32 * j, s, lane, b_off[j][s]);
     }
-#pragma unroll
-    for (int t = 0; t < RING_STAGES - 1; ++t)
-        if (t < nk) {
-            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
-            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
-        }
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of tile kt have landed once at most the next tile's LPT instructions are outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1)%3
-        if (kt + RING_STAGES - 1 < nk) {
-            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
-            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
-            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
-        }
+        __builtin_amdgcn_s_barrier();                 // the loaders' pieces of tile kt have landed
         const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        // every fragment read of the k-tile is in flight before the first MFMA needs one (one wave per SIMD computes: nothing else hides
+        // the LDS latency; read-per-k16-step cost 1.4 us of the 14.4 at K = 2048)
+        bf16x8 af[RB][GB_K / 16], bfr[CB][GB_K / 16];
 #pragma unroll
         for (int s = 0; s < GB_K / 16; ++s) {
-            bf16x8 af[RB], bfr[CB];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) af[i] = TA::frag_at(as, a_off[i][s]);
+            for (int i = 0; i < RB; ++i) af[i][s] = TA::frag_at(as, a_off[i][s]);
 #pragma unroll
-            for (int j = 0; j < CB; ++j) bfr[j] = TB::frag_at(bs, b_off[j][s]);
+            for (int j = 0; j < CB; ++j) bfr[j][s] = TB::frag_at(bs, b_off[j][s]);
+        }
+#pragma unroll
+        for (int s = 0; s < GB_K / 16; ++s)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue tile overwrites the ring (the loader waves end behind it)
     gemm_epilogue<BM, BN, OUT_MODE>(acc, smem, Cv, M, N, ldc, slab_stride, m0, n0, wm, wn, lane, ep, ty, tz);
 }
 
@@ -520,16 +562,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const bf16_t *__
 // order ((w0 + w2) + (w1 + w3)) before the slab / accumulate store.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int OUT_MODE>
-__global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C,
+__global__ __launch_bounds__(RING_THREADS, 1) void gemm_tt64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C,
                                                                  int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
                                                                  long long slab_stride, int nsplit) {
     using TA = RingTile<64, true>;
     using TB = RingTile<64, true>;
     constexpr int SLOT = TA::BYTES + TB::BYTES;
-    constexpr int LPT = TA::INSTR + TB::INSTR;
     static_assert(GB_K / 16 == 4, "one k16 step per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3;
     int tx, ty, tz;
     tile_coords((N + 63) / 64, (M + 63) / 64, nsplit, tx, ty, tz);
     const int m0 = ty * 64, n0 = tx * 64;
@@ -540,31 +581,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *_
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
-    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
-    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
-    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
-    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    if (wave8 >= 4) {      // loader waves (see gemm_bf16_ring_kernel)
+        ring_loader<TA, TB>(A, B, lda, ldb, m0, M, n0, N, kbeg, nk, smem, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     int a_off[2][TA::NFO], b_off[2][TB::NFO];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         TA::frag_offsets(32 * i, wave, lane, a_off[i]);
         TB::frag_offsets(32 * i, wave, lane, b_off[i]);
     }
-#pragma unroll
-    for (int t = 0; t < RING_STAGES - 1; ++t)
-        if (t < nk) {
-            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
-            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
-        }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + RING_STAGES - 1 < nk) {
-            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
-            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
-            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
-        }
+        __builtin_amdgcn_s_barrier();                 // the loaders' pieces of tile kt have landed
         const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
         bf16x8 af[2], bfr[2];
 #pragma unroll
@@ -577,7 +606,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *_
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // all fragment reads done before the partial tiles overwrite the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all fragment reads done before the partial tiles overwrite the ring (the loader waves end behind it)
     constexpr int LDT = 64 + 4;
     static_assert(2 * 64 * LDT * 4 <= RING_STAGES * SLOT, "two fp32 tiles fit the ring");
     float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 64 * LDT;
@@ -632,16 +662,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tt64_wavek_kernel(const bf16_t *_
 // The same wave-K split for the plain forward / data-gradient 64x64 tile (both operands k-contiguous, bf16 output): the main loops
 // of these kernels are bound by LDS bandwidth, not by MFMA or by the DMA latency (bytes through LDS per 32x32x16 MFMA: 2 KB of
 // fragment reads + 1 KB of DMA writes with one 32x32 block per wave; 1 + 1 KB with a 64x64 block per wave).
-__global__ __launch_bounds__(256, 2) void gemm_nn64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
+__global__ __launch_bounds__(RING_THREADS, 1) void gemm_nn64_wavek_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
                                                                  int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
                                                                  long long slab_stride, int nsplit) {
     using TA = RingTile<64, false>;
     using TB = RingTile<64, false>;
     constexpr int SLOT = TA::BYTES + TB::BYTES;
-    constexpr int LPT = TA::INSTR + TB::INSTR;
     static_assert(GB_K / 16 == 4, "one k16 step per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3;
     int tx, ty, tz;
     tile_coords((N + 63) / 64, (M + 63) / 64, nsplit, tx, ty, tz);
     const int m0 = ty * 64, n0 = tx * 64;
@@ -652,31 +681,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nn64_wavek_kernel(const bf16_t *_
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
-    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
-    TA::src_ptrs(A, lda, m0, M, kbeg, wave, lane, ga);
-    TB::src_ptrs(B, ldb, n0, N, kbeg, wave, lane, gb);
-    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    if (wave8 >= 4) {      // loader waves (see gemm_bf16_ring_kernel)
+        ring_loader<TA, TB>(A, B, lda, ldb, m0, M, n0, N, kbeg, nk, smem, wave, lane);
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     int a_off[2][TA::NFO], b_off[2][TB::NFO];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         TA::frag_offsets(32 * i, wave, lane, a_off[i]);
         TB::frag_offsets(32 * i, wave, lane, b_off[i]);
     }
-#pragma unroll
-    for (int t = 0; t < RING_STAGES - 1; ++t)
-        if (t < nk) {
-            TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
-            TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
-        }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + RING_STAGES - 1 < nk) {
-            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
-            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, wave);
-            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, wave);
-        }
+        __builtin_amdgcn_s_barrier();                 // the loaders' pieces of tile kt have landed
         const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
         bf16x8 af[2], bfr[2];
 #pragma unroll
@@ -689,7 +706,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn64_wavek_kernel(const bf16_t *_
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // all fragment reads done before the partial tiles overwrite the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all fragment reads done before the partial tiles overwrite the ring (the loader waves end behind it)
     constexpr int LDT = 64 + 4;
     static_assert(2 * 64 * LDT * 4 <= RING_STAGES * SLOT, "two fp32 tiles fit the ring");
     float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 64 * LDT;
@@ -726,6 +744,310 @@ __global__ __launch_bounds__(256, 2) void gemm_nn64_wavek_kernel(const bf16_t *_
         for (int e = 0; e < 8; e += 4) {
             const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e), vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc + e);
             v[e] = va.x + vb.x; v[e + 1] = va.y + vb.y; v[e + 2] = va.z + vb.z; v[e + 3] = va.w + vb.w;
+        }
+        bf16_t *dst = C + (long long)m * ldc + n;
+        if (vec && n + 8 <= N) st8(dst, v);
+        else
+            for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128x64 forward / data-gradient tile (both operands k-contiguous, bf16 out, no fused epilogue) - the shape of the step's dominant GEMM
+// launches (N = 256: FFN down-projection and the up-projection's data gradient at K = 2048; attention / conv-module projections at
+// K = 256 ... 768). Parameters of the main loop:
+//   STAGES: LDS-DMA ring slots (STAGES - 1 k-tiles in flight behind the MFMAs; 3 = the generic ring kernel above);
+//   WAVEK : 1 = the four waves split the k-tile (wave w owns k16 step w and accumulates the WHOLE 128x64 tile: 4 A + 2 B fragment reads
+//           for 8 MFMAs instead of 4 x (2 + 1): half the fragment traffic through the LDS port the DMA writes share), partial tiles
+//           combined through LDS in the fixed order (w0 + w2) + (w1 + w3);
+//   FLOOR : lab only (tools/gemm_bench.py --floor): 1 = the DMA ring and its barriers alone (no fragment reads, no MFMA): what the
+//           L2 -> LDS path delivers to one workgroup per CU; 2 = fragment reads + MFMA alone (no DMA).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int STAGES, int WAVEK, int FLOOR>
+__global__ __launch_bounds__(256, 1) void gemm_nn128x64_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
+                                                               int M, int N, int K, long long lda, long long ldb, long long ldc) {
+    using TA = RingTile<128, false>;
+    using TB = RingTile<64, false>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;
+    // WAVEK 0 / 1: see above. WAVEK == 2: the 2x2 wave tiling with the fragments of k-tile kt + 1 read into registers BEFORE the MFMAs of
+    // k-tile kt are issued (software pipeline across the barrier): with one wave per SIMD nothing else hides the LDS read latency - the
+    // plain loop (reads of a k16 step, wait, its two MFMAs) spends 670 cycles per k-tile for 256 cycles of MFMA (lab floor "mfma only").
+    constexpr bool PIPE = WAVEK == 2;
+    constexpr int RB = WAVEK == 1 ? 4 : 2, CB = WAVEK == 1 ? 2 : 1, NS = WAVEK == 1 ? 1 : GB_K / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+    int tx, ty, tz;
+    tile_coords((N + 63) / 64, (M + 127) / 128, 1, tx, ty, tz);
+    const int m0 = ty * 128, n0 = tx * 64;
+    const int nk = K / GB_K;
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
+    const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+    TA::src_ptrs(A, lda, m0, M, 0, wave, lane, ga);
+    TB::src_ptrs(B, ldb, n0, N, 0, wave, lane, gb);
+    const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+    int a_off[RB][NS][TA::NFO], b_off[CB][NS][TB::NFO];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) TA::frag_offsets(WAVEK == 1 ? 32 * i : wm * 64 + 32 * i, WAVEK == 1 ? wave : s, lane, a_off[i][s]);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) TB::frag_offsets(WAVEK == 1 ? 32 * j : wn * 32 + 32 * j, WAVEK == 1 ? wave : s, lane, b_off[j][s]);
+    }
+    if (FLOOR != 2) {
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) {
+                TA::issue_at(ga, t * a_step, smem + t * SLOT, wave);
+                TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
+            }
+    }
+    // wait until at most `younger` k-tiles' worth of this wave's DMA instructions are outstanding
+    auto wait_younger = [&](int younger) {
+        if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (!PIPE) {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (FLOOR != 2) wait_younger(min(STAGES - 2, nk - 1 - kt));   // tile kt has landed
+            __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1) % STAGES
+            if (FLOOR != 2 && kt + STAGES - 1 < nk) {
+                char *slot = smem + ((kt + STAGES - 1) % STAGES) * SLOT;
+                TA::issue_at(ga, (kt + STAGES - 1) * a_step, slot, wave);
+                TB::issue_at(gb, (kt + STAGES - 1) * b_step, slot + TA::BYTES, wave);
+            }
+            if (FLOOR == 1) continue;
+            const char *as = smem + (kt % STAGES) * SLOT, *bs = as + TA::BYTES;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                bf16x8 af[RB], bfr[CB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) af[i] = TA::frag_at(as, a_off[i][s]);
+#pragma unroll
+                for (int j = 0; j < CB; ++j) bfr[j] = TB::frag_at(bs, b_off[j][s]);
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+        // iteration kt: [tile kt + 1 landed] barrier [DMA of tile kt + STAGES - 1 into the slot of tile kt - 1, whose fragments every wave
+        // consumed in iteration kt - 1] [fragment reads of tile kt + 1 -> nxt] [MFMAs of tile kt on cur] cur <- nxt
+        static_assert(!PIPE || STAGES >= 4, "the register pipeline needs tile kt + 1 landed while tile kt computes");
+        // Two register sets alternate roles (no copies); inside a step the MFMAs of k16 step s are followed IN PROGRAM ORDER by the three
+        // fragment reads of step s of the next tile (sched_group_barrier pins the interleave), so the reads issue while the matrix pipe
+        // works and their results are first needed after the next barrier.
+        bf16x8 fa0[RB][NS], fb0[NS], fa1[RB][NS], fb1[NS];
+        if (FLOOR != 2) wait_younger(min(STAGES - 2, nk - 1));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) fa0[i][s] = TA::frag_at(smem, a_off[i][s]);
+            fb0[s] = TB::frag_at(smem + TA::BYTES, b_off[0][s]);
+        }
+#define NN128_STEP(CA, CB_, NA, NB, KT)                                                                                                  \
+        {                                                                                                                                \
+            if (FLOOR != 2) wait_younger(min(STAGES - 3, nk - 2 - (KT)));   /* tile KT + 1 has landed (this wave's pieces) */            \
+            __builtin_amdgcn_s_barrier();                                                                                                \
+            if (FLOOR != 2 && (KT) + STAGES - 1 < nk) {                                                                                  \
+                char *slot = smem + (((KT) + STAGES - 1) % STAGES) * SLOT;                                                               \
+                TA::issue_at(ga, ((KT) + STAGES - 1) * a_step, slot, wave);                                                              \
+                TB::issue_at(gb, ((KT) + STAGES - 1) * b_step, slot + TA::BYTES, wave);                                                  \
+            }                                                                                                                            \
+            const char *as_ = smem + (((KT) + 1) % STAGES) * SLOT, *bs_ = as_ + TA::BYTES;                                               \
+            _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                             \
+                if (FLOOR != 1) {                                                                                                        \
+                    _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                                       \
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CA[i][s], CB_[s], acc[i][0], 0, 0, 0);                        \
+                }                                                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < RB; ++i) NA[i][s] = TA::frag_at(as_, a_off[i][s]);                                 \
+                NB[s] = TB::frag_at(bs_, b_off[0][s]);                                                                                   \
+                if (FLOOR != 1) __builtin_amdgcn_sched_group_barrier(0x008, RB, 0);                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, RB + 1, 0);                                                                  \
+            }                                                                                                                            \
+        }
+#define NN128_LAST(CA, CB_)                                                                                                              \
+        if (FLOOR != 1) {                                                                                                                \
+            _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                                               \
+                _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                                           \
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CA[i][s], CB_[s], acc[i][0], 0, 0, 0);                            \
+        }
+        int kt = 0;
+        bool in0 = true;                                   // which register set holds tile kt
+        while (kt + 1 < nk) {
+            NN128_STEP(fa0, fb0, fa1, fb1, kt);
+            ++kt;
+            in0 = false;
+            if (kt + 1 < nk) {
+                NN128_STEP(fa1, fb1, fa0, fb0, kt);
+                ++kt;
+                in0 = true;
+            }
+        }
+        if (in0) { NN128_LAST(fa0, fb0); } else { NN128_LAST(fa1, fb1); }
+#undef NN128_STEP
+#undef NN128_LAST
+    }
+    __syncthreads();  // all fragment reads done before the epilogue tiles overwrite the ring
+    const int r = lane & 31, hh = lane >> 5;
+    const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    constexpr int LDT = 64 + 4;
+    float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 128 * LDT;
+    static_assert(2 * 128 * LDT * 4 <= 3 * SLOT, "two fp32 tiles fit the smallest ring");
+    if (WAVEK == 1) {
+        float *mine = (wave & 1) ? t1 : t0;
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) mine[(32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r] = acc[i][j][g];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        float *q = mine + (32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r;
+                        *q = acc[i][j][g] + *q;
+                    }
+        }
+        __syncthreads();
+    } else {
+        // each wave owns a disjoint 64x32 block: one fp32 tile, no sums
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t0[(wm * 64 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * 32 + r] = acc[i][0][g];
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < 128 * 8; c += 256) {
+        const int rr = c >> 3, cc = (c & 7) * 8;
+        const int m = m0 + rr, n = n0 + cc;
+        if (m >= M || n >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e);
+            v[e] = va.x; v[e + 1] = va.y; v[e + 2] = va.z; v[e + 3] = va.w;
+            if (WAVEK == 1) {
+                const float4 vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc + e);
+                v[e] += vb.x; v[e + 1] += vb.y; v[e + 2] += vb.z; v[e + 3] += vb.w;
+            }
+        }
+        bf16_t *dst = C + (long long)m * ldc + n;
+        if (vec && n + 8 <= N) st8(dst, v);
+        else
+            for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
+    }
+}
+
+// The same tile with SPECIALISED waves: 8 waves, 0-3 compute (2x2 tiling, fragments of the next k16 step / k-tile read ahead), 4-7 only
+// issue the LDS-DMA ring. Why: the lab floors of the 4-wave loop (tools/gemm_bench.py --nn128, profiles/r04_notes.md) are 11.4 us for the
+// DMA ring alone and 8.8-10.9 us for fragment reads + MFMA alone, yet together they take 16 us whatever the compute part costs: a wave
+// that issues a DMA into a full vector-memory queue sits in the issue stage until older requests drain, and the MFMAs behind it in
+// program order wait with it. A loader wave may block there for free.
+template <int STAGES>
+__global__ __launch_bounds__(512, 1) void gemm_nn128x64_ws_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
+                                                                  int M, int N, int K, long long lda, long long ldb, long long ldc) {
+    using TA = RingTile<128, false>;
+    using TB = RingTile<64, false>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    constexpr int LPT = TA::INSTR + TB::INSTR;
+    constexpr int NS = GB_K / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    int tx, ty, tz;
+    tile_coords((N + 63) / 64, (M + 127) / 128, 1, tx, ty, tz);
+    const int m0 = ty * 128, n0 = tx * 64;
+    const int nk = K / GB_K;
+    f32x16 acc[2];
+    acc[0] = (f32x16){0}; acc[1] = (f32x16){0};
+    if (loader) {
+        const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
+        TA::src_ptrs(A, lda, m0, M, 0, cw, lane, ga);
+        TB::src_ptrs(B, ldb, n0, N, 0, cw, lane, gb);
+        const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) {
+                TA::issue_at(ga, t * a_step, smem + t * SLOT, cw);
+                TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, cw);
+            }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int younger = min(STAGES - 2, nk - 1 - kt);     // tile kt has landed once only the younger tiles' instructions are outstanding
+            if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // tile kt visible to the compute waves; they are done with tile kt - 1
+            if (kt + STAGES - 1 < nk) {
+                char *slot = smem + ((kt + STAGES - 1) % STAGES) * SLOT;
+                TA::issue_at(ga, (kt + STAGES - 1) * a_step, slot, cw);
+                TB::issue_at(gb, (kt + STAGES - 1) * b_step, slot + TA::BYTES, cw);
+            }
+        }
+    } else {
+        int a_off[2][NS][TA::NFO], b_off[NS][TB::NFO];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) TA::frag_offsets(wm * 64 + 32 * i, s, lane, a_off[i][s]);
+            TB::frag_offsets(wn * 32, s, lane, b_off[s]);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            const char *as = smem + (kt % STAGES) * SLOT, *bs = as + TA::BYTES;
+            bf16x8 fa[2][NS], fb[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {                  // all twelve reads of the k-tile in flight before the first MFMA needs one
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i][s] = TA::frag_at(as, a_off[i][s]);
+                fb[s] = TB::frag_at(bs, b_off[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[s], acc[i], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
+    const int r = lane & 31, hh = lane >> 5;
+    const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    constexpr int LDT = 64 + 4;
+    float *t0 = reinterpret_cast<float *>(smem);
+    if (!loader) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t0[(wm * 64 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * 32 + r] = acc[i][g];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 128 * 8; c += 512) {
+        const int rr = c >> 3, cc = (c & 7) * 8;
+        const int m = m0 + rr, n = n0 + cc;
+        if (m >= M || n >= N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e);
+            v[e] = va.x; v[e + 1] = va.y; v[e + 2] = va.z; v[e + 3] = va.w;
         }
         bf16_t *dst = C + (long long)m * ldc + n;
         if (vec && n + 8 <= N) st8(dst, v);
@@ -823,6 +1145,24 @@ int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, i
                           const unsigned long long *seed_dev, float *colpart, void *mask, hipStream_t st);
 
 static int g_use_ring = 1;   // 0: never, 1: long K or small tiles, 2: always
+// 128x64 nn bf16 tile: ring slots / wave-K split / lab floor mode of gemm_nn128x64_kernel; stages 0 = the generic ring kernel
+static int g_nn128_stages = 0, g_nn128_wavek = 0, g_nn128_floor = 0;
+
+template <int STAGES>
+static void launch_nn128x64_ws(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = STAGES * (RingTile<128, false>::BYTES + RingTile<64, false>::BYTES);
+    auto kern = gemm_nn128x64_ws_kernel<STAGES>;
+    if (BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    kern<<<grid, 512, BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc);
+}
+
+template <int STAGES, int WAVEK, int FLOOR>
+static void launch_nn128x64(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = STAGES * (RingTile<128, false>::BYTES + RingTile<64, false>::BYTES);
+    auto kern = gemm_nn128x64_kernel<STAGES, WAVEK, FLOOR>;
+    if (BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    kern<<<grid, 256, BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc);
+}
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
@@ -836,7 +1176,7 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         static const int wavek = 1;
         if (ring && wavek) {
             using R = RingSmem<64, 64, true, true>;
-            gemm_tt64_wavek_kernel<OUT_MODE><<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (float *)C, M, N, K, lda, ldb, ldc, kchunk,
+            gemm_tt64_wavek_kernel<OUT_MODE><<<grid, RING_THREADS, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (float *)C, M, N, K, lda, ldb, ldc, kchunk,
                                                                           slab_stride, splits);
             return;
         }
@@ -845,16 +1185,44 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         static const int wavek = 1;
         if (ring && wavek && ep.mode == 0 && min(K, kchunk) >= 16 * GB_K) {   // short K: the heavier epilogue costs more than the loop gains (5.4 -> 6.1 us at K = 256; 13.1 -> 11.2 us at M = 4000, K = 2048)
             using R = RingSmem<64, 64, false, false>;
-            gemm_nn64_wavek_kernel<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, kchunk,
+            gemm_nn64_wavek_kernel<<<grid, RING_THREADS, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, kchunk,
                                                                 slab_stride, splits);
             return;
+        }
+    }
+    if constexpr (BM == 128 && BN == 64 && !AT && !BT && OUT_MODE == 0) {
+        if (ring && g_nn128_stages && ep.mode == 0 && !ep.btab && splits == 1 && K % GB_K == 0) {
+            const int v = g_nn128_stages * 100 + g_nn128_wavek * 10 + g_nn128_floor;
+            switch (v) {
+            case 300: launch_nn128x64<3, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 400: launch_nn128x64<4, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 500: launch_nn128x64<5, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 600: launch_nn128x64<6, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 310: launch_nn128x64<3, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 410: launch_nn128x64<4, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 510: launch_nn128x64<5, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 610: launch_nn128x64<6, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 401: launch_nn128x64<4, 0, 1>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 601: launch_nn128x64<6, 0, 1>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 402: launch_nn128x64<4, 0, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 412: launch_nn128x64<4, 1, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 420: launch_nn128x64<4, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 520: launch_nn128x64<5, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 620: launch_nn128x64<6, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 422: launch_nn128x64<4, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 330: launch_nn128x64_ws<3>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 430: launch_nn128x64_ws<4>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 530: launch_nn128x64_ws<5>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            case 630: launch_nn128x64_ws<6>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
+            default: break;
+            }
         }
     }
     if (ring) {
         using R = RingSmem<BM, BN, AT, BT>;
         auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE>;
         if (R::BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::BYTES);
-        kern<<<grid, 256, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
+        kern<<<grid, RING_THREADS, R::BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
         return;
     }
     using S = GemmSmem<BM, BN, AT, BT>;
@@ -928,6 +1296,9 @@ extern "C" {
 void tsasr_gemm_set_ring(int on) { g_use_ring = on; }
 /* A/B tests only: force the macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64; -1 = automatic) and the split-K factor of fp32-output GEMMs. */
 void tsasr_gemm_set_plan(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
+/* 128x64 bf16 tile of the N = 256 projections: ring slots (0 = generic 3-slot ring kernel; 3..6), wave-K split (0 / 1), lab floor mode
+ * (0 = the GEMM; 1 = LDS-DMA ring alone, 2 = fragment reads + MFMA alone: results are NOT the product - tools/gemm_bench.py --floor). */
+void tsasr_gemm_set_nn128(int stages, int wavek, int floor_mode) { g_nn128_stages = stages; g_nn128_wavek = wavek; g_nn128_floor = floor_mode; }
 
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype) {
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
@@ -988,7 +1359,7 @@ int tsasr_gemm_bf16_nt_batched(const void *A, const void *const *btab, void *C, 
     ep.btab = btab; ep.c_batch = c_batch;
     using R = RingSmem<64, 64, false, false>;
     dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 64)), (unsigned)nbatch);
-    gemm_bf16_ring_kernel<64, 64, false, false, 0><<<grid, 256, R::BYTES, (hipStream_t)stream>>>((const bf16_t *)A, nullptr, C, M, N, K, lda, ldb, ldc, K, 0, 1, ep);
+    gemm_bf16_ring_kernel<64, 64, false, false, 0><<<grid, RING_THREADS, R::BYTES, (hipStream_t)stream>>>((const bf16_t *)A, nullptr, C, M, N, K, lda, ldb, ldc, K, 0, 1, ep);
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_nt_batched");
     return 0;
 }

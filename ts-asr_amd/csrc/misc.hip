@@ -45,152 +45,79 @@ __global__ void count_nonfinite_kernel(const float *__restrict__ x, int n, int *
     if (threadIdx.x == 0 && c) *counter += c;
 }
 
-// test aid: every CU's whole LDS is overwritten with `pattern` (a kernel that reads LDS it never wrote then sees this, not leftovers)
-__global__ __launch_bounds__(256) void fill_lds_kernel(unsigned pattern, int words, unsigned *sink) {
-    extern __shared__ unsigned fill_lds[];
-    for (int i = threadIdx.x; i < words; i += 256) fill_lds[i] = pattern;
+// ---- speaker-embedding injection `sum` / `prod` (models/conformer.py:247-253): out[b,t,:] = src[b,t,:] (+ | *) spk[b,0,:]; backward in ONE
+// pass over dout: dsrc = dout (sum) | dout * spk (prod), dspk[b,:] = sum_t dout (sum) | sum_t dout * src (prod), fixed summation order
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void inject_fwd_kernel(const T *__restrict__ src, const T *__restrict__ spk, T *__restrict__ out, int Tn, int D, long long total) {
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= total) return;
+    const int d = (int)(e % D);
+    const long long b = e / ((long long)D * Tn);
+    float x[8], s[8];
+    ld8(src + e, x);
+    ld8(spk + b * D + d, s);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = PROD ? x[i] * s[i] : x[i] + s[i];
+    st8(out + e, x);
+}
+
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void inject_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ src, const T *__restrict__ spk,
+                                                         T *__restrict__ dsrc, T *__restrict__ dspk, int Tn, int D) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const float sp = (PROD && d < D) ? ld1(spk + (long long)b * D + d) : 1.f;
+    float acc = 0.f;
+    if (d < D)
+        for (int t = sl; t < Tn; t += 4) {
+            const long long e = ((long long)b * Tn + t) * D + d;
+            const float g = ld1(dout + e);
+            if (PROD) {
+                acc += g * ld1(src + e);
+                st1(dsrc + e, g * sp);
+            } else {
+                acc += g;
+                st1(dsrc + e, g);
+            }
+        }
+    red[sl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (sink && fill_lds[(threadIdx.x * 97) % words] != pattern) *sink = 1;   // keeps the stores alive
-}
-
-__global__ void fill_words_kernel(unsigned *p, unsigned pattern, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pattern;
-}
-
-// TEST AID: LDS canary. A workgroup fills `words` 32-bit words of its own LDS with a pattern derived from its id, then verifies and
-// rewrites them `iters` times; every word that does not read back as written is counted. Run beside another stream's kernels it
-// detects writes that land outside their own LDS allocation (an LDS-DMA with a destination beyond the workgroup's allocation is not
-// a `ds_write`: nothing says it is bounds-checked the same way).
-__global__ __launch_bounds__(256) void lds_canary_kernel(int words, int iters, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
-    extern __shared__ unsigned cw[];
-    const unsigned key = 0xA5000000u ^ (blockIdx.x * 2654435761u);
-    for (int i = threadIdx.x; i < words; i += 256) cw[i] = key ^ (unsigned)i;
-    __syncthreads();
-    unsigned bad = 0;
-    for (int it = 0; it < iters; ++it) {
-        for (int i = threadIdx.x; i < words; i += 256) {
-            const unsigned v = cw[i];
-            if (v != (key ^ (unsigned)i)) {
-                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x; first_bad[1] = (unsigned)i; first_bad[2] = v; first_bad[3] = key ^ (unsigned)i; }
-                ++bad;
-                cw[i] = key ^ (unsigned)i;
-            }
-        }
-        __builtin_amdgcn_s_sleep(32);
-        __syncthreads();
-    }
-    if (bad) atomicAdd(errors, bad);
-}
-
-// TEST AID: register canary. Every lane keeps 48 known values in VGPRs (pinned there by empty asm statements), sleeps, and checks them
-// `iters` times: a value that changed was written by somebody else - this wave never writes them after the first assignment.
-__global__ __launch_bounds__(256) void vgpr_canary_kernel(int iters, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
-    unsigned v[48];
-    const unsigned key = 0x5A000000u ^ ((blockIdx.x * 256u + threadIdx.x) * 2246822519u);
-#pragma unroll
-    for (int i = 0; i < 48; ++i) { v[i] = key + (unsigned)i * 0x01000193u; asm volatile("" : "+v"(v[i])); }
-    unsigned bad = 0;
-    for (int it = 0; it < iters; ++it) {
-        __builtin_amdgcn_s_sleep(16);
-#pragma unroll
-        for (int i = 0; i < 48; ++i) {
-            asm volatile("" : "+v"(v[i]));
-            if (v[i] != key + (unsigned)i * 0x01000193u) {
-                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x * 256u + threadIdx.x; first_bad[1] = (unsigned)i; first_bad[2] = v[i]; first_bad[3] = key + (unsigned)i * 0x01000193u; }
-                ++bad;
-                v[i] = key + (unsigned)i * 0x01000193u;
-            }
-        }
-    }
-    if (bad) atomicAdd(errors, bad);
-}
-
-// TEST AID: barrier canary. The cross-wave pattern of the log-mel kernel (a table every wave fills a quarter of, one workgroup barrier,
-// then every wave reads all of it): each round the four waves write round-dependent words, meet at the barrier, and every lane checks
-// four words written by each OTHER wave. A mismatch = the barrier let a wave through before the others' LDS stores were visible.
-__global__ __launch_bounds__(256) void barrier_canary_kernel(int rounds, unsigned *__restrict__ errors, unsigned *__restrict__ first_bad) {
-    __shared__ unsigned pad0[4096];          // 16 KB in front (the log-mel kernel keeps its FFT buffers there)
-    __shared__ unsigned tab[256 + 1280];     // the shared table sits at the log-mel kernel's offset of its twiddles (20496 B = 5124 words)
-    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    pad0[tid] = tid;
-    unsigned bad = 0;
-    for (int rd = 0; rd < rounds; ++rd) {
-        const unsigned key = 0xC3000000u ^ (unsigned)(rd * 40503u) ^ (blockIdx.x << 8);
-        tab[1028 + tid] = key + tid;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned idx = w * 64 + ((lane * 7 + rd) & 63), v = tab[1028 + idx];
-            if (v != key + idx) {
-                if (bad == 0 && first_bad) { first_bad[0] = blockIdx.x; first_bad[1] = (wave << 16) | (w << 8) | lane; first_bad[2] = v; first_bad[3] = key + idx; }
-                ++bad;
-            }
-        }
-        __syncthreads();
-    }
-    if (bad) atomicAdd(errors, bad);
-    if (pad0[(tid * 5) & 4095] == 0xFFFFFFFFu) errors[1] = 1;   // keeps pad0 allocated
+    if (sl == 0 && d < D) st1(dspk + (long long)b * D + d, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 extern "C" {
 
-/* TEST AID: `wgs` workgroups run `rounds` write / barrier / cross-wave read rounds; *errors (DEVICE uint[2]) += stale words seen. */
-int tsasr_debug_barrier_canary(int wgs, int rounds, void *errors, void *first_bad, void *stream) {
-    TSASR_CHECK_ARG(wgs > 0 && rounds > 0 && errors, "tsasr_debug_barrier_canary: bad arguments");
-    barrier_canary_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(rounds, (unsigned *)errors, (unsigned *)first_bad);
-    TSASR_CHECK_LAUNCH("tsasr_debug_barrier_canary");
+/* out [B,T,D] = src [B,T,D] (+ | *) spk [B,1,D]  (mode 0 = sum, 1 = prod; D % 8 == 0) */
+int tsasr_inject_fwd(const void *src, const void *spk, void *out, int B, int T, int D, int mode, int io_dtype, void *stream) {
+    TSASR_CHECK_ARG(src && spk && out && B > 0 && T > 0 && D > 0 && D % 8 == 0 && (mode == 0 || mode == 1), "tsasr_inject_fwd: bad arguments");
+    const long long total = (long long)B * T * D;
+    const unsigned grid = (unsigned)((total / 8 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32) {
+        if (mode) inject_fwd_kernel<float, true><<<grid, 256, 0, st>>>((const float *)src, (const float *)spk, (float *)out, T, D, total);
+        else inject_fwd_kernel<float, false><<<grid, 256, 0, st>>>((const float *)src, (const float *)spk, (float *)out, T, D, total);
+    } else {
+        if (mode) inject_fwd_kernel<bf16_t, true><<<grid, 256, 0, st>>>((const bf16_t *)src, (const bf16_t *)spk, (bf16_t *)out, T, D, total);
+        else inject_fwd_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t *)src, (const bf16_t *)spk, (bf16_t *)out, T, D, total);
+    }
+    TSASR_CHECK_LAUNCH("tsasr_inject_fwd");
     return 0;
 }
 
-/* TEST AID: `wgs` workgroups of 256 lanes keep 48 VGPRs each and verify them `iters` times; *errors (DEVICE uint) += changed registers. */
-int tsasr_debug_vgpr_canary(int wgs, int iters, void *errors, void *first_bad, void *stream) {
-    TSASR_CHECK_ARG(wgs > 0 && iters > 0 && errors, "tsasr_debug_vgpr_canary: bad arguments");
-    vgpr_canary_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(iters, (unsigned *)errors, (unsigned *)first_bad);
-    TSASR_CHECK_LAUNCH("tsasr_debug_vgpr_canary");
-    return 0;
-}
-
-/* TEST AID: `wgs` workgroups hold `lds_bytes` of LDS each, check them `iters` times; *errors (device uint) += corrupted words seen,
- * first_bad (device uint[4], may be NULL) = {workgroup, word, value read, value expected} of one of them. */
-int tsasr_debug_lds_canary(int wgs, int lds_bytes, int iters, void *errors, void *first_bad, void *stream) {
-    TSASR_CHECK_ARG(wgs > 0 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && iters > 0 && errors, "tsasr_debug_lds_canary: bad arguments");
-    (void)hipFuncSetAttribute((const void *)lds_canary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    lds_canary_kernel<<<wgs, 256, lds_bytes, (hipStream_t)stream>>>(lds_bytes / 4, iters, (unsigned *)errors, (unsigned *)first_bad);
-    TSASR_CHECK_LAUNCH("tsasr_debug_lds_canary");
-    return 0;
-}
-
-/* TEST AID: fill the LDS of every CU with a 32-bit pattern (160 KB workgroups, enough of them that every CU runs at least one). */
-int tsasr_debug_fill_lds(unsigned pattern, void *stream) {
-    const int bytes = 160 * 1024;
-    (void)hipFuncSetAttribute((const void *)fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    fill_lds_kernel<<<4 * cus, 256, bytes, (hipStream_t)stream>>>(pattern, bytes / 4, nullptr);
-    TSASR_CHECK_LAUNCH("tsasr_debug_fill_lds");
-    return 0;
-}
-
-/* TOOL AID: *out = the device's constant-rate wall clock (100 MHz) at the moment this one-thread kernel runs on `stream` - a captured
- * step carries a handful of these (prof.stamp, TSASR_STAMPS=1) to show when each phase REALLY starts in an unprofiled replay; rocprofv3's
- * kernel trace perturbs exactly that (tools/step_stamps.py). */
-__global__ void stamp_kernel(unsigned long long *out) { *out = wall_clock64(); }
-int tsasr_debug_stamp(void *out, void *stream) {
-    TSASR_CHECK_ARG(out && ((uintptr_t)out & 7) == 0, "tsasr_debug_stamp: null or misaligned pointer");
-    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>((unsigned long long *)out);
-    TSASR_CHECK_LAUNCH("tsasr_debug_stamp");
-    return 0;
-}
-
-/* TEST AID: fill `nwords` 32-bit words of device memory with a pattern (tools/det_stress.py --poison: NaN into every inactive block of the
- * captured step's memory pool between replays - a kernel that reads a buffer before its producer of THIS replay wrote it then shows up as
- * NaN instead of as the previous replay's nearly identical values). */
-int tsasr_debug_fill(void *p, unsigned pattern, size_t nwords, void *stream) {
-    TSASR_CHECK_ARG(p && ((uintptr_t)p & 3) == 0, "tsasr_debug_fill: null or misaligned pointer");
-    if (nwords == 0) return 0;
-    fill_words_kernel<<<(unsigned)std::min<size_t>(4096, (nwords + 255) / 256), 256, 0, (hipStream_t)stream>>>((unsigned *)p, pattern, nwords);
-    TSASR_CHECK_LAUNCH("tsasr_debug_fill");
+/* dsrc [B,T,D], dspk [B,1,D] from dout [B,T,D] (src, spk read only in mode 1) */
+int tsasr_inject_bwd(const void *dout, const void *src, const void *spk, void *dsrc, void *dspk, int B, int T, int D, int mode, int io_dtype,
+                     void *stream) {
+    TSASR_CHECK_ARG(dout && dsrc && dspk && B > 0 && T > 0 && D > 0 && (mode == 0 || (mode == 1 && src && spk)), "tsasr_inject_bwd: bad arguments");
+    dim3 grid(cdiv(D, 64), B);
+    hipStream_t st = (hipStream_t)stream;
+    if (io_dtype == TSASR_F32) {
+        if (mode) inject_bwd_kernel<float, true><<<grid, 256, 0, st>>>((const float *)dout, (const float *)src, (const float *)spk, (float *)dsrc, (float *)dspk, T, D);
+        else inject_bwd_kernel<float, false><<<grid, 256, 0, st>>>((const float *)dout, nullptr, nullptr, (float *)dsrc, (float *)dspk, T, D);
+    } else {
+        if (mode) inject_bwd_kernel<bf16_t, true><<<grid, 256, 0, st>>>((const bf16_t *)dout, (const bf16_t *)src, (const bf16_t *)spk, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
+        else inject_bwd_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t *)dout, nullptr, nullptr, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
+    }
+    TSASR_CHECK_LAUNCH("tsasr_inject_bwd");
     return 0;
 }
 

@@ -150,6 +150,31 @@ def mix_sources(sigs, delays, start, duration, target_speaker_idx, sample_rate=1
     return mixed[a:a + math.ceil(duration * sample_rate)]
 
 
+def mix_sources_device(sigs, delays, start, duration, target_speaker_idx, sample_rate=16000, gain_nontarget=0):
+    """mix_sources on the GPU (csrc/dataio.hip, tsasr_mix_sources): ``sigs`` are 1-D fp32 device tensors; returns the cropped mixture as a
+    device tensor. The host only converts seconds to samples with the reference's own ceil (train_librispeechmix_scratch.py:370,379-385).
+    Bit-identical to mix_sources when gain_nontarget == 0; with a gain, the two mean powers behind it are fp64 sums rounded once (the
+    reference's fp32 cascade sum depends on the host's SIMD width), every other operation is the reference's fp32 operation."""
+    import ctypes
+    from . import _capi as C
+    C.require_gpu(*sigs)
+    n = len(sigs)
+    lens = [int(s.numel()) for s in sigs]
+    src = sigs[0].float().contiguous() if n == 1 else torch.cat([s.float().reshape(-1) for s in sigs])
+    off = (ctypes.c_longlong * (n + 1))(*([0] + [sum(lens[:j + 1]) for j in range(n)]))
+    dly = (ctypes.c_int * n)(*[math.ceil(d * sample_rate) for d in delays])
+    a, L = math.ceil(start * sample_rate), math.ceil(duration * sample_rate)
+    out_len = int(C.lib().tsasr_mix_sources_out_len(off, dly, n, a, L))
+    out = torch.empty(out_len, dtype=torch.float32, device=src.device)
+    if out_len == 0:         # the window starts beyond the mixture: an empty slice, as in the reference
+        return out
+    ws = torch.empty(max(int(C.lib().tsasr_mix_sources_workspace_bytes()), 16), dtype=torch.uint8, device=src.device)
+    ratio = float(torch.tensor(10 ** (gain_nontarget / 10), dtype=torch.float32)) if gain_nontarget != 0 else 1.0
+    C.check(C.lib().tsasr_mix_sources(C.ptr(src), off, dly, n, int(target_speaker_idx), ratio, int(gain_nontarget != 0), a, L,
+                                      C.ptr(out), C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_mix_sources")
+    return out
+
+
 def trim_enroll(enroll_sig, trim_enroll_seconds, sample_rate=16000):
     return enroll_sig[: math.ceil(trim_enroll_seconds * sample_rate)]
 
@@ -180,12 +205,14 @@ def manifest_batches(json_path, hparams, data_folder=None, device="cpu"):
     (`sorting: ascending`) and grouped by DynamicBatchSampler when hparams has `max_batch_length`, else in fixed `batch_size` groups."""
     entries = load_manifest(json_path, {"data_folder": data_folder} if data_folder else None)
     sr = int(hparams.get("sample_rate", 16000))
+    on_device = torch.device(device).type == "cuda"      # the mixture is then built by the HIP kernel from the sources' device copies
     items = []
     for uid, e in entries.items():
         t = torch.load(e["tensors"])
-        mixed = mix_sources([s.float() for s in t["sigs"]], e["delays"], e.get("start", 0.0), e["duration"], e["target_speaker_idx"], sr,
-                            hparams.get("gain_nontarget", 0))
-        enroll = trim_enroll(t["enroll_sig"].float(), hparams.get("trim_enroll", 20.0), sr)
+        mix = mix_sources_device if on_device else mix_sources
+        mixed = mix([s.float().to(device) if on_device else s.float() for s in t["sigs"]], e["delays"], e.get("start", 0.0), e["duration"],
+                    e["target_speaker_idx"], sr, hparams.get("gain_nontarget", 0))
+        enroll = trim_enroll(t["enroll_sig"].float().to(device) if on_device else t["enroll_sig"].float(), hparams.get("trim_enroll", 20.0), sr)
         items.append({"id": uid, "duration": float(e["duration"]), "mixed_sig": mixed, "enroll_sig": enroll, "tokens": t["tokens"]})
     items.sort(key=lambda x: x["duration"])
     if hparams.get("max_batch_length"):

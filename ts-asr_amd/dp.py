@@ -348,11 +348,7 @@ class GradArena:
         if ops.wgrad_pending() == 0:
             self._send_completed()      # (an earlier flush may have finished a bucket's queued gradients before its last plain gradient came in)
             return
-        if self.device.type == "cuda":
-            cur = torch.cuda.current_stream()
-            for st in [self._main_stream] + list(self.aux_streams):
-                if st is not None and st != cur:
-                    cur.wait_stream(st)
+        self.join_streams()
         if hold:
             ops.wgrad_flush(hold=self._wgrad_hold)
             self._wgrad_held = True
@@ -361,6 +357,15 @@ class GradArena:
             if self._wgrad_held and release:    # held operands go only once every stream of the step has joined (finish_backward)
                 self._wgrad_held, self._wgrad_hold = False, []
         self._send_completed()
+
+    def join_streams(self):
+        """Order the current stream behind every stream of the step (main + forked branches): what a launch that consumes work queued from
+        several streams (grouped weight gradients, deferred d(pk) passes) needs before it goes out."""
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream()
+            for st in [self._main_stream] + list(self.aux_streams):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
 
     def _send_completed(self):
         """Buckets whose every contribution is in and whose queued weight gradients have been launched: all-reduce them now."""

@@ -155,6 +155,7 @@ def reduce_flush():
     """Run the queued reductions now (one launch); the parked workspaces are released afterwards (stream order keeps them valid)."""
     if not _DEFER["on"]:
         return
+    dpk_flush_joined()   # queued d(pk) passes read workspaces (dS, q + v, partials, key_lens) parked in _DEFER["keep"]: run them before the release
     _reduce_flush("tsasr_reduce_flush")
     _DEFER["keep"] = []
 
@@ -271,6 +272,19 @@ def dpk_flush():
     ring.launched(k)
 
 
+def dpk_flush_joined():
+    """dpk_flush from inside a backward node (a reader needs a queued pass's output now): the C-side queue is shared by every stream of
+    the step, so the launch is first ordered behind all of them (GradArena.join_streams) - a bare flush on the current stream could run
+    a pass queued by the other branch's backward before its producers have finished."""
+    if _DPK["ring"] is None or C.lib().tsasr_relpos_dpk_pending() == 0:
+        _DPK["outs"].clear()
+        return
+    sink = _GRAD_SINK
+    if sink is not None and getattr(sink, "in_backward", False) and hasattr(sink, "join_streams"):
+        sink.join_streams()
+    dpk_flush()
+
+
 def dpk_defer_end():
     if not _DPK["on"]:
         return
@@ -337,6 +351,10 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
     """C[M,N] (+)= op(A).op(B) on the hand-written MFMA kernel (csrc/gemm.hip); see include/tsasr_hip.h for the layouts."""
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    elif ldc is None:     # a caller-owned output may be a column range of a wider matrix: its row stride, not N
+        if out.dim() != 2 or out.stride(1) != 1:
+            raise ValueError("gemm_bf16: `out` must be a 2-D tensor with unit column stride")
+        ldc = out.stride(0)
     od = C.F32 if out.dtype == torch.float32 else C.BF16
     nws = C.lib().tsasr_gemm_bf16_workspace_bytes(M, N, K, od)
     ws = _ws(nws, a.device) if nws else None
@@ -436,7 +454,7 @@ class _LinearFn(torch.autograd.Function):
                 _wgrad_into(sink, weight, weight.grad.view(N, K), dy2, x2)                           # grad += dy^T . x
             else:
                 if dy.data_ptr() in _DPK["outs"] or dy2.data_ptr() in _DPK["outs"]:
-                    dpk_flush()     # dy is a deferred d(pk): the plain GEMM reads it now
+                    dpk_flush_joined()     # dy is a deferred d(pk): the plain GEMM reads it now
                 dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
         return dx, dw
 
@@ -497,7 +515,9 @@ def linear_cols(x, weight, bias, c0, n):
     return _LinearColsFn.apply(x, weight, bias, int(c0), int(n))
 
 
-_PTR_TABLES = {}     # device arrays of weight-shadow addresses for the batched projections, by the tuple of addresses
+# device arrays of weight-shadow addresses for the batched projections, by the tuple of addresses. Kept for the life of the process: a
+# captured step has the table's address baked into its batched-GEMM node (a few hundred bytes per distinct set of weights)
+_PTR_TABLES = {}
 
 
 class _ProjectManyFn(torch.autograd.Function):
@@ -535,7 +555,7 @@ class _ProjectManyFn(torch.autograd.Function):
                     _wgrad_into(sink, w, w.grad.view(N, K), dy2, x2)
                 else:
                     if dy.data_ptr() in _DPK["outs"] or dy2.data_ptr() in _DPK["outs"]:
-                        dpk_flush()
+                        dpk_flush_joined()
                     dw = gemm_bf16(dy2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(w.dtype).view(w.shape)
             grads.append(dw)
         return (None, None, *grads)
@@ -563,8 +583,6 @@ def project_many(x2, weights):
     if table is None:
         if torch.cuda.is_current_stream_capturing():
             return None
-        if len(_PTR_TABLES) > 64:
-            _PTR_TABLES.clear()
         table = _PTR_TABLES[key] = torch.tensor(ptrs, dtype=torch.int64).to(x2.device)
     return list(_ProjectManyFn.apply(x2, table, *weights))
 
@@ -641,8 +659,11 @@ def _wgrad_into(sink, weight, grad2d, dy2, x2, key=None):
         sink.wgrad_queued(weight)
         return
     if dy2.data_ptr() in _DPK["outs"]:
-        dpk_flush()     # dy2 is a deferred d(pk): the split-K GEMM below reads it now
-    gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, defer_ok=True)
+        dpk_flush_joined()     # dy2 is a deferred d(pk): the split-K GEMM below reads it now
+    # grad2d may be a column range of the weight's slot (_LinearColsFn): its rows are grad2d.stride(0) apart, and the slab-deferred
+    # accumulate form (contiguous output only) is not for it
+    gemm_bf16(dy2, x2, N, K, M, dy2.stride(0), x2.stride(0), 1, 1, out=grad2d, accumulate=True, ldc=grad2d.stride(0),
+              defer_ok=grad2d.stride(0) == K)
     sink.mark_ready(weight)
 
 
@@ -684,7 +705,7 @@ class _FFNFn(torch.autograd.Function):
         # the epilogue's mask words (keep-bits + sign of the stored activation, 2 bits per element) are kept for the backward when both of
         # its GEMMs take them: the data gradient then reads M*F1/4 bytes instead of the whole activation (2*M*F1) and hashes nothing
         mask = None
-        if _FFN_MASK and (slope >= 0 or p > 0) and F1 % 8 == 0 and fused_mask_ok(M, F1, D) and fused_mask_ok(M, F1, w2.shape[0]) \
+        if _FFN_MASK and (slope >= 0 or p > 0) and slope <= 1 and F1 % 8 == 0 and fused_mask_ok(M, F1, D) and fused_mask_ok(M, F1, w2.shape[0]) \
                 and _bf16_weight_t(w2) is not None:
             mask = torch.empty(M, F1 // 8, dtype=torch.int16, device=x2.device)
         h = gemm_bf16_fused(x2, w1h, M, F1, D, D, D, 0, 0, 1, bias=b1f, slope=slope, p=p, seed=seed, mask=mask)
@@ -1290,6 +1311,44 @@ def mean_pool(x, rel_lens):
     return _MeanPoolFn.apply(x, rel_lens)
 
 
+class _InjectFn(torch.autograd.Function):
+    """src [B,T,D] (+ | *) spk [B,1,D] - the `sum` / `prod` speaker-embedding injections (models/conformer.py:247-253) as one HIP launch
+    each way (tsasr_inject_fwd / _bwd) instead of ATen's broadcast op + its sum-to-size backward."""
+
+    @staticmethod
+    def forward(ctx, src, spk, mode):
+        C.require_gpu(src, spk)
+        srcc, spkc = src.contiguous(), spk.contiguous()
+        B, T, D = srcc.shape
+        out = torch.empty_like(srcc)
+        with prof.region("inject_fwd"):
+            C.check(C.lib().tsasr_inject_fwd(C.ptr(srcc), C.ptr(spkc), C.ptr(out), B, T, D, mode, C.io_dtype(srcc), C.stream_ptr()), "tsasr_inject_fwd")
+        ctx.save_for_backward(*((srcc, spkc) if mode == 1 else ()))
+        ctx.mode, ctx.shape = mode, (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D = ctx.shape
+        srcc, spkc = ctx.saved_tensors if ctx.mode == 1 else (None, None)
+        dout = dout.contiguous()
+        dsrc, dspk = torch.empty_like(dout), torch.empty(B, 1, D, dtype=dout.dtype, device=dout.device)
+        with prof.region("inject_bwd"):
+            C.check(C.lib().tsasr_inject_bwd(C.ptr(dout), C.ptr(srcc), C.ptr(spkc), C.ptr(dsrc), C.ptr(dspk), B, T, D, ctx.mode,
+                                             C.io_dtype(dout), C.stream_ptr()), "tsasr_inject_bwd")
+        return dsrc, dspk, None
+
+
+def inject_ok(src, spk):
+    return (src.is_cuda and src.dim() == 3 and spk.dim() == 3 and spk.shape[1] == 1 and spk.shape[0] == src.shape[0] and spk.shape[2] == src.shape[2]
+            and src.shape[2] % 8 == 0 and src.dtype == spk.dtype and src.dtype in (torch.float32, torch.bfloat16))
+
+
+def inject(src, spk, mode):
+    """mode "sum" | "prod" (see _InjectFn)."""
+    return _InjectFn.apply(src, spk, 1 if mode == "prod" else 0)
+
+
 def abs_lengths(rel, dim, mode=0):
     """int32 [B] absolute lengths from relative ones on the device, one launch: mode 0 = (rel * dim).round() (half to even, as
     torch.round: models/conformer.py:272, SB/nnet/losses.py:58-59), 1 = floor (SB/nnet/RNN.py:35), 2 = ceil clamped to dim."""
@@ -1684,7 +1743,7 @@ class _RelPosAttnFn(torch.autograd.Function):
             _keep(key_lens)               # the queued pass reads it at the flush, after autograd has released this node's saved tensors
             _DPK["outs"].add(dpk.data_ptr())    # whoever reads dpk outside the grouped weight-gradient launch flushes first (_LinearFn.backward)
         if _DPK["on"] and not defer:      # this call launches its own pass (queued ones first: the switch refuses to go off over a queue)
-            dpk_flush()
+            dpk_flush_joined()
             C.check(C.lib().tsasr_relpos_dpk_defer(0), "tsasr_relpos_dpk_defer")
         if ctx.keepbits is not None:
             C.lib().tsasr_relpos_attn_keepbits(C.ptr(ctx.keepbits))
@@ -1698,12 +1757,114 @@ class _RelPosAttnFn(torch.autograd.Function):
         return dqkv, dpk, _pgrad(pu, du), _pgrad(pv, dv), None, None, None, None, None, None, None
 
 
+ATTN_F32_EXACT = True     # fp32 activations: attention in exact fp32 arithmetic (csrc/attention_f32.hip). False: the MFMA kernels with fp32
+                          # storage and bf16-rounded operands (tests that cover that instantiation switch it off)
+
+
+def _strides9(q, k, v, H):
+    """{batch, row, head} element strides of three [B, T, H*Dh]-shaped views whose last dim is a contiguous run of H heads."""
+    import ctypes
+    out = []
+    for t in (q, k, v):
+        Dh = t.shape[-1] // H
+        if t.stride(-1) != 1:
+            raise ValueError("attention operands need unit stride along the feature dim")
+        out += [t.stride(0), t.stride(1), Dh if getattr(t, "_head_stride", None) is None else t._head_stride]
+    return (ctypes.c_longlong * 9)(*out)
+
+
+class _AttnF32Fn(torch.autograd.Function):
+    """softmax(scale * ((q+u).k^T [+ (q+v).p_rel^T]) + masks) . v in exact fp32 arithmetic (tsasr_attn_f32_*), io dtype fp32 or bf16.
+    q [B,Tq,H*Dh], k / v [B,Tk,H*Dh] are (possibly strided) views; with ``pk`` [2T-1, H*Dh] it is RelPosMHAXL's core
+    (SB/nnet/attention.py:586-633), without it torch.nn.MultiheadAttention's (the `cross_attention` injection). hs* = head strides."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed, hsq, hsk, hsv):
+        import ctypes
+        C.require_gpu(q, k, v)
+        B, Tq, D = q.shape
+        Tk, Dh = k.shape[1], D // H
+        st = (ctypes.c_longlong * 9)(q.stride(0), q.stride(1), hsq, k.stride(0), k.stride(1), hsk, v.stride(0), v.stride(1), hsv)
+        u = None if pos_bias_u is None else _f32(pos_bias_u).reshape(-1).contiguous()     # (Dh,H) storage read as [H,Dh]
+        vb = None if pos_bias_v is None else _f32(pos_bias_v).reshape(-1).contiguous()
+        pkc = None if pk is None else pk.contiguous()
+        out = torch.empty(B, Tq, D, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+        with prof.region("attn_f32_fwd"):
+            C.check(C.lib().tsasr_attn_f32_fwd(C.ptr(q), C.ptr(k), C.ptr(v), st, C.ptr(pkc), C.ptr(u), C.ptr(vb), C.ptr(key_lens), C.ptr(out),
+                                               C.ptr(lse), B, Tq, Tk, H, Dh, float(scale), int(causal), float(pdrop), seed,
+                                               C.ptr(seed_state(q.device)), C.io_dtype(q), C.stream_ptr()), "tsasr_attn_f32_fwd")
+        ctx.save_for_backward(q, k, v, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
+        ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed, int(hsq), int(hsk), int(hsv))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        q, k, v, pkc, pu, pv, key_lens, out, lse = ctx.saved_tensors
+        H, scale, causal, pdrop, seed, hsq, hsk, hsv = ctx.cfg
+        B, Tq, D = q.shape
+        Tk, Dh = k.shape[1], D // H
+        st = (ctypes.c_longlong * 9)(q.stride(0), q.stride(1), hsq, k.stride(0), k.stride(1), hsk, v.stride(0), v.stride(1), hsv)
+        # gradients are laid out like their operands: when q, k, v are the three column groups of ONE interleaved qkv tensor the caller
+        # gets views of one dqkv tensor back (autograd adds nothing: the three slices are disjoint)
+        base = getattr(q, "_base", None)
+        if base is not None and base is getattr(k, "_base", None) and base is getattr(v, "_base", None) and base.is_contiguous():
+            dbase = torch.empty_like(base)
+            dq = dbase.as_strided(q.shape, q.stride(), q.storage_offset() - base.storage_offset())
+            dk = dbase.as_strided(k.shape, k.stride(), k.storage_offset() - base.storage_offset())
+            dv = dbase.as_strided(v.shape, v.stride(), v.storage_offset() - base.storage_offset())
+            dst = st
+        else:
+            dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
+            dst = (ctypes.c_longlong * 9)(dq.stride(0), dq.stride(1), Dh, dk.stride(0), dk.stride(1), Dh, dv.stride(0), dv.stride(1), Dh)
+        dout = dout.contiguous()
+        u = None if pu is None else _f32(pu).reshape(-1).contiguous()
+        vb = None if pv is None else _f32(pv).reshape(-1).contiguous()
+        dpk = None if pkc is None else torch.empty_like(pkc)
+        du = None if pu is None else torch.empty(H * Dh, dtype=torch.float32, device=q.device)
+        dvb = None if pv is None else torch.empty(H * Dh, dtype=torch.float32, device=q.device)
+        _keep(du, dvb)
+        ws = _ws(C.lib().tsasr_attn_f32_bwd_workspace_bytes(B, Tq, Tk, H, Dh), q.device)
+        with prof.region("attn_f32_bwd"):
+            C.check(C.lib().tsasr_attn_f32_bwd(C.ptr(q), C.ptr(k), C.ptr(v), st, C.ptr(pkc), C.ptr(u), C.ptr(vb), C.ptr(key_lens), C.ptr(out),
+                                               C.ptr(dout), C.ptr(lse), C.ptr(dq), C.ptr(dk), C.ptr(dv), dst, C.ptr(dpk), C.ptr(du), C.ptr(dvb),
+                                               B, Tq, Tk, H, Dh, scale, causal, pdrop, seed, C.ptr(seed_state(q.device)), C.io_dtype(q),
+                                               C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_attn_f32_bwd")
+        return (dq, dk, dv, dpk, None if pu is None else _pgrad(pu, du), None if pv is None else _pgrad(pv, dvb), None, None, None, None,
+                None, None, None, None, None)
+
+
+def attention_f32(q, k, v, H, scale, key_lens=None, causal=False, dropout_p=0.0, pk=None, pos_bias_u=None, pos_bias_v=None,
+                  head_strides=None):
+    """Exact-fp32 attention on (possibly strided) [B,T,H*Dh] views (see _AttnF32Fn); head_strides default to Dh (heads side by side)."""
+    Dh = q.shape[-1] // H
+    hsq, hsk, hsv = head_strides if head_strides is not None else (Dh, Dh, Dh)
+    p = float(dropout_p)
+    return _AttnF32Fn.apply(q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0, hsq, hsk, hsv)
+
+
+def _relpos_attention_f32(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p):
+    """RelPosMHAXL's core on the interleaved qkv [B,T,H,(Q|K|V)*Dh] tensor through the exact-fp32 kernels."""
+    B, T, D3 = qkv.shape
+    Dh = D3 // 3 // H
+    qkvc = qkv.contiguous()
+    D = H * Dh
+
+    def view(off):     # [B, T, H*Dh]-shaped strided window: head h at column h * 3Dh + off
+        return qkvc.as_strided((B, T, D), (T * D3, D3, 1), qkvc.storage_offset() + off)
+    return attention_f32(view(0), view(Dh), view(2 * Dh), H, scale, key_lens, causal, dropout_p, pk, pos_bias_u, pos_bias_v,
+                         head_strides=(3 * Dh, 3 * Dh, 3 * Dh))
+
+
 def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights, dpk_deferrable=False):
     """Fused HIP kernels (forward and backward) unless the caller wants the [B,H,T,T] weights back (plots only). ``dpk_deferrable``:
     the caller made ``pk`` with ops.matmul_nt on the HIP GEMM path and nothing else reads its gradient (see _RelPosAttnFn.backward)."""
     if need_weights:
         return _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights)
     p = float(dropout_p)
+    if ATTN_F32_EXACT and qkv.dtype == torch.float32:      # compute_dtype fp32 = the parity mode: no operand is rounded to bf16
+        return _relpos_attention_f32(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p), None
     return _RelPosAttnFn.apply(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0, dpk_deferrable), None
 
 

@@ -107,7 +107,8 @@ def stamp(name):
     from . import _capi as C
     k = len(_stamp_names)
     _stamp_names.append(name)
-    C.check(C.lib().tsasr_debug_stamp(C.ptr(_stamp_buf[k:k + 1]), C.stream_ptr()), "tsasr_debug_stamp")
+    if C.lab().tsasr_lab_stamp(C.ptr(_stamp_buf[k:k + 1]), C.stream_ptr()) != 0:      # lab equipment (include/tsasr_lab.h), tools only
+        raise C.TsasrHipError("tsasr_lab_stamp failed")
 
 
 def stamps_us():

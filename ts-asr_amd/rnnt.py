@@ -12,6 +12,12 @@ from . import _capi as C
 from . import prof
 
 _LDL = 32  # logits rows are padded to 32 floats (128 B) so that every row access is a 16-byte multiple
+JOINT_F32_EXACT = True   # fp32 activations: joint + head in exact fp32 arithmetic (csrc/joint_f32.hip). False: the MFMA kernels with fp32
+                         # storage and bf16-rounded operands (tests that cover that instantiation switch it off)
+
+
+def _exact(enc, J, V):
+    return JOINT_F32_EXACT and enc.dtype == torch.float32 and J <= 768 and V <= 32
 
 
 def _ws(nbytes, device):
@@ -30,9 +36,14 @@ class _JointLogitsFn(torch.autograd.Function):
         U1 = dec.shape[1]
         V = w32.shape[0]
         buf = torch.empty(B, T, U1, _LDL, dtype=torch.float32, device=enc.device)
+        ctx.exact = _exact(enc, J, V)
         with prof.region("joint_fwd"):
-            C.check(C.lib().tsasr_joint_fwd(C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(b32), C.ptr(buf), B, T, U1, J, V, _LDL,
-                                            C.io_dtype(enc), float(slope), C.stream_ptr()), "tsasr_joint_fwd")
+            if ctx.exact:
+                C.check(C.lib().tsasr_joint_f32_fwd(C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(b32), C.ptr(buf), B, T, U1, J, V, _LDL,
+                                                    float(slope), C.stream_ptr()), "tsasr_joint_f32_fwd")
+            else:
+                C.check(C.lib().tsasr_joint_fwd(C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(b32), C.ptr(buf), B, T, U1, J, V, _LDL,
+                                                C.io_dtype(enc), float(slope), C.stream_ptr()), "tsasr_joint_fwd")
         ctx.save_for_backward(enc, dec, w32, tlen, ulen)
         ctx.slope, ctx.V = float(slope), V
         ctx.params = (weight, bias)
@@ -47,10 +58,15 @@ class _JointLogitsFn(torch.autograd.Function):
         denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
         dW = torch.empty(V, J, dtype=torch.float32, device=enc.device)
         db = torch.empty(V, dtype=torch.float32, device=enc.device)
-        nws = C.lib().tsasr_joint_bwd_workspace_bytes(B, T, U1, J)
+        nws = C.lib().tsasr_joint_f32_bwd_workspace_bytes(B, U1, J) if ctx.exact else C.lib().tsasr_joint_bwd_workspace_bytes(B, T, U1, J)
         ws = _ws(nws, enc.device)
         with prof.region("joint_bwd"):
-            C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
+            if ctx.exact:
+                C.check(C.lib().tsasr_joint_f32_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
+                                                    C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), ctx.slope,
+                                                    C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_f32_bwd")
+            else:
+              C.check(C.lib().tsasr_joint_bwd(C.ptr(dl), C.ptr(enc), C.ptr(dec), C.ptr(w32), C.ptr(denc), C.ptr(ddec), C.ptr(dW), C.ptr(db),
                                             C.ptr(tlen), C.ptr(ulen), B, T, U1, J, V, dl.stride(-2), C.io_dtype(enc), ctx.slope,
                                             C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_joint_bwd")
         from .ops import _keep, _pgrad
