@@ -411,9 +411,8 @@ def test_attention_exact_fp32_dropout_and_cross_shapes(ops):
     dout = torch.randn(B, Tn, D, generator=g).to(DEV)
 
     def run(x, seed):
-        Bx, Tx, D3 = x.shape
-        view = lambda off: x.as_strided((Bx, Tx, D), (Tx * D3, D3, 1), x.storage_offset() + off)   # noqa: E731
-        return ops._AttnF32Fn.apply(view(0), view(Dh), view(2 * Dh), pk, u, v, None, H, 1.0 / D ** 0.5, 0, 0.3, seed, 3 * Dh, 3 * Dh, 3 * Dh)
+        x4 = x.view(x.shape[0], x.shape[1], H, 3 * Dh)
+        return ops._AttnF32Fn.apply(x4[..., :Dh], x4[..., Dh:2 * Dh], x4[..., 2 * Dh:], pk, u, v, None, H, 1.0 / D ** 0.5, 0, 0.3, seed)
     x = qkv.clone().requires_grad_()
     out = run(x, 1234)
     out.backward(dout)
@@ -441,7 +440,8 @@ def test_attention_exact_fp32_dropout_and_cross_shapes(ops):
     ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, Tq, D)
     ref.backward(do.double())
     qg, kvg = q.to(DEV).requires_grad_(), kv.to(DEV).requires_grad_()
-    o = ops.attention_f32(qg, kvg[..., :D], kvg[..., D:], H, 1.0 / Dh ** 0.5, lens.to(DEV), False, 0.0)
+    kv5 = kvg.view(B, Tk, 2, H, Dh)
+    o = ops.attention_f32(qg.view(B, Tq, H, Dh), kv5[:, :, 0], kv5[:, :, 1], H, 1.0 / Dh ** 0.5, lens.to(DEV), False, 0.0)
     o.backward(do.to(DEV))
     for got, want, name in ((o, ref, "out"), (qg.grad, qd.grad, "dq"), (kvg.grad, kvd.grad, "dkv")):
         rel = float((got.detach().double().cpu() - want.detach()).norm() / want.detach().norm())

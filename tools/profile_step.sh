@@ -12,5 +12,7 @@ cd $R
 db=$(find $O/prof -name "*.db" | head -1)
 python tools/trace_summary.py $db --steps 17 --top 80 > $O/trace_summary.txt
 python tools/stream_timeline.py $db --names > $O/timeline.txt 2>&1 || true
+python tools/stream_timeline.py $db --dump 2.60 2.90 > $O/dump_fwd_layer.txt 2>&1 || true      # one mixture layer forward ...
+python tools/stream_timeline.py $db --dump 5.20 5.60 > $O/dump_bwd_layer.txt 2>&1 || true      # ... and backward, kernel by kernel
 rm -rf $O/prof
 tail -4 $O/bench_prof.log | cut -c1-300

@@ -49,8 +49,8 @@ class _SpeakerAttention(nn.Module):
         q = ops.linear(src, w[:D], b[:D]).view(B, T, H, D // H).transpose(1, 2)
         kv = ops.linear(_cd(spk), w[D:], b[D:]).view(B, S, 2, H, D // H)
         if D // H <= 64:    # scores, softmax, dropout, .V in one HIP kernel each way (csrc/attention_f32.hip, exact fp32 arithmetic)
-            qf, kvf = q.transpose(1, 2).reshape(B, T, D), kv.view(B, S, 2 * D)
-            o = ops.attention_f32(qf, kvf[..., :D], kvf[..., D:], H, 1.0 / (D // H) ** 0.5, key_lens, False, self.dropout if self.training else 0.0)
+            o = ops.attention_f32(q.transpose(1, 2), kv[:, :, 0], kv[:, :, 1], H, 1.0 / (D // H) ** 0.5, key_lens, False,
+                                  self.dropout if self.training else 0.0)     # [B,T,H,Dh] / [B,S,H,Dh] strided views
             return ops.linear(o, self.att.out_proj.weight, self.att.out_proj.bias)
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         s = torch.matmul(q, k.transpose(-1, -2)).float() / (D // H) ** 0.5

@@ -464,7 +464,7 @@ __device__ __forceinline__ void ring_wait_landed(int younger_tiles, int lpt) {
 }
 
 // the loader waves' whole life: fill the ring for k-tiles [0, nk)
-template <typename TA, typename TB>
+template <typename TA, typename TB, int ST = RING_STAGES>
 __device__ __forceinline__ void ring_loader(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, long long lda, long long ldb, int m0, int M,
                                             int n0, int N, int kbeg, int nk, char *smem, int cw, int lane) {
     constexpr int SLOT = TA::BYTES + TB::BYTES;
@@ -475,23 +475,23 @@ __device__ __forceinline__ void ring_loader(const bf16_t *__restrict__ A, const 
     TB::src_ptrs(B, ldb, n0, N, kbeg, cw, lane, gb);
     const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
 #pragma unroll
-    for (int t = 0; t < RING_STAGES - 1; ++t)
+    for (int t = 0; t < ST - 1; ++t)
         if (t < nk) {
             TA::issue_at(ga, t * a_step, smem + t * SLOT, cw);
             TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, cw);
         }
     for (int kt = 0; kt < nk; ++kt) {
-        ring_wait_landed(min(RING_STAGES - 2, nk - 1 - kt), LPT);
+        ring_wait_landed(min(ST - 2, nk - 1 - kt), LPT);
         __builtin_amdgcn_s_barrier();
-        if (kt + RING_STAGES - 1 < nk) {
-            char *slot = smem + ((kt + RING_STAGES - 1) % RING_STAGES) * SLOT;
-            TA::issue_at(ga, (kt + RING_STAGES - 1) * a_step, slot, cw);
-            TB::issue_at(gb, (kt + RING_STAGES - 1) * b_step, slot + TA::BYTES, cw);
+        if (kt + ST - 1 < nk) {
+            char *slot = smem + ((kt + ST - 1) % ST) * SLOT;
+            TA::issue_at(ga, (kt + ST - 1) * a_step, slot, cw);
+            TB::issue_at(gb, (kt + ST - 1) * b_step, slot + TA::BYTES, cw);
         }
     }
 }
 
-template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
+template <int BM, int BN, bool AT, bool BT, int OUT_MODE, int ST = RING_STAGES>
 __global__ __launch_bounds__(RING_THREADS, 1) void gemm_bf16_ring_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, void *__restrict__ Cv,
                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int kchunk,
                                                                 long long slab_stride, int nsplit, EpiArgs ep) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(RING_THREADS, 1) void gemm_bf16_ring_kernel(const b
         Cv = reinterpret_cast<bf16_t *>(Cv) + (long long)blockIdx.y * ep.c_batch;
     }
     if (wave8 >= 4) {
-        ring_loader<TA, TB>(A, Bm, lda, ldb, m0, M, n0, N, kbeg, nk, smem, wave, lane);
+        ring_loader<TA, TB, ST>(A, Bm, lda, ldb, m0, M, n0, N, kbeg, nk, smem, wave, lane);
         __builtin_amdgcn_s_barrier();     // pairs with the compute waves' barrier in front of the epilogue
         return;
     }
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(RING_THREADS, 1) void gemm_bf16_ring_kernel(const b
     }
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_barrier();                 // the loaders' pieces of tile kt have landed
-        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        const char *as = smem + (kt % ST) * SLOT, *bs = as + TA::BYTES;
         // every fragment read of the k-tile is in flight before the first MFMA needs one (one wave per SIMD computes: nothing else hides
         // the LDS latency; read-per-k16-step cost 1.4 us of the 14.4 at K = 2048)
         bf16x8 af[RB][GB_K / 16], bfr[CB][GB_K / 16];
@@ -1145,6 +1145,7 @@ int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, i
                           const unsigned long long *seed_dev, float *colpart, void *mask, hipStream_t st);
 
 static int g_use_ring = 1;   // 0: never, 1: long K or small tiles, 2: always
+static int g_ring_deep = getenv("TSASR_RING_DEEP") ? atoi(getenv("TSASR_RING_DEEP")) : 0;
 // 128x64 nn bf16 tile: ring slots / wave-K split / lab floor mode of gemm_nn128x64_kernel; stages 0 = the generic ring kernel
 static int g_nn128_stages = 0, g_nn128_wavek = 0, g_nn128_floor = 0;
 
@@ -1216,6 +1217,23 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
             case 630: launch_nn128x64_ws<6>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
             default: break;
             }
+        }
+    }
+    if constexpr (BM == 128 && BN == 64 && !AT && OUT_MODE == 0) {
+        // the step's N = 256 projections: one workgroup per CU whatever the ring size, operands mostly from beyond L2 (the activation the
+        // previous kernel wrote): g_ring_deep slots keep more bytes in flight per CU (TSASR_RING_DEEP; 0 = the 3-slot ring)
+        if (ring && g_ring_deep >= 4 && grid.x <= 2 * 256) {
+            constexpr int SLOTB = RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES;
+            if (g_ring_deep >= 6) {
+                auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE, 6>;
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * SLOTB);
+                kern<<<grid, RING_THREADS, 6 * SLOTB, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
+            } else {
+                auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE, 4>;
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOTB);
+                kern<<<grid, RING_THREADS, 4 * SLOTB, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
+            }
+            return;
         }
     }
     if (ring) {

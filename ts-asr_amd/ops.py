@@ -1761,30 +1761,28 @@ ATTN_F32_EXACT = True     # fp32 activations: attention in exact fp32 arithmetic
                           # storage and bf16-rounded operands (tests that cover that instantiation switch it off)
 
 
-def _strides9(q, k, v, H):
-    """{batch, row, head} element strides of three [B, T, H*Dh]-shaped views whose last dim is a contiguous run of H heads."""
+def _strides9(q, k, v):
+    """{batch, row, head} element strides of three [B, T, H, Dh] views with unit stride along Dh (HOST array for tsasr_attn_f32_*)."""
     import ctypes
     out = []
     for t in (q, k, v):
-        Dh = t.shape[-1] // H
-        if t.stride(-1) != 1:
-            raise ValueError("attention operands need unit stride along the feature dim")
-        out += [t.stride(0), t.stride(1), Dh if getattr(t, "_head_stride", None) is None else t._head_stride]
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise ValueError("attention operands must be [B, T, H, Dh] views with unit stride along Dh")
+        out += [t.stride(0), t.stride(1), t.stride(2)]
     return (ctypes.c_longlong * 9)(*out)
 
 
 class _AttnF32Fn(torch.autograd.Function):
     """softmax(scale * ((q+u).k^T [+ (q+v).p_rel^T]) + masks) . v in exact fp32 arithmetic (tsasr_attn_f32_*), io dtype fp32 or bf16.
-    q [B,Tq,H*Dh], k / v [B,Tk,H*Dh] are (possibly strided) views; with ``pk`` [2T-1, H*Dh] it is RelPosMHAXL's core
-    (SB/nnet/attention.py:586-633), without it torch.nn.MultiheadAttention's (the `cross_attention` injection). hs* = head strides."""
+    q [B,Tq,H,Dh], k / v [B,Tk,H,Dh] are (possibly strided) views; with ``pk`` [2T-1, H*Dh] it is RelPosMHAXL's core
+    (SB/nnet/attention.py:586-633), without it torch.nn.MultiheadAttention's (the `cross_attention` injection). Returns [B,Tq,H*Dh]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed, hsq, hsk, hsv):
-        import ctypes
+    def forward(ctx, q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, pdrop, seed):
         C.require_gpu(q, k, v)
-        B, Tq, D = q.shape
-        Tk, Dh = k.shape[1], D // H
-        st = (ctypes.c_longlong * 9)(q.stride(0), q.stride(1), hsq, k.stride(0), k.stride(1), hsk, v.stride(0), v.stride(1), hsv)
+        B, Tq, _, Dh = q.shape
+        Tk, D = k.shape[1], H * Dh
+        st = _strides9(q, k, v)
         u = None if pos_bias_u is None else _f32(pos_bias_u).reshape(-1).contiguous()     # (Dh,H) storage read as [H,Dh]
         vb = None if pos_bias_v is None else _f32(pos_bias_v).reshape(-1).contiguous()
         pkc = None if pk is None else pk.contiguous()
@@ -1795,29 +1793,18 @@ class _AttnF32Fn(torch.autograd.Function):
                                                C.ptr(lse), B, Tq, Tk, H, Dh, float(scale), int(causal), float(pdrop), seed,
                                                C.ptr(seed_state(q.device)), C.io_dtype(q), C.stream_ptr()), "tsasr_attn_f32_fwd")
         ctx.save_for_backward(q, k, v, pkc, pos_bias_u, pos_bias_v, key_lens, out, lse)
-        ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed, int(hsq), int(hsk), int(hsv))
+        ctx.cfg = (H, float(scale), int(causal), float(pdrop), seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        import ctypes
         q, k, v, pkc, pu, pv, key_lens, out, lse = ctx.saved_tensors
-        H, scale, causal, pdrop, seed, hsq, hsk, hsv = ctx.cfg
-        B, Tq, D = q.shape
-        Tk, Dh = k.shape[1], D // H
-        st = (ctypes.c_longlong * 9)(q.stride(0), q.stride(1), hsq, k.stride(0), k.stride(1), hsk, v.stride(0), v.stride(1), hsv)
-        # gradients are laid out like their operands: when q, k, v are the three column groups of ONE interleaved qkv tensor the caller
-        # gets views of one dqkv tensor back (autograd adds nothing: the three slices are disjoint)
-        base = getattr(q, "_base", None)
-        if base is not None and base is getattr(k, "_base", None) and base is getattr(v, "_base", None) and base.is_contiguous():
-            dbase = torch.empty_like(base)
-            dq = dbase.as_strided(q.shape, q.stride(), q.storage_offset() - base.storage_offset())
-            dk = dbase.as_strided(k.shape, k.stride(), k.storage_offset() - base.storage_offset())
-            dv = dbase.as_strided(v.shape, v.stride(), v.storage_offset() - base.storage_offset())
-            dst = st
-        else:
-            dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
-            dst = (ctypes.c_longlong * 9)(dq.stride(0), dq.stride(1), Dh, dk.stride(0), dk.stride(1), Dh, dv.stride(0), dv.stride(1), Dh)
+        H, scale, causal, pdrop, seed = ctx.cfg
+        B, Tq, _, Dh = q.shape
+        Tk = k.shape[1]
+        st = _strides9(q, k, v)
+        dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))     # contiguous [B,T,H,Dh]
+        dst = _strides9(dq, dk, dv)
         dout = dout.contiguous()
         u = None if pu is None else _f32(pu).reshape(-1).contiguous()
         vb = None if pv is None else _f32(pv).reshape(-1).contiguous()
@@ -1832,29 +1819,21 @@ class _AttnF32Fn(torch.autograd.Function):
                                                B, Tq, Tk, H, Dh, scale, causal, pdrop, seed, C.ptr(seed_state(q.device)), C.io_dtype(q),
                                                C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_attn_f32_bwd")
         return (dq, dk, dv, dpk, None if pu is None else _pgrad(pu, du), None if pv is None else _pgrad(pv, dvb), None, None, None, None,
-                None, None, None, None, None)
+                None, None)
 
 
-def attention_f32(q, k, v, H, scale, key_lens=None, causal=False, dropout_p=0.0, pk=None, pos_bias_u=None, pos_bias_v=None,
-                  head_strides=None):
-    """Exact-fp32 attention on (possibly strided) [B,T,H*Dh] views (see _AttnF32Fn); head_strides default to Dh (heads side by side)."""
-    Dh = q.shape[-1] // H
-    hsq, hsk, hsv = head_strides if head_strides is not None else (Dh, Dh, Dh)
+def attention_f32(q, k, v, H, scale, key_lens=None, causal=False, dropout_p=0.0, pk=None, pos_bias_u=None, pos_bias_v=None):
+    """Exact-fp32 attention on [B,T,H,Dh] views (see _AttnF32Fn); returns the context as [B,Tq,H*Dh]."""
     p = float(dropout_p)
-    return _AttnF32Fn.apply(q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0, hsq, hsk, hsv)
+    return _AttnF32Fn.apply(q, k, v, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, p, next_seed() if p > 0 else 0)
 
 
 def _relpos_attention_f32(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p):
-    """RelPosMHAXL's core on the interleaved qkv [B,T,H,(Q|K|V)*Dh] tensor through the exact-fp32 kernels."""
+    """RelPosMHAXL's core on the interleaved qkv [B,T,H*(Q|K|V)*Dh] tensor through the exact-fp32 kernels."""
     B, T, D3 = qkv.shape
     Dh = D3 // 3 // H
-    qkvc = qkv.contiguous()
-    D = H * Dh
-
-    def view(off):     # [B, T, H*Dh]-shaped strided window: head h at column h * 3Dh + off
-        return qkvc.as_strided((B, T, D), (T * D3, D3, 1), qkvc.storage_offset() + off)
-    return attention_f32(view(0), view(Dh), view(2 * Dh), H, scale, key_lens, causal, dropout_p, pk, pos_bias_u, pos_bias_v,
-                         head_strides=(3 * Dh, 3 * Dh, 3 * Dh))
+    x = qkv.view(B, T, H, 3 * Dh) if qkv.is_contiguous() else qkv.contiguous().view(B, T, H, 3 * Dh)
+    return attention_f32(x[..., :Dh], x[..., Dh:2 * Dh], x[..., 2 * Dh:], H, scale, key_lens, causal, dropout_p, pk, pos_bias_u, pos_bias_v)
 
 
 def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights, dpk_deferrable=False):
