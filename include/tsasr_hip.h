@@ -269,7 +269,7 @@ int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, floa
  *   fp32 gradient arena (long inner dimensions are split into fp32 slabs in `workspace`, summed in a fixed order).
  * ------------------------------------------------------------------------------------------ */
 void tsasr_gemm_set_ring(int on);                 /* 1 (default): LDS-DMA ring main loop for long inner dimensions; 2: whenever K % 64 == 0; 0: register-staged loop (A/B tests) */
-void tsasr_gemm_set_nn128(int stages, int wavek, int floor_mode);   /* tuning / lab: main loop of the 128x64 bf16 tile (csrc/gemm.hip gemm_nn128x64_kernel); 0,0,0 = default */
+void tsasr_gemm_set_lab_floor(int floor_mode);   /* lab (tools/gemm_bench.py --floors): -1 off; 0/1/2 = round-3 four-wave loop / its DMA ring alone / its MFMA part alone */
 void tsasr_gemm_set_plan(int tile, int splits);   /* A/B tests only: force macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64, -1 = automatic) and split-K */
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype);
 int tsasr_gemm_bf16(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc,

@@ -2,8 +2,9 @@
 """Micro-benchmark of csrc/gemm.hip at the model's shapes (interleaved rounds in one process, each timing = 20 launches captured into one
 hipGraph). `lib` = torch.matmul (hipBLASLt / rocBLAS) on the same operands: a YARDSTICK only, never dispatched by the package.
   python tools/gemm_bench.py            the shapes of the step, default kernels vs the library
-  python tools/gemm_bench.py --nn128    main-loop variants of the 128x64 tile (ring slots x wave-K split) and its lab floors (LDS-DMA ring
-                                        alone / fragment reads + MFMA alone) at the N = 256 shapes of the step"""
+  python tools/gemm_bench.py --floors   the 128x64 tile's lab floors (round-3 four-wave loop; its LDS-DMA ring alone; its fragment reads +
+                                        MFMA alone) beside the product kernel (loader waves) at the N = 256 shapes of the step
+  python tools/gemm_bench.py --chain    the FFN as the step runs it: up-projection -> down-projection, operand from beyond L2"""
 import importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -43,32 +44,63 @@ def operands(M, N, K, ta, tb, f32):
     return A, B, out
 
 
-if "--nn128" in sys.argv:
-    variants = [(0, 0, 0), (4, 0, 0), (4, 2, 0), (3, 3, 0), (4, 3, 0), (5, 3, 0), (6, 3, 0), (4, 0, 1), (4, 0, 2), (4, 2, 2)]
-    for (M, N, K) in [(8000, 256, 2048), (8000, 256, 256), (8000, 256, 768), (8000, 768, 256), (8000, 512, 256), (4000, 256, 2048)]:
+if "--floors" in sys.argv:
+    # lab floors of the 128x64 tile (csrc/gemm.hip gemm_nn128x64_lab_kernel): the round-3 four-wave loop, its DMA ring alone, its
+    # fragment reads + MFMA alone, against the product kernel (loader waves) and the library - profiles/r04_notes.md section 1
+    for (M, N, K) in [(8000, 256, 2048), (8000, 256, 768), (8000, 256, 256), (4000, 256, 2048)]:
         A, B, out = operands(M, N, K, 0, 0, 0)
-        C.lib().tsasr_gemm_set_plan(1, 1)         # force the 128x64 tile for every shape of this sweep
+        C.lib().tsasr_gemm_set_plan(1, 1)         # the 128x64 tile for every shape of this sweep
         ref = (A.float() @ B.float().t())
-        best = {v: 1e9 for v in variants}
         fn = lambda: ops.gemm_bf16(A, B, M, N, K, K, K, 0, 0, out=out)
+        modes = [(-1, "product kernel: 4 compute + 4 loader waves"), (0, "round-3 loop: 4 waves load AND compute"), (1, "FLOOR: its LDS-DMA ring alone"),
+                 (2, "FLOOR: its fragment reads + MFMA alone")]
+        best = {m: 1e9 for m, _ in modes}
         for rnd in range(3):
-            for v in variants:
-                C.lib().tsasr_gemm_set_nn128(*v)
-                best[v] = min(best[v], timeit(fn))
-        libt = min(timeit(lambda: torch.matmul(A, B.t())) for _ in range(2))
+            for m, _ in modes:
+                C.lib().tsasr_gemm_set_lab_floor(m)
+                best[m] = min(best[m], timeit(fn))
         errs = {}
-        for v in variants:
-            if v[2] == 0:
-                C.lib().tsasr_gemm_set_nn128(*v); out.zero_(); fn(); torch.cuda.synchronize()
-                errs[v] = float((out.float() - ref).norm() / ref.norm())
-        C.lib().tsasr_gemm_set_nn128(0, 0, 0); C.lib().tsasr_gemm_set_plan(-1, 0)
+        for m in (-1, 0):
+            C.lib().tsasr_gemm_set_lab_floor(m); out.zero_(); fn(); torch.cuda.synchronize()
+            errs[m] = float((out.float() - ref).norm() / ref.norm())
+        C.lib().tsasr_gemm_set_lab_floor(-1); C.lib().tsasr_gemm_set_plan(-1, 0)
+        libt = min(timeit(lambda: torch.matmul(A, B.t())) for _ in range(2))
         fl = 2.0 * M * N * K
         ingest = (128 + 64) * K * 2.0      # bytes one workgroup pulls through L2 -> LDS
-        print(f"M={M} N={N} K={K}: {fl/1e9:.2f} GFLOP, {ingest/1e3:.0f} KB per workgroup through the LDS-DMA path; lib (yardstick) {libt:6.1f} us")
-        for v in variants:
-            tag = {0: "gemm ", 1: "FLOOR dma only", 2: "FLOOR mfma only"}[v[2]] + {0: "", 1: " wave-K", 2: " reg-pipe", 3: " loader waves"}[v[1]]
-            extra = f"rel.err {errs[v]:.1e}" if v in errs else f"{ingest/best[v]/1e3:6.1f} GB/s per CU" if v[2] == 1 else ""
-            print(f"   stages={v[0]} wavek={v[1]} {tag:26s} {best[v]:6.1f} us {fl/best[v]/1e6:7.1f} TF  {extra}")
+        print(f"M={M} N={N} K={K}: {fl/1e9:.2f} GFLOP, {ingest/1e3:.0f} KB per workgroup through the LDS-DMA path; library (yardstick only) {libt:6.1f} us")
+        for m, tag in modes:
+            extra = f"rel.err {errs[m]:.1e}" if m in errs else (f"{ingest/best[m]/1e3:6.1f} GB/s per CU" if m == 1 else "")
+            print(f"   {tag:46s} {best[m]:6.1f} us {fl/best[m]/1e6:7.1f} TF  {extra}")
+    sys.exit(0)
+
+if "--chain" in sys.argv:
+    # the FFN as the step runs it: up-projection (writes the 32.8 MB hidden activation) -> down-projection (reads it), 20 pairs per graph:
+    # the down-projection's A operand comes from beyond L2, as in the step, not from an L2 that the previous replay left hot
+    M, F1, D = 8000, 2048, 256
+    x = torch.randn(M, D, device=DEV).to(torch.bfloat16); w1 = torch.randn(F1, D, device=DEV).to(torch.bfloat16)
+    b1 = torch.randn(F1, device=DEV); w2 = torch.randn(D, F1, device=DEV).to(torch.bfloat16)
+    hs = [torch.empty(M, F1, device=DEV, dtype=torch.bfloat16) for _ in range(4)]     # rotating buffers: 131 MB > L2, < Infinity Cache
+    outs = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    state = {"i": 0}
+
+    def up():
+        h = hs[state["i"] % 4]
+        C.check(C.lib().tsasr_gemm_bf16_fused(C.ptr(x), C.ptr(w1), C.ptr(h), M, F1, D, D, D, F1, 0, 0, 1, C.ptr(b1), None, 0, 0.01, 0.1, 5,
+                                              None, None, None, None, 0, C.stream_ptr()), "up")
+        return h
+
+    def pair():
+        h = up(); state["i"] += 1
+        ops.gemm_bf16(h, w2, M, D, F1, F1, F1, 0, 0, out=outs)
+
+    def down_hot():
+        ops.gemm_bf16(hs[0], w2, M, D, F1, F1, F1, 0, 0, out=outs)
+
+    def up_only():
+        up(); state["i"] += 1
+    res = [(timeit(up_only), timeit(down_hot), timeit(pair)) for _ in range(2)]
+    u, d, p2 = (min(r[i] for r in res) for i in range(3))
+    print(f"up-projection alone {u:5.1f} us | down-projection on a hot operand {d:5.1f} us | pair {p2:5.1f} us -> down-projection behind its producer {p2 - u:5.1f} us")
     sys.exit(0)
 
 for (M, N, K, ta, tb, f32) in SHAPES:

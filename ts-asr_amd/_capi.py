@@ -86,7 +86,7 @@ _PROTOS = {
     "tsasr_clip_adamw_step": (c_int, [c_void_p] * 8 + [c_ll] + [c_float] * 5 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_gemm_set_plan": (None, [c_int, c_int]),
     "tsasr_gemm_set_ring": (None, [c_int]),
-    "tsasr_gemm_set_nn128": (None, [c_int, c_int, c_int]),
+    "tsasr_gemm_set_lab_floor": (None, [c_int]),
     "tsasr_gemm_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_gemm_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 3 + [c_int] * 3 + [c_void_p]),
     "tsasr_gemm_bf16_nt_batched": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_ll] * 4 + [c_int, c_void_p]),

@@ -78,6 +78,18 @@ __device__ __forceinline__ void st8(bf16_t *p, const float (&v)[8]) {
     *reinterpret_cast<uint4 *>(p) = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
 }
 
+// WRITE-THROUGH 16-byte store (sc1): the bytes leave the XCD's L2 for memory as they are produced instead of sitting there dirty until the
+// end-of-kernel write-back, which the NEXT kernel of the chain waits for (guide "boundary" row: + dirty bytes / 6 TB/s per dependent
+// launch; the reader is usually on another XCD and reads from beyond L2 anyway). Inline asm: hipcc does not count it - the in-order vmcnt
+// only makes its own later waits wait longer, never shorter.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_wt(void *p, u32x4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st8_wt(bf16_t *p, const float (&v)[8]) {
+    st16_wt(p, (u32x4_t){pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])});
+}
+
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
 // ---- counter-based dropout bits ------------------------------------------------------------

@@ -753,50 +753,37 @@ __global__ __launch_bounds__(RING_THREADS, 1) void gemm_nn64_wavek_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 128x64 forward / data-gradient tile (both operands k-contiguous, bf16 out, no fused epilogue) - the shape of the step's dominant GEMM
-// launches (N = 256: FFN down-projection and the up-projection's data gradient at K = 2048; attention / conv-module projections at
-// K = 256 ... 768). Parameters of the main loop:
-//   STAGES: LDS-DMA ring slots (STAGES - 1 k-tiles in flight behind the MFMAs; 3 = the generic ring kernel above);
-//   WAVEK : 1 = the four waves split the k-tile (wave w owns k16 step w and accumulates the WHOLE 128x64 tile: 4 A + 2 B fragment reads
-//           for 8 MFMAs instead of 4 x (2 + 1): half the fragment traffic through the LDS port the DMA writes share), partial tiles
-//           combined through LDS in the fixed order (w0 + w2) + (w1 + w3);
-//   FLOOR : lab only (tools/gemm_bench.py --floor): 1 = the DMA ring and its barriers alone (no fragment reads, no MFMA): what the
-//           L2 -> LDS path delivers to one workgroup per CU; 2 = fragment reads + MFMA alone (no DMA).
+// LAB ONLY (tools/gemm_bench.py --floors; never launched by the product path): the 128x64 tile of the step's N = 256 projections in its
+// ROUND-3 form - four waves that each issue their share of the LDS-DMA ring AND compute - with two floor modes. They are the evidence
+// behind the loader waves of the ring kernels above (profiles/r04_notes.md section 1), at 8000 x 256 x 2048, operands hot in L2:
+//   FLOOR 0: the GEMM, 16.1 - 17.4 us;   FLOOR 1: the DMA ring and its barriers alone (no fragment reads, no MFMA): 11.4 us = 69 GB/s
+//   per CU = what the L2 -> LDS path delivers to one workgroup per CU;   FLOOR 2: fragment reads + MFMA alone (no DMA): 10.9 us.
+//   Neither floor explains 16-17 us; with the DMA issue moved to waves of its own the same tile runs in 13.0 us.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int STAGES, int WAVEK, int FLOOR>
-__global__ __launch_bounds__(256, 1) void gemm_nn128x64_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
-                                                               int M, int N, int K, long long lda, long long ldb, long long ldc) {
+template <int FLOOR>
+__global__ __launch_bounds__(256, 1) void gemm_nn128x64_lab_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
+                                                                   int M, int N, int K, long long lda, long long ldb, long long ldc) {
     using TA = RingTile<128, false>;
     using TB = RingTile<64, false>;
-    constexpr int SLOT = TA::BYTES + TB::BYTES;
-    constexpr int LPT = TA::INSTR + TB::INSTR;
-    // WAVEK 0 / 1: see above. WAVEK == 2: the 2x2 wave tiling with the fragments of k-tile kt + 1 read into registers BEFORE the MFMAs of
-    // k-tile kt are issued (software pipeline across the barrier): with one wave per SIMD nothing else hides the LDS read latency - the
-    // plain loop (reads of a k16 step, wait, its two MFMAs) spends 670 cycles per k-tile for 256 cycles of MFMA (lab floor "mfma only").
-    constexpr bool PIPE = WAVEK == 2;
-    constexpr int RB = WAVEK == 1 ? 4 : 2, CB = WAVEK == 1 ? 2 : 1, NS = WAVEK == 1 ? 1 : GB_K / 16;
+    constexpr int STAGES = 4, SLOT = TA::BYTES + TB::BYTES, LPT = TA::INSTR + TB::INSTR, NS = GB_K / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
     int tx, ty, tz;
     tile_coords((N + 63) / 64, (M + 127) / 128, 1, tx, ty, tz);
     const int m0 = ty * 128, n0 = tx * 64;
     const int nk = K / GB_K;
-    f32x16 acc[RB][CB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < CB; ++j) acc[i][j] = (f32x16){0};
+    f32x16 acc[2];
+    acc[0] = (f32x16){0}; acc[1] = (f32x16){0};
     const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
     TA::src_ptrs(A, lda, m0, M, 0, wave, lane, ga);
     TB::src_ptrs(B, ldb, n0, N, 0, wave, lane, gb);
     const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
-    int a_off[RB][NS][TA::NFO], b_off[CB][NS][TB::NFO];
+    int a_off[2][NS][TA::NFO], b_off[NS][TB::NFO];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) TA::frag_offsets(WAVEK == 1 ? 32 * i : wm * 64 + 32 * i, WAVEK == 1 ? wave : s, lane, a_off[i][s]);
-#pragma unroll
-        for (int j = 0; j < CB; ++j) TB::frag_offsets(WAVEK == 1 ? 32 * j : wn * 32 + 32 * j, WAVEK == 1 ? wave : s, lane, b_off[j][s]);
+        for (int i = 0; i < 2; ++i) TA::frag_offsets(wm * 64 + 32 * i, s, lane, a_off[i][s]);
+        TB::frag_offsets(wn * 32, s, lane, b_off[s]);
     }
     if (FLOOR != 2) {
 #pragma unroll
@@ -806,253 +793,39 @@ __global__ __launch_bounds__(256, 1) void gemm_nn128x64_kernel(const bf16_t *__r
                 TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, wave);
             }
     }
-    // wait until at most `younger` k-tiles' worth of this wave's DMA instructions are outstanding
-    auto wait_younger = [&](int younger) {
-        if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
-        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    if (!PIPE) {
-        for (int kt = 0; kt < nk; ++kt) {
-            if (FLOOR != 2) wait_younger(min(STAGES - 2, nk - 1 - kt));   // tile kt has landed
-            __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1) % STAGES
-            if (FLOOR != 2 && kt + STAGES - 1 < nk) {
-                char *slot = smem + ((kt + STAGES - 1) % STAGES) * SLOT;
-                TA::issue_at(ga, (kt + STAGES - 1) * a_step, slot, wave);
-                TB::issue_at(gb, (kt + STAGES - 1) * b_step, slot + TA::BYTES, wave);
-            }
-            if (FLOOR == 1) continue;
-            const char *as = smem + (kt % STAGES) * SLOT, *bs = as + TA::BYTES;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                bf16x8 af[RB], bfr[CB];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) af[i] = TA::frag_at(as, a_off[i][s]);
-#pragma unroll
-                for (int j = 0; j < CB; ++j) bfr[j] = TB::frag_at(bs, b_off[j][s]);
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (FLOOR != 2) ring_wait_landed(min(STAGES - 2, nk - 1 - kt), LPT);   // tile kt has landed
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces landed; every wave is done reading slot (kt-1) % STAGES
+        if (FLOOR != 2 && kt + STAGES - 1 < nk) {
+            char *slot = smem + ((kt + STAGES - 1) % STAGES) * SLOT;
+            TA::issue_at(ga, (kt + STAGES - 1) * a_step, slot, wave);
+            TB::issue_at(gb, (kt + STAGES - 1) * b_step, slot + TA::BYTES, wave);
         }
-    } else {
-        // iteration kt: [tile kt + 1 landed] barrier [DMA of tile kt + STAGES - 1 into the slot of tile kt - 1, whose fragments every wave
-        // consumed in iteration kt - 1] [fragment reads of tile kt + 1 -> nxt] [MFMAs of tile kt on cur] cur <- nxt
-        static_assert(!PIPE || STAGES >= 4, "the register pipeline needs tile kt + 1 landed while tile kt computes");
-        // Two register sets alternate roles (no copies); inside a step the MFMAs of k16 step s are followed IN PROGRAM ORDER by the three
-        // fragment reads of step s of the next tile (sched_group_barrier pins the interleave), so the reads issue while the matrix pipe
-        // works and their results are first needed after the next barrier.
-        bf16x8 fa0[RB][NS], fb0[NS], fa1[RB][NS], fb1[NS];
-        if (FLOOR != 2) wait_younger(min(STAGES - 2, nk - 1));
-        __builtin_amdgcn_s_barrier();
+        if (FLOOR == 1) continue;
+        const char *as = smem + (kt % STAGES) * SLOT, *bs = as + TA::BYTES;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            const bf16x8 bfr = TB::frag_at(bs, b_off[s]);
 #pragma unroll
-            for (int i = 0; i < RB; ++i) fa0[i][s] = TA::frag_at(smem, a_off[i][s]);
-            fb0[s] = TB::frag_at(smem + TA::BYTES, b_off[0][s]);
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TA::frag_at(as, a_off[i][s]), bfr, acc[i], 0, 0, 0);
         }
-#define NN128_STEP(CA, CB_, NA, NB, KT)                                                                                                  \
-        {                                                                                                                                \
-            if (FLOOR != 2) wait_younger(min(STAGES - 3, nk - 2 - (KT)));   /* tile KT + 1 has landed (this wave's pieces) */            \
-            __builtin_amdgcn_s_barrier();                                                                                                \
-            if (FLOOR != 2 && (KT) + STAGES - 1 < nk) {                                                                                  \
-                char *slot = smem + (((KT) + STAGES - 1) % STAGES) * SLOT;                                                               \
-                TA::issue_at(ga, ((KT) + STAGES - 1) * a_step, slot, wave);                                                              \
-                TB::issue_at(gb, ((KT) + STAGES - 1) * b_step, slot + TA::BYTES, wave);                                                  \
-            }                                                                                                                            \
-            const char *as_ = smem + (((KT) + 1) % STAGES) * SLOT, *bs_ = as_ + TA::BYTES;                                               \
-            _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                             \
-                if (FLOOR != 1) {                                                                                                        \
-                    _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                                       \
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CA[i][s], CB_[s], acc[i][0], 0, 0, 0);                        \
-                }                                                                                                                        \
-                _Pragma("unroll") for (int i = 0; i < RB; ++i) NA[i][s] = TA::frag_at(as_, a_off[i][s]);                                 \
-                NB[s] = TB::frag_at(bs_, b_off[0][s]);                                                                                   \
-                if (FLOOR != 1) __builtin_amdgcn_sched_group_barrier(0x008, RB, 0);                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x100, RB + 1, 0);                                                                  \
-            }                                                                                                                            \
-        }
-#define NN128_LAST(CA, CB_)                                                                                                              \
-        if (FLOOR != 1) {                                                                                                                \
-            _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                                               \
-                _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                                           \
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CA[i][s], CB_[s], acc[i][0], 0, 0, 0);                            \
-        }
-        int kt = 0;
-        bool in0 = true;                                   // which register set holds tile kt
-        while (kt + 1 < nk) {
-            NN128_STEP(fa0, fb0, fa1, fb1, kt);
-            ++kt;
-            in0 = false;
-            if (kt + 1 < nk) {
-                NN128_STEP(fa1, fb1, fa0, fb0, kt);
-                ++kt;
-                in0 = true;
-            }
-        }
-        if (in0) { NN128_LAST(fa0, fb0); } else { NN128_LAST(fa1, fb1); }
-#undef NN128_STEP
-#undef NN128_LAST
     }
-    __syncthreads();  // all fragment reads done before the epilogue tiles overwrite the ring
+    __syncthreads();
     const int r = lane & 31, hh = lane >> 5;
-    const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     constexpr int LDT = 64 + 4;
-    float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 128 * LDT;
-    static_assert(2 * 128 * LDT * 4 <= 3 * SLOT, "two fp32 tiles fit the smallest ring");
-    if (WAVEK == 1) {
-        float *mine = (wave & 1) ? t1 : t0;
-        if (wave >= 2) {
+    float *t0 = reinterpret_cast<float *>(smem);
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < CB; ++j)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) mine[(32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r] = acc[i][j][g];
-        }
-        __syncthreads();
-        if (wave < 2) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int j = 0; j < CB; ++j)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        float *q = mine + (32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + 32 * j + r;
-                        *q = acc[i][j][g] + *q;
-                    }
-        }
-        __syncthreads();
-    } else {
-        // each wave owns a disjoint 64x32 block: one fp32 tile, no sums
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) t0[(wm * 64 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * 32 + r] = acc[i][0][g];
-        __syncthreads();
-    }
+        for (int g = 0; g < 16; ++g) t0[(wm * 64 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * 32 + r] = acc[i][g];
+    __syncthreads();
     for (int c = threadIdx.x; c < 128 * 8; c += 256) {
         const int rr = c >> 3, cc = (c & 7) * 8;
         const int m = m0 + rr, n = n0 + cc;
-        if (m >= M || n >= N) continue;
+        if (m >= M || n + 8 > N) continue;
         float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-            const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e);
-            v[e] = va.x; v[e + 1] = va.y; v[e + 2] = va.z; v[e + 3] = va.w;
-            if (WAVEK == 1) {
-                const float4 vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc + e);
-                v[e] += vb.x; v[e + 1] += vb.y; v[e + 2] += vb.z; v[e + 3] += vb.w;
-            }
-        }
-        bf16_t *dst = C + (long long)m * ldc + n;
-        if (vec && n + 8 <= N) st8(dst, v);
-        else
-            for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
-    }
-}
-
-// The same tile with SPECIALISED waves: 8 waves, 0-3 compute (2x2 tiling, fragments of the next k16 step / k-tile read ahead), 4-7 only
-// issue the LDS-DMA ring. Why: the lab floors of the 4-wave loop (tools/gemm_bench.py --nn128, profiles/r04_notes.md) are 11.4 us for the
-// DMA ring alone and 8.8-10.9 us for fragment reads + MFMA alone, yet together they take 16 us whatever the compute part costs: a wave
-// that issues a DMA into a full vector-memory queue sits in the issue stage until older requests drain, and the MFMAs behind it in
-// program order wait with it. A loader wave may block there for free.
-template <int STAGES>
-__global__ __launch_bounds__(512, 1) void gemm_nn128x64_ws_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, bf16_t *__restrict__ C,
-                                                                  int M, int N, int K, long long lda, long long ldb, long long ldc) {
-    using TA = RingTile<128, false>;
-    using TB = RingTile<64, false>;
-    constexpr int SLOT = TA::BYTES + TB::BYTES;
-    constexpr int LPT = TA::INSTR + TB::INSTR;
-    constexpr int NS = GB_K / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave >= 4;
-    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
-    int tx, ty, tz;
-    tile_coords((N + 63) / 64, (M + 127) / 128, 1, tx, ty, tz);
-    const int m0 = ty * 128, n0 = tx * 64;
-    const int nk = K / GB_K;
-    f32x16 acc[2];
-    acc[0] = (f32x16){0}; acc[1] = (f32x16){0};
-    if (loader) {
-        const bf16_t *ga[TA::INSTR], *gb[TB::INSTR];
-        TA::src_ptrs(A, lda, m0, M, 0, cw, lane, ga);
-        TB::src_ptrs(B, ldb, n0, N, 0, cw, lane, gb);
-        const long long a_step = TA::k_step(lda), b_step = TB::k_step(ldb);
-#pragma unroll
-        for (int t = 0; t < STAGES - 1; ++t)
-            if (t < nk) {
-                TA::issue_at(ga, t * a_step, smem + t * SLOT, cw);
-                TB::issue_at(gb, t * b_step, smem + t * SLOT + TA::BYTES, cw);
-            }
-        for (int kt = 0; kt < nk; ++kt) {
-            const int younger = min(STAGES - 2, nk - 1 - kt);     // tile kt has landed once only the younger tiles' instructions are outstanding
-            if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
-            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // tile kt visible to the compute waves; they are done with tile kt - 1
-            if (kt + STAGES - 1 < nk) {
-                char *slot = smem + ((kt + STAGES - 1) % STAGES) * SLOT;
-                TA::issue_at(ga, (kt + STAGES - 1) * a_step, slot, cw);
-                TB::issue_at(gb, (kt + STAGES - 1) * b_step, slot + TA::BYTES, cw);
-            }
-        }
-    } else {
-        int a_off[2][NS][TA::NFO], b_off[NS][TB::NFO];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) TA::frag_offsets(wm * 64 + 32 * i, s, lane, a_off[i][s]);
-            TB::frag_offsets(wn * 32, s, lane, b_off[s]);
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            __builtin_amdgcn_s_barrier();
-            const char *as = smem + (kt % STAGES) * SLOT, *bs = as + TA::BYTES;
-            bf16x8 fa[2][NS], fb[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {                  // all twelve reads of the k-tile in flight before the first MFMA needs one
-#pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i][s] = TA::frag_at(as, a_off[i][s]);
-                fb[s] = TB::frag_at(bs, b_off[s]);
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[s], acc[i], 0, 0, 0);
-        }
-    }
-    __syncthreads();  // all fragment reads done before the epilogue tile overwrites the ring
-    const int r = lane & 31, hh = lane >> 5;
-    const bool vec = (ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-    constexpr int LDT = 64 + 4;
-    float *t0 = reinterpret_cast<float *>(smem);
-    if (!loader) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) t0[(wm * 64 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh) * LDT + wn * 32 + r] = acc[i][g];
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 128 * 8; c += 512) {
-        const int rr = c >> 3, cc = (c & 7) * 8;
-        const int m = m0 + rr, n = n0 + cc;
-        if (m >= M || n >= N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-            const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc + e);
-            v[e] = va.x; v[e + 1] = va.y; v[e + 2] = va.z; v[e + 3] = va.w;
-        }
-        bf16_t *dst = C + (long long)m * ldc + n;
-        if (vec && n + 8 <= N) st8(dst, v);
-        else
-            for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
+        ld8(t0 + rr * LDT + cc, v);
+        st8(C + (long long)m * ldc + n, v);
     }
 }
 
@@ -1145,25 +918,7 @@ int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, i
                           const unsigned long long *seed_dev, float *colpart, void *mask, hipStream_t st);
 
 static int g_use_ring = 1;   // 0: never, 1: long K or small tiles, 2: always
-static int g_ring_deep = getenv("TSASR_RING_DEEP") ? atoi(getenv("TSASR_RING_DEEP")) : 0;
-// 128x64 nn bf16 tile: ring slots / wave-K split / lab floor mode of gemm_nn128x64_kernel; stages 0 = the generic ring kernel
-static int g_nn128_stages = 0, g_nn128_wavek = 0, g_nn128_floor = 0;
-
-template <int STAGES>
-static void launch_nn128x64_ws(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, dim3 grid, hipStream_t st) {
-    constexpr int BYTES = STAGES * (RingTile<128, false>::BYTES + RingTile<64, false>::BYTES);
-    auto kern = gemm_nn128x64_ws_kernel<STAGES>;
-    if (BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    kern<<<grid, 512, BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc);
-}
-
-template <int STAGES, int WAVEK, int FLOOR>
-static void launch_nn128x64(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, dim3 grid, hipStream_t st) {
-    constexpr int BYTES = STAGES * (RingTile<128, false>::BYTES + RingTile<64, false>::BYTES);
-    auto kern = gemm_nn128x64_kernel<STAGES, WAVEK, FLOOR>;
-    if (BYTES > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    kern<<<grid, 256, BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc);
-}
+static int g_lab_floor = -1;   // tools/gemm_bench.py --floors: -1 = off; 0 / 1 / 2 = gemm_nn128x64_lab_kernel<FLOOR> for the 128x64 nn bf16 tile
 
 template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
@@ -1192,47 +947,11 @@ static void launch(const void *A, const void *B, void *C, int M, int N, int K, l
         }
     }
     if constexpr (BM == 128 && BN == 64 && !AT && !BT && OUT_MODE == 0) {
-        if (ring && g_nn128_stages && ep.mode == 0 && !ep.btab && splits == 1 && K % GB_K == 0) {
-            const int v = g_nn128_stages * 100 + g_nn128_wavek * 10 + g_nn128_floor;
-            switch (v) {
-            case 300: launch_nn128x64<3, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 400: launch_nn128x64<4, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 500: launch_nn128x64<5, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 600: launch_nn128x64<6, 0, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 310: launch_nn128x64<3, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 410: launch_nn128x64<4, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 510: launch_nn128x64<5, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 610: launch_nn128x64<6, 1, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 401: launch_nn128x64<4, 0, 1>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 601: launch_nn128x64<6, 0, 1>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 402: launch_nn128x64<4, 0, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 412: launch_nn128x64<4, 1, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 420: launch_nn128x64<4, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 520: launch_nn128x64<5, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 620: launch_nn128x64<6, 2, 0>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 422: launch_nn128x64<4, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 330: launch_nn128x64_ws<3>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 430: launch_nn128x64_ws<4>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 530: launch_nn128x64_ws<5>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            case 630: launch_nn128x64_ws<6>(A, B, C, M, N, K, lda, ldb, ldc, grid, st); return;
-            default: break;
-            }
-        }
-    }
-    if constexpr (BM == 128 && BN == 64 && !AT && OUT_MODE == 0) {
-        // the step's N = 256 projections: one workgroup per CU whatever the ring size, operands mostly from beyond L2 (the activation the
-        // previous kernel wrote): g_ring_deep slots keep more bytes in flight per CU (TSASR_RING_DEEP; 0 = the 3-slot ring)
-        if (ring && g_ring_deep >= 4 && grid.x <= 2 * 256) {
-            constexpr int SLOTB = RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES;
-            if (g_ring_deep >= 6) {
-                auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE, 6>;
-                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * SLOTB);
-                kern<<<grid, RING_THREADS, 6 * SLOTB, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
-            } else {
-                auto kern = gemm_bf16_ring_kernel<BM, BN, AT, BT, OUT_MODE, 4>;
-                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOTB);
-                kern<<<grid, RING_THREADS, 4 * SLOTB, st>>>((const bf16_t *)A, (const bf16_t *)B, C, M, N, K, lda, ldb, ldc, kchunk, slab_stride, splits, ep);
-            }
+        if (g_lab_floor >= 0 && ep.mode == 0 && !ep.btab && splits == 1 && K % GB_K == 0 && N % 8 == 0 && ldc % 8 == 0) {   // lab only
+            constexpr int BYTES = 4 * (RingTile<128, false>::BYTES + RingTile<64, false>::BYTES);
+            auto kern = g_lab_floor == 0 ? gemm_nn128x64_lab_kernel<0> : g_lab_floor == 1 ? gemm_nn128x64_lab_kernel<1> : gemm_nn128x64_lab_kernel<2>;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            kern<<<grid, 256, BYTES, st>>>((const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc);
             return;
         }
     }
@@ -1314,9 +1033,9 @@ extern "C" {
 void tsasr_gemm_set_ring(int on) { g_use_ring = on; }
 /* A/B tests only: force the macro-tile (0 = 128x128, 1 = 128x64, 2 = 64x64; -1 = automatic) and the split-K factor of fp32-output GEMMs. */
 void tsasr_gemm_set_plan(int tile, int splits) { g_force_tile = tile; g_force_splits = splits; }
-/* 128x64 bf16 tile of the N = 256 projections: ring slots (0 = generic 3-slot ring kernel; 3..6), wave-K split (0 / 1), lab floor mode
- * (0 = the GEMM; 1 = LDS-DMA ring alone, 2 = fragment reads + MFMA alone: results are NOT the product - tools/gemm_bench.py --floor). */
-void tsasr_gemm_set_nn128(int stages, int wavek, int floor_mode) { g_nn128_stages = stages; g_nn128_wavek = wavek; g_nn128_floor = floor_mode; }
+/* LAB (tools/gemm_bench.py --floors): -1 = off; 0 / 1 / 2: the 128x64 nn bf16 tile runs gemm_nn128x64_lab_kernel<floor> - the round-3 four-wave
+ * loop / its LDS-DMA ring alone / its fragment reads + MFMA alone (modes 1 and 2 do NOT compute the product). */
+void tsasr_gemm_set_lab_floor(int floor_mode) { g_lab_floor = floor_mode; }
 
 size_t tsasr_gemm_bf16_workspace_bytes(int M, int N, int K, int out_dtype) {
     const GemmPlan p = plan(M, N, K, out_dtype == TSASR_F32);
