@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsasr_hip.so")
+LIB_PATH = os.environ.get("TSASR_HIP_LIB") or os.path.join(_HERE, "lib", "libtsasr_hip.so")   # (TSASR_HIP_LIB: A/B builds of the same ABI, tools only)
 
 F32, BF16 = 0, 1
 

@@ -89,6 +89,17 @@ __device__ __forceinline__ void st16_wt(void *p, u32x4_t v) {
 __device__ __forceinline__ void st8_wt(bf16_t *p, const float (&v)[8]) {
     st16_wt(p, (u32x4_t){pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])});
 }
+// st8_g / st16_g: 16-byte stores of a LARGE kernel output that the next kernel streams once (the 32.8 MB FFN activation / its gradient:
+// csrc/gemm_big.hip) - write-through unless the library is built with -DTSASR_NO_WT (`make nowt`, the A/B build of profiles/r04_notes.md:
+// 10.79 -> 10.70 ms per step). NOT for the 4 MB row-kernel / projection outputs: written through they cost the step 0.07 ms (their
+// readers find them in L2 when they stay).
+#ifdef TSASR_NO_WT
+__device__ __forceinline__ void st8_g(bf16_t *p, const float (&v)[8]) { st8(p, v); }
+__device__ __forceinline__ void st16_g(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+#else
+__device__ __forceinline__ void st8_g(bf16_t *p, const float (&v)[8]) { st8_wt(p, v); }
+__device__ __forceinline__ void st16_g(void *p, uint4 v) { st16_wt(p, (u32x4_t){v.x, v.y, v.z, v.w}); }
+#endif
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 

@@ -41,7 +41,6 @@ struct BigArgs {
     // Mode 1 writes it (when given); mode 2 reads it INSTEAD of the saved activation y and of re-hashing the keep-bits: 4 MB instead of
     // 32.8 MB read per FFN backward launch at configs[1], no hash (tools/gemm_bench.py: the mode-2 epilogue was 13 us of a 33 us launch)
     unsigned short *mask;
-    int wt;           // 1: the C tile leaves by write-through stores (common.h st8_wt)
 };
 
 __device__ __forceinline__ void gbg_dma16(const bf16_t *gsrc, unsigned lds_dst) {
@@ -229,10 +228,7 @@ __global__ __launch_bounds__(GBG_THREADS, 2) void gemm_big_kernel(BigArgs a) {
                     }
                 }
             }
-            if (FULL || m < a.M) {
-                if (a.wt) st8_wt(a.C + (long long)m * a.ldc + n, v);
-                else st8(a.C + (long long)m * a.ldc + n, v);
-            }
+            if (FULL || m < a.M) st8_g(a.C + (long long)m * a.ldc + n, v);    // write-through: 32.8 MB per launch that the next kernel reads from beyond L2
         }
         };
         if (m0 + half * HR + HR <= a.M) pass(std::true_type{});
@@ -275,9 +271,7 @@ int tsasr_gemm_big_launch(const void *A, const void *B, void *C, int M, int N, i
     if (!bm) return 1;
     if (mode == 1 && slope > 1.f) return 1;      // the mode-1 epilogue's LeakyReLU is max(x, slope * x): the caller's general path takes slopes above 1
     BigArgs a{(const bf16_t *)A, (const bf16_t *)B, (bf16_t *)C, M, N, K, lda, ldb, ldc, mode, bias, (const bf16_t *)y, ldy, slope, p, seed, seed_dev, colpart,
-              (unsigned short *)mask, 0};
-    static const int wt = getenv("TSASR_WT_STORES") ? atoi(getenv("TSASR_WT_STORES")) : 0;
-    a.wt = wt & 1;
+              (unsigned short *)mask};
     const int grid = cdiv(M, bm) * (N / GBG_BN);
     constexpr int LDS256 = 128 * GBG_LDF * 4 > 2 * (256 + GBG_BN) * GBG_ROW ? 128 * GBG_LDF * 4 : 2 * (256 + GBG_BN) * GBG_ROW;   // fp32 half tile 130 KiB
     constexpr int LDS128 = 2 * (128 + GBG_BN) * GBG_ROW;   // 96 KiB >= the 64 x 260 fp32 half tile
