@@ -484,6 +484,19 @@ int tsasr_colsum(const void *x, float *out, long long M, int N, int accumulate, 
                  void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Single-layer LSTM in EXACT fp32 arithmetic with an optional initial state (csrc/lstm_f32.hip): the `compute_dtype: fp32` parity mode of
+ * the predictor (torch.nn.LSTM behind SB/nnet/RNN.py:170-278) and the step-wise predictor calls of the searchers
+ * (SB/decoders/transducer.py:246-353,411-466: one token, carried (h, c)). Gate order i, f, g, o; x [B,U,I], w_ih [4H,I], w_hh [4H,H],
+ * biases [4H] or NULL, h0 / c0 [B,H] or NULL (zeros). hs [B,U,H]; hn / cn [B,H] or NULL; cs [B,U,H] and gates [B,U,4H] (activated) are
+ * what the backward needs (NULL when not training). Backward: dgates [B,U,4H] w.r.t. the gate pre-activations (the weight / bias / input
+ * gradients are GEMMs over all (b,t): tsasr_gemm_f32), dh0 / dc0 optional. H <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int tsasr_lstm_f32_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *h0,
+                       const float *c0, float *hs, float *cs, float *gates, float *hn, float *cn, int B, int U, int I, int H, void *stream);
+int tsasr_lstm_f32_bwd(const float *dout, const float *dhn, const float *dcn, const float *gates, const float *cs, const float *c0,
+                       const float *w_hh, float *dgates, float *dh0, float *dc0, int B, int U, int H, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Attention in EXACT fp32 arithmetic (csrc/attention_f32.hip; no matrix cores, no bf16 rounding of operands): the `compute_dtype: fp32`
  * parity mode of RelPosMHAXL (same reference lines as tsasr_relpos_attn_*: SB/nnet/attention.py:586-633, rel_shift :468-483) and, with
  * pk == NULL and Tq != Tk, the core of torch.nn.MultiheadAttention for the `cross_attention` speaker injection (models/conformer.py:263-266).

@@ -448,6 +448,41 @@ def test_attention_exact_fp32_dropout_and_cross_shapes(ops):
         assert rel < 2e-5, (name, rel)
 
 
+@pytest.mark.parametrize("B,U,I,H", [(4, 21, 28, 64), (2, 7, 28, 512), (3, 1, 5, 20)])
+def test_lstm_exact_fp32_vs_float64_and_stepwise(ops, B, U, I, H):
+    """The fp32 LSTM kernels (csrc/lstm_f32.hip: parity-mode predictor and the searchers' step-wise calls; torch.nn.LSTM behind
+    SB/nnet/RNN.py:170-278, stepped by SB/decoders/transducer.py:246-353) against torch.nn.LSTM evaluated in float64 on the CPU: outputs,
+    final state and every gradient (input, both weights, both biases, initial state) to 1e-5 relative L2; U single steps with a carried
+    (h, c) reproduce the sequence call BIT FOR BIT (the same arithmetic in the same order)."""
+    g = torch.Generator().manual_seed(U * 7 + H)
+    rnn = torch.nn.LSTM(I, H, batch_first=True)
+    x = torch.randn(B, U, I, generator=g)
+    h0, c0 = torch.randn(1, B, H, generator=g) * 0.5, torch.randn(1, B, H, generator=g) * 0.5
+    dout, dhn = torch.randn(B, U, H, generator=g), torch.randn(1, B, H, generator=g)
+    ref = torch.nn.LSTM(I, H, batch_first=True).double()
+    ref.load_state_dict({k: v.double() for k, v in rnn.state_dict().items()})
+    xr, h0r, c0r = x.double().requires_grad_(), h0.double().requires_grad_(), c0.double().requires_grad_()
+    out_r, (hn_r, cn_r) = ref(xr, (h0r, c0r))
+    ((out_r * dout.double()).sum() + (hn_r * dhn.double()).sum() + cn_r.sum()).backward()
+    dev = rnn.to(DEV)
+    xg, h0g, c0g = x.to(DEV).requires_grad_(), h0.to(DEV).requires_grad_(), c0.to(DEV).requires_grad_()
+    assert ops.LSTM_F32_HIP and ops.lstm_f32_ok(dev)
+    out, (hn, cn) = ops.lstm(xg, dev, (h0g, c0g))
+    ((out * dout.to(DEV)).sum() + (hn * dhn.to(DEV)).sum() + cn.sum()).backward()
+    rel = lambda a, b: float((a.detach().double().cpu() - b.detach()).norm() / (b.detach().norm() + 1e-30))  # noqa: E731
+    for a, b, name in ((out, out_r, "out"), (hn, hn_r, "hn"), (cn, cn_r, "cn"), (xg.grad, xr.grad, "dx"), (h0g.grad, h0r.grad, "dh0"),
+                       (c0g.grad, c0r.grad, "dc0"), (dev.weight_ih_l0.grad, ref.weight_ih_l0.grad, "dW_ih"),
+                       (dev.weight_hh_l0.grad, ref.weight_hh_l0.grad, "dW_hh"), (dev.bias_ih_l0.grad, ref.bias_ih_l0.grad, "db_ih"),
+                       (dev.bias_hh_l0.grad, ref.bias_hh_l0.grad, "db_hh")):
+        assert rel(a, b) < 1e-5, (name, rel(a, b))
+    with torch.no_grad():
+        hid, outs = (h0g.detach(), c0g.detach()), []
+        for t in range(U):
+            o, hid = ops.lstm(x[:, t:t + 1].to(DEV), dev, hid)
+            outs.append(o)
+        assert torch.equal(torch.cat(outs, 1), out.detach()) and torch.equal(hid[0], hn.detach()) and torch.equal(hid[1], cn.detach())
+
+
 def test_fused_attention_dropout_consistency(ops):
     """With dropout the backward must regenerate the forward's mask: check d(out)/d(V) . dout == out . dout structure via
     finite differences on V (out is linear in V for a fixed mask)."""

@@ -101,6 +101,48 @@ if "--chain" in sys.argv:
     res = [(timeit(up_only), timeit(down_hot), timeit(pair)) for _ in range(2)]
     u, d, p2 = (min(r[i] for r in res) for i in range(3))
     print(f"up-projection alone {u:5.1f} us | down-projection on a hot operand {d:5.1f} us | pair {p2:5.1f} us -> down-projection behind its producer {p2 - u:5.1f} us")
+    # the same pairs with a DIFFERENT pair of weight matrices per launch (24 layers' worth, 48 MB + transposes: not L2-resident), as the
+    # step's layers have
+    w1s = [torch.randn(F1, D, device=DEV).to(torch.bfloat16) for _ in range(24)]
+    w2s = [torch.randn(D, F1, device=DEV).to(torch.bfloat16) for _ in range(24)]
+
+    def up_cold():
+        h = hs[state["i"] % 4]
+        C.check(C.lib().tsasr_gemm_bf16_fused(C.ptr(x), C.ptr(w1s[state["i"] % 24]), C.ptr(h), M, F1, D, D, D, F1, 0, 0, 1, C.ptr(b1), None, 0, 0.01, 0.1, 5,
+                                              None, None, None, None, 0, C.stream_ptr()), "up")
+        return h
+
+    def pair_cold():
+        h = up_cold()
+        ops.gemm_bf16(h, w2s[state["i"] % 24], M, D, F1, F1, F1, 0, 0, out=outs)
+        state["i"] += 1
+
+    def up_cold_only():
+        up_cold(); state["i"] += 1
+    res = [(timeit(up_cold_only, 24), timeit(pair_cold, 24)) for _ in range(2)]
+    u, p2 = (min(r[i] for r in res) for i in range(2))
+    print(f"per-layer weights: up-projection alone {u:5.1f} us | pair {p2:5.1f} us -> down-projection behind its producer, cold weights {p2 - u:5.1f} us")
+    # ... and a FRESH hidden activation per pair, as the step keeps every layer's for its backward: 24 x 32.8 MB = 787 MB, three times the
+    # Infinity Cache - every write now costs HBM write bandwidth (a buffer rotating inside 131 MB is absorbed by the cache)
+    del hs[:]
+    hs.extend(torch.empty(M, F1, device=DEV, dtype=torch.bfloat16) for _ in range(24))
+
+    def up_fresh():
+        h = hs[state["i"] % 24]
+        C.check(C.lib().tsasr_gemm_bf16_fused(C.ptr(x), C.ptr(w1s[state["i"] % 24]), C.ptr(h), M, F1, D, D, D, F1, 0, 0, 1, C.ptr(b1), None, 0, 0.01, 0.1, 5,
+                                              None, None, None, None, 0, C.stream_ptr()), "up")
+        return h
+
+    def pair_fresh():
+        h = up_fresh()
+        ops.gemm_bf16(h, w2s[state["i"] % 24], M, D, F1, F1, F1, 0, 0, out=outs)
+        state["i"] += 1
+
+    def up_fresh_only():
+        up_fresh(); state["i"] += 1
+    res = [(timeit(up_fresh_only, 24), timeit(pair_fresh, 24)) for _ in range(2)]
+    u, p2 = (min(r[i] for r in res) for i in range(2))
+    print(f"fresh 32.8 MB activation per pair (787 MB in all): up-projection alone {u:5.1f} us | pair {p2:5.1f} us -> down-projection {p2 - u:5.1f} us")
     sys.exit(0)
 
 for (M, N, K, ta, tb, f32) in SHAPES:

@@ -145,6 +145,8 @@ _PROTOS = {
     "tsasr_specaug_apply": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_resample_out_len": (c_ll, [c_ll, c_int, c_int]),
     "tsasr_resample_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "tsasr_lstm_f32_fwd": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_void_p]),
+    "tsasr_lstm_f32_bwd": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "tsasr_attn_f32_fwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p]),
     "tsasr_attn_f32_bwd_workspace_bytes": (c_size_t, [c_int] * 5),
     "tsasr_attn_f32_bwd": (c_int, [c_void_p] * 18 + [c_int] * 5 + [c_float, c_int, c_float, c_ull, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

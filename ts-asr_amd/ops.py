@@ -1,10 +1,9 @@
 """Operator layer between the host modules (nnet.py / conformer.py) and the device.
 
-Two kinds of operator live here, and DESIGN.md lists which is which:
-  * HIP  - hand-written gfx950 kernels behind the C-ABI (autograd.Functions in this file / rnnt.py);
-  * GLUE - plain library calls through PyTorch-ROCm (hipBLASLt GEMMs, MIOpen conv/LSTM, rocFFT) that have no
-           hand-written kernel yet. They run on the GPU, never on the CPU, and are the list of work for the
-           next rounds. ``STATUS`` below is the machine-readable version of that list.
+Everything that computes on the path is a hand-written gfx950 kernel behind the C-ABI (autograd.Functions in this file / rnnt.py);
+``STATUS`` is the machine-readable list. Since round 4 no library kernel (MIOpen / hipBLASLt / rocFFT) is left on the path for the shapes
+the three recipes use: the fp32 parity mode runs exact-fp32 HIP kernels (gemm_f32, attention_f32, joint_f32, lstm_f32), the searchers'
+step-wise predictor calls run lstm_f32. A library module is only reached by LSTM shapes no kernel takes (several layers, bidirectional).
 """
 import math
 import os
@@ -19,7 +18,9 @@ STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
     "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
-    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "HIP (gemm_f32: fp32 matrix cores; fwd, dgrad, wgrad)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "GLUE(MIOpen)", "fbank": "HIP", "sentence_norm": "HIP",
+    "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "HIP (gemm_f32: fp32 matrix cores; fwd, dgrad, wgrad)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "HIP (lstm_f32: exact fp32, optional initial state)",
+    "attention(fp32 parity, cross_attention injection)": "HIP (attention_f32: exact fp32)", "joint(fp32 parity)": "HIP (joint_f32)",
+    "injection sum / prod": "HIP (inject)", "mix_sources": "HIP (dataio.hip)", "fbank": "HIP", "sentence_norm": "HIP",
     "relpos_attention": "HIP (forward; backward = query-major, key-major, d(pk) and partial-sum kernels)",
 }
 
@@ -371,7 +372,7 @@ def gemm_bf16(a, b, M, N, K, lda, ldb, trans_a, trans_b, out=None, out_dtype=tor
             label = "gemm_nn64_wavek_kernel"
         else:
             label = (f"gemm_bf16_{'ring_' if ring else ''}kernel<{tile}, {'true' if trans_a else 'false'}, "
-                     f"{'true' if trans_b else 'false'}, {mode}>")
+                     f"{'true' if trans_b else 'false'}, {mode}{', 3' if ring else ''}>")       # (ring kernels: + the slot count)
     else:
         label = "gemm"
     with prof.region(label, 2.0 * M * N * K):
@@ -959,15 +960,78 @@ def lstm_onehot(tokens, rnn, blank):
     return _LstmFn.apply(tokens, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, int(blank))
 
 
+class _LstmF32Fn(torch.autograd.Function):
+    """Single-layer LSTM in exact fp32 arithmetic with an optional initial state (csrc/lstm_f32.hip): returns (out [B,U,H], hn, cn [B,H]).
+    The recurrence is one HIP launch each way; dx / dW_ih / dW_hh / db are fp32 GEMMs over all (b, t) (csrc/gemm_f32.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+        C.require_gpu(x, w_ih, w_hh)
+        xc = x.contiguous()
+        B, U, I = xc.shape
+        H = w_hh.shape[1]
+        f = lambda t: None if t is None else _f32(t).contiguous()  # noqa: E731
+        wi, wh, bi, bh, h0c, c0c = f(w_ih), f(w_hh), f(b_ih), f(b_hh), f(h0), f(c0)
+        train = any(ctx.needs_input_grad)
+        hs = torch.empty(B, U, H, dtype=torch.float32, device=x.device)
+        hn, cn = torch.empty(B, H, dtype=torch.float32, device=x.device), torch.empty(B, H, dtype=torch.float32, device=x.device)
+        cs = torch.empty(B, U, H, dtype=torch.float32, device=x.device) if train else None
+        gates = torch.empty(B, U, 4 * H, dtype=torch.float32, device=x.device) if train else None
+        with prof.region("lstm_f32_fwd"):
+            C.check(C.lib().tsasr_lstm_f32_fwd(C.ptr(xc), C.ptr(wi), C.ptr(wh), C.ptr(bi), C.ptr(bh), C.ptr(h0c), C.ptr(c0c), C.ptr(hs), C.ptr(cs),
+                                               C.ptr(gates), C.ptr(hn), C.ptr(cn), B, U, I, H, C.stream_ptr()), "tsasr_lstm_f32_fwd")
+        if train:
+            ctx.save_for_backward(xc, wi, wh, hs, cs, gates, h0c, c0c)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        return hs, hn, cn
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        xc, wi, wh, hs, cs, gates, h0c, c0c = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        B, U, I = xc.shape
+        H = wh.shape[1]
+        f = lambda t: None if t is None else t.float().contiguous()  # noqa: E731
+        dgates = torch.empty(B, U, 4 * H, dtype=torch.float32, device=xc.device)
+        dh0 = torch.empty(B, H, dtype=torch.float32, device=xc.device) if ctx.needs_input_grad[5] else None
+        dc0 = torch.empty(B, H, dtype=torch.float32, device=xc.device) if ctx.needs_input_grad[6] else None
+        with prof.region("lstm_f32_bwd"):
+            C.check(C.lib().tsasr_lstm_f32_bwd(C.ptr(f(dout)), C.ptr(f(dhn)), C.ptr(f(dcn)), C.ptr(gates), C.ptr(cs), C.ptr(c0c), C.ptr(wh),
+                                               C.ptr(dgates), C.ptr(dh0), C.ptr(dc0), B, U, H, C.stream_ptr()), "tsasr_lstm_f32_bwd")
+        dg2 = dgates.view(B * U, 4 * H)
+        h_prev = torch.empty_like(hs)
+        h_prev[:, 1:] = hs[:, :-1]
+        h_prev[:, 0] = 0.0 if h0c is None else h0c
+        G = 4 * H
+        dx = gemm_f32(dg2, wi, B * U, I, G, G, I, 0, 1).view(B, U, I) if ctx.needs_input_grad[0] else None
+        dw_ih = gemm_f32(dg2, xc.view(B * U, I), G, I, B * U, G, I, 1, 1) if ctx.needs_input_grad[1] else None
+        dw_hh = gemm_f32(dg2, h_prev.view(B * U, H), G, H, B * U, G, H, 1, 1) if ctx.needs_input_grad[2] else None
+        db = dg2.sum(0) if (b_ih is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])) else None
+        return (dx, dw_ih, dw_hh, db if ctx.needs_input_grad[3] else None, db if (b_hh is not None and ctx.needs_input_grad[4]) else None, dh0, dc0)
+
+
+def lstm_f32_ok(rnn):
+    return rnn.num_layers == 1 and not rnn.bidirectional and rnn.hidden_size <= 1024 and rnn.batch_first and getattr(rnn, "proj_size", 0) == 0
+
+
 def lstm(x, rnn, hx=None):
-    """bf16 training path: HIP cell kernels + HIP GEMM per step. Stepwise decoding (hx given) and fp32 parity runs keep the
-    library LSTM (MIOpen through PyTorch-ROCm)."""
+    """bf16 training path (no initial state): persistent HIP recurrence on MFMA (_LstmFn). Everything else the recipes do with the predictor -
+    fp32 parity runs, the searchers' step-wise calls with a carried (h, c) - runs the exact-fp32 HIP kernels of csrc/lstm_f32.hip
+    (_LstmF32Fn); only LSTM shapes neither kernel takes (several layers, bidirectional, H > 1024) fall back to the library module."""
     if (hx is None and x.dtype == torch.bfloat16 and rnn.num_layers == 1 and not rnn.bidirectional and rnn.hidden_size % 16 == 0
             and x.shape[1] > 1):
         out = _LstmFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
         return out, None
+    if LSTM_F32_HIP and lstm_f32_ok(rnn) and x.is_cuda:
+        h0, c0 = (None, None) if hx is None else (hx[0][0], hx[1][0])       # torch's (num_layers, B, H)
+        b_ih, b_hh = (rnn.bias_ih_l0, rnn.bias_hh_l0) if rnn.bias else (None, None)
+        out, hn, cn = _LstmF32Fn.apply(x.float(), rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, h0, c0)
+        return out.to(x.dtype), (hn.unsqueeze(0), cn.unsqueeze(0))
     out, hn = rnn(x.float(), hx) if hx is not None else rnn(x.float())
     return out.to(x.dtype), hn
+
+
+LSTM_F32_HIP = True       # (tests compare with the library module by switching it off)
 
 
 class _LayerNormFn(torch.autograd.Function):
