@@ -157,6 +157,17 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
                       int K, int causal, float slope, int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 
+/* Front-end block 2 as IMPLICIT GEMMs (csrc/gemm.hip conv_s2_*): the 3x3 stride-2 Conv2d + 1x1 stride-2 residual conv of a ConvBlock with
+ * C_in > 1 (SB/lobes/models/convolution.py:178-266, SB/nnet/CNN.py:629-711) without the [P, 9*Ci] patch matrix: the ring kernels' loader
+ * waves gather the patch rows from x [B,T,F,Ci] (bf16, channels-last) with the padding rule folded into the source address. Wm [128, 9*Ci] =
+ * the 3x3 filter as [Co, (kt, kf, ci)], W2 [128, Ci] (bf16); b1 / b2 fp32 [128]; y1, y2 [B,T',F',128] bf16. Co == 128, Ci in {64, 128}.
+ * Filter gradients: dWm [128, 9*Ci], dW2 [128, Ci] fp32 (overwritten; split-K slabs in the workspace, summed in fixed order) from dy1, dy2
+ * [P,128] and x. (The data gradient is dy1 . Wm through tsasr_gemm_bf16 + tsasr_frontend_col2im.) */
+int tsasr_conv3x3s2_fwd(const void *x, const void *Wm, const float *b1, const void *W2, const float *b2, void *y1, void *y2, int B, int T, int F,
+                        int Ci, int Co, int causal, void *stream);
+size_t tsasr_conv3x3s2_wgrad_workspace_bytes(int B, int T, int F, int Ci);
+int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                          void *workspace, size_t workspace_bytes, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Convolutional front-end (SB/lobes/models/convolution.py:103-266, Conv2d.forward SB/nnet/CNN.py:629-711): stride-2 3x3
  * conv ('same' = reflect padding, or causal = (2,0) zero pad on time, (1,1) on frequency) + 1x1 stride-2 residual conv.

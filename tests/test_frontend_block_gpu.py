@@ -176,3 +176,35 @@ def test_convblock_module_uses_fused_path():
         nnet._FUSED_CONVBLOCK = prev
     assert a.shape == b.shape
     assert rel_l2(a, b) < 6e-3     # the unfused chain rounds y, r and both LayerNorm outputs to bf16 on the way
+
+
+@pytest.mark.parametrize("B,T,F,Ci,causal", [(2, 37, 21, 128, False), (2, 37, 21, 128, True), (1, 500, 40, 128, False), (3, 10, 8, 64, True), (1, 2, 2, 128, False)])
+def test_conv_implicit_gemm_equals_im2col_path(B, T, F, Ci, causal):
+    """Front-end block 2's convolutions as implicit GEMMs (csrc/gemm.hip conv_s2_fwd / conv_s2_wgrad: the ring kernels' loader waves gather
+    the 3x3 patch rows, padding rule folded into the address - SB/nnet/CNN.py:629-711 reflect / causal) against the im2col + GEMM path
+    they replace, which the golden-vector tests above pin to the reference: same bf16 operands, fp32 accumulation in another order.
+    Outputs, data gradient, both filter gradients and both bias gradients; odd and even sizes, reflection at both ends, causal zero
+    padding, a single output position, Ci = 64."""
+    ops = importlib.import_module("ts-asr_amd.ops")
+    Co = 128
+    g = torch.Generator().manual_seed(T * 3 + F + Ci)
+    x = torch.randn(B, T, F, Ci, generator=g).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
+    w2 = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).to(DEV)
+    b1, b2 = torch.randn(Co, generator=g).to(DEV), torch.randn(Co, generator=g).to(DEV)
+    To, Fo = (T - 1) // 2 + 1, (F - 1) // 2 + 1
+    d1 = torch.randn(B, To, Fo, Co, generator=g).to(torch.bfloat16).to(DEV)
+    d2 = torch.randn(B, To, Fo, Co, generator=g).to(torch.bfloat16).to(DEV)
+    res = {}
+    for implicit in (True, False):
+        ops.CONV_IMPLICIT = implicit
+        try:
+            leaves = [t.clone().requires_grad_() for t in (x, w1, b1, w2, b2)]
+            y1, y2 = ops._FrontendConvFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], causal)
+            torch.autograd.backward([y1, y2], [d1, d2])
+            res[implicit] = [y1.detach().float(), y2.detach().float()] + [t.grad.float() for t in leaves]
+        finally:
+            ops.CONV_IMPLICIT = True
+    for a, b_, name in zip(res[True], res[False], ("y1", "y2", "dx", "dw1", "db1", "dw2", "db2")):
+        rel = float((a - b_).norm() / (b_.norm() + 1e-30))
+        assert rel < (4e-3 if name in ("y1", "y2", "dx") else 2e-4), (name, rel)      # bf16 outputs round once each way; fp32 filter gradients

@@ -829,6 +829,293 @@ __global__ __launch_bounds__(256, 1) void gemm_nn128x64_lab_kernel(const bf16_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front-end block 2 (3x3 stride-2 Conv2d over channels-last [B,T,F,Ci] + the 1x1 stride-2 residual conv; SB/lobes/models/convolution.py:
+// 178-266, SB/nnet/CNN.py:629-711) as IMPLICIT GEMMs: the [P, 9*Ci] patch matrix (369 MB at configs[1]) is never built. The loader waves of
+// the ring kernels compute, per LDS-DMA piece, which input pixel a patch row comes from (the padding rule of csrc/frontend.hip's
+// src_index: reflect / causal-zero) and point the DMA there; rows that fall into zero padding read a zero line. Compute waves are the
+// ring kernels' unchanged. Forward: y1 = patches . Wm^T + b1 and y2 = centre tap . W2^T + b2 from the SAME staged A tiles (the centre
+// segment's k-tiles feed a second accumulator against W2, resident in LDS). Filter gradient: dWm[Co, 9Ci] = dY^T . patches with the
+// patch rows gathered as the k-major operand. (The data gradient stays dA = dY . Wm + col2im: a stride-2 tap hits an input pixel 1, 2 or
+// 4 times, plus reflection fix-ups - no single GEMM.)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int B, T, F, To, Fo, Ci, tmode, fmode;   // input [B,T,F,Ci]; output positions P = B*To*Fo; padding modes as csrc/frontend.hip
+};
+__device__ __attribute__((aligned(256))) bf16_t g_conv_zero_line[128];   // zero-initialised: what a patch row in zero padding reads
+
+__device__ __forceinline__ int conv_src_index(int o, int k, int n, int mode) {   // = frontend.hip src_index
+    if (mode == 1) { const int i = 2 * o + k - 2; return i < 0 ? -1 : i; }
+    int i = 2 * o + k - 1;
+    if (mode == 0) { if (i < 0) i = -i; if (i >= n) i = 2 * (n - 1) - i; return i; }
+    return (i < 0 || i >= n) ? -1 : i;
+}
+// output position (b, to, fo) of patch row p - 32-bit arithmetic (P < 2^31 is checked by the launchers): a 64-bit division per DMA piece
+// and k-tile made the loader waves the bottleneck of the first version (conv_s2_wgrad 550 us against 290 us for the im2col + GEMM path)
+struct ConvPos { int b, to, fo; };
+__device__ __forceinline__ ConvPos conv_pos(const ConvGeom &g, unsigned p) {
+    const unsigned q = p / (unsigned)g.Fo;
+    return ConvPos{(int)(q / (unsigned)g.To), (int)(q % (unsigned)g.To), (int)(p - q * (unsigned)g.Fo)};
+}
+// ... advanced by `rows` patch rows (rows / Fo and rows % Fo precomputed: dq, dr) - no division on the per-k-tile path
+__device__ __forceinline__ void conv_pos_advance(const ConvGeom &g, ConvPos &c, int dq, int dr) {
+    c.fo += dr;
+    c.to += dq;
+    if (c.fo >= g.Fo) { c.fo -= g.Fo; c.to += 1; }
+    while (c.to >= g.To) { c.to -= g.To; c.b += 1; }
+}
+// channel vector of the patch row at position c, tap (kt, kf): pointer to x[b, ti, fi, 0] or NULL for zero padding
+__device__ __forceinline__ const bf16_t *conv_row_ptr(const bf16_t *__restrict__ x, const ConvGeom &g, const ConvPos &c, int kt, int kf) {
+    const int ti = conv_src_index(c.to, kt, g.T, g.tmode), fi = conv_src_index(c.fo, kf, g.F, g.fmode);
+    if (ti < 0 || fi < 0) return nullptr;
+    return x + ((long long)(c.b * g.T + ti) * g.F + fi) * g.Ci;
+}
+
+// forward: grid = cdiv(P, 128) workgroups of 8 waves; Co == 128 (one column tile), Ci % 64 == 0
+__global__ __launch_bounds__(RING_THREADS, 1) void conv_s2_fwd_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ Wm /*[128][9Ci]*/,
+                                                                      const float *__restrict__ b1, const bf16_t *__restrict__ W2 /*[128][Ci]*/,
+                                                                      const float *__restrict__ b2, bf16_t *__restrict__ y1, bf16_t *__restrict__ y2,
+                                                                      ConvGeom g, long long P, int centre) {
+    using TA = RingTile<128, false>;
+    using TB = RingTile<128, false>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES, NS = GB_K / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *w2s = smem + RING_STAGES * SLOT;                 // W2 as Ci / 64 k-tiles of TB::BYTES, resident
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3, wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int tps = g.Ci / GB_K;                           // k-tiles per tap segment
+    const int nk = 9 * tps, K = 9 * g.Ci;
+    if (wave8 >= 4) {
+        // ---- loader waves: B (filters) by the regular strided pieces, A by the patch-row gather, W2 once
+        constexpr int LPT = TA::INSTR + TB::INSTR;
+        const bf16_t *gb[TB::INSTR], *g2[TB::INSTR];
+        TB::src_ptrs(Wm, K, 0, 128, 0, wave, lane, gb);
+        TB::src_ptrs(W2, g.Ci, 0, 128, 0, wave, lane, g2);
+        for (int t2 = 0; t2 < tps; ++t2) TB::issue_at(g2, (long long)t2 * GB_K, w2s + t2 * TB::BYTES, wave);
+        ConvPos prow[TA::INSTR];      // this lane's four patch rows: fixed for the whole kernel, only the tap changes with the k-tile
+        int chunk[TA::INSTR];
+#pragma unroll
+        for (int i = 0; i < TA::INSTR; ++i) {
+            const int byte = (i * 4 + wave) * 1024 + lane * 16;
+            const int lrow = byte / TA::ROW_BYTES, pos = (byte % TA::ROW_BYTES) / 16;
+            prow[i] = conv_pos(g, (unsigned)min(m0 + lrow, P - 1));
+            chunk[i] = TA::swz(lrow, pos) * 8;
+        }
+        auto issue = [&](int kt) {
+            char *slot = smem + (kt % RING_STAGES) * SLOT;
+            const int seg = kt / tps, koff = (kt - seg * tps) * GB_K, tap_t = seg / 3, tap_f = seg - 3 * tap_t;
+#pragma unroll
+            for (int i = 0; i < TA::INSTR; ++i) {
+                const bf16_t *rp = conv_row_ptr(x, g, prow[i], tap_t, tap_f);
+                const bf16_t *src = rp ? rp + koff + chunk[i] : g_conv_zero_line + chunk[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
+            TB::issue_at(gb, (long long)kt * GB_K, slot + TA::BYTES, wave);
+        };
+        for (int t = 0; t < RING_STAGES - 1; ++t)
+            if (t < nk) issue(t);
+        for (int kt = 0; kt < nk; ++kt) {
+            ring_wait_landed(min(RING_STAGES - 2, nk - 1 - kt), LPT);     // (the W2 pieces were issued first: landed with tile 0)
+            __builtin_amdgcn_s_barrier();
+            if (kt + RING_STAGES - 1 < nk) issue(kt + RING_STAGES - 1);
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    f32x16 acc[2][2], acc2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x16){0}; acc2[i][j] = (f32x16){0}; }
+    int a_off[2][NS][TA::NFO], b_off[2][NS][TB::NFO];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            TA::frag_offsets(wm * 64 + 32 * i, s, lane, a_off[i][s]);
+            TB::frag_offsets(wn * 64 + 32 * i, s, lane, b_off[i][s]);
+        }
+    const int c_lo = centre * tps, c_hi = c_lo + tps;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        bf16x8 af[2][NS], bfr[2][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i][s] = TA::frag_at(as, a_off[i][s]);
+                bfr[i][s] = TB::frag_at(bs, b_off[i][s]);
+            }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
+        if (kt >= c_lo && kt < c_hi) {      // workgroup-uniform: the centre tap's tiles also feed the 1x1 stride-2 conv
+            const char *b2s = w2s + (kt - c_lo) * TB::BYTES;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                bf16x8 b2f[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b2f[j] = TB::frag_at(b2s, b_off[j][s]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], b2f[j], acc2[i][j], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // the loader waves end behind it; the ring becomes the output staging tile
+    constexpr int LDT = 128 + 8;
+    bf16_t *tile = reinterpret_cast<bf16_t *>(smem);      // [128][LDT] bf16 = 34 KB
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float *bias = which ? b2 : b1;
+        bf16_t *out = which ? y2 : y1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bj = bias[wn * 64 + 32 * j + r];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 16; ++gq) {
+                    const float v = (which ? acc2[i][j][gq] : acc[i][j][gq]) + bj;
+                    tile[(wm * 64 + 32 * i + (gq & 3) + 8 * (gq >> 2) + 4 * hh) * LDT + wn * 64 + 32 * j + r] = (bf16_t)v;
+                }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 128 * 16; c += 256) {
+            const int rr = c >> 4, cc = (c & 15) * 8;
+            if (m0 + rr < P) *reinterpret_cast<uint4 *>(out + (m0 + rr) * 128 + cc) = *reinterpret_cast<const uint4 *>(tile + rr * LDT + cc);
+        }
+        __syncthreads();
+    }
+}
+
+// filter gradient: slab[z][m][n] = sum over the z-th chunk of patch rows p of G[p][m] * patches[p][n_base + n], m < 128 (two 64-row tiles),
+// n < Nout (64-column tiles). grid = (Nout / 64) * 2 * splits workgroups; the slabs are added in fixed order by the caller.
+__global__ __launch_bounds__(RING_THREADS, 1) void conv_s2_wgrad_kernel(const bf16_t *__restrict__ G /*[P][128]*/, const bf16_t *__restrict__ x,
+                                                                        float *__restrict__ slab, ConvGeom g, long long P, int n_base, int Nout,
+                                                                        int kchunk, int nsplit) {
+    using TA = RingTile<64, true>;
+    using TB = RingTile<64, true>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3;
+    int tx, ty, tz;
+    tile_coords(Nout / 64, 2, nsplit, tx, ty, tz);
+    const int m0 = ty * 64, n0 = tx * 64;
+    const long long kbeg = (long long)tz * kchunk, kend = min(P, kbeg + (long long)kchunk);
+    const int nk = (int)((kend - kbeg + GB_K - 1) / GB_K);      // the last k-tile may run past P: its rows are clamped and ZERO-weighted below
+    const int ncol = n_base + n0, seg = ncol / g.Ci, coff = ncol - seg * g.Ci;
+    if (wave8 >= 4) {
+        constexpr int LPT = TA::INSTR + TB::INSTR;
+        int lrow[TB::INSTR], chunk[TB::INSTR];
+        ConvPos pos[TB::INSTR];       // position of this lane's patch rows in the NEXT k-tile to issue (tiles are issued in order: + 64 rows each)
+        const int tap_t = seg / 3, tap_f = seg - 3 * tap_t, dq = GB_K / g.Fo, dr = GB_K - dq * g.Fo;
+#pragma unroll
+        for (int i = 0; i < TB::INSTR; ++i) {
+            const int byte = (i * 4 + wave) * 1024 + lane * 16;
+            lrow[i] = byte / TB::ROW_BYTES;
+            chunk[i] = TB::swz(lrow[i], (byte % TB::ROW_BYTES) / 16) * 8;
+            pos[i] = conv_pos(g, (unsigned)min(kbeg + lrow[i], P - 1));
+        }
+        auto issue = [&](int kt) {
+            char *slot = smem + (kt % RING_STAGES) * SLOT;
+            const long long k0 = kbeg + (long long)kt * GB_K;
+#pragma unroll
+            for (int i = 0; i < TA::INSTR; ++i) {      // dY rows (k-major operand): rows beyond P read the zero line (they must not contribute)
+                const int byte = (i * 4 + wave) * 1024 + lane * 16, lr = byte / TA::ROW_BYTES, ch = TA::swz(lr, (byte % TA::ROW_BYTES) / 16) * 8;
+                const long long p = k0 + lr;
+                const bf16_t *src = p < kend ? G + p * 128 + m0 + ch : g_conv_zero_line + ch;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TB::INSTR; ++i) {
+                const long long p = k0 + lrow[i];
+                const bf16_t *rp = p < kend ? conv_row_ptr(x, g, pos[i], tap_t, tap_f) : nullptr;
+                conv_pos_advance(g, pos[i], dq, dr);
+                const bf16_t *src = rp ? rp + coff + chunk[i] : g_conv_zero_line + chunk[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(slot + TA::BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
+        };
+        for (int t = 0; t < RING_STAGES - 1; ++t)
+            if (t < nk) issue(t);
+        for (int kt = 0; kt < nk; ++kt) {
+            ring_wait_landed(min(RING_STAGES - 2, nk - 1 - kt), LPT);
+            __builtin_amdgcn_s_barrier();
+            if (kt + RING_STAGES - 1 < nk) issue(kt + RING_STAGES - 1);
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    int a_off[2][TA::NFO], b_off[2][TB::NFO];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        TA::frag_offsets(32 * i, wave, lane, a_off[i]);
+        TB::frag_offsets(32 * i, wave, lane, b_off[i]);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = TA::frag_at(as, a_off[i]);
+            bfr[i] = TB::frag_at(bs, b_off[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int LDT = 64 + 4;
+    float *t0 = reinterpret_cast<float *>(smem), *t1 = t0 + 64 * LDT;
+    const int r = lane & 31, hh = lane >> 5;
+    float *mine = (wave & 1) ? t1 : t0;
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gq = 0; gq < 16; ++gq) mine[(32 * i + (gq & 3) + 8 * (gq >> 2) + 4 * hh) * LDT + 32 * j + r] = acc[i][j][gq];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gq = 0; gq < 16; ++gq) {
+                    float *q = mine + (32 * i + (gq & 3) + 8 * (gq >> 2) + 4 * hh) * LDT + 32 * j + r;
+                    *q = acc[i][j][gq] + *q;
+                }
+    }
+    __syncthreads();
+    float *Cf = slab + (long long)tz * 128 * Nout;
+    for (int c = threadIdx.x; c < 64 * 16; c += 256) {
+        const int rr = c >> 4, cc = (c & 15) * 4;
+        const float4 va = *reinterpret_cast<const float4 *>(t0 + rr * LDT + cc), vb = *reinterpret_cast<const float4 *>(t1 + rr * LDT + cc);
+        *reinterpret_cast<float4 *>(Cf + (long long)(m0 + rr) * Nout + n0 + cc) = make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+    }
+}
+
 template <int BM, int BN, bool AT, bool BT>
 struct RingSmem {
     static constexpr size_t PIPE = (size_t)RING_STAGES * (RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES);
@@ -1098,6 +1385,61 @@ int tsasr_gemm_bf16_nt_batched(const void *A, const void *const *btab, void *C, 
     dim3 grid((unsigned)(cdiv(N, 64) * cdiv(M, 64)), (unsigned)nbatch);
     gemm_bf16_ring_kernel<64, 64, false, false, 0><<<grid, RING_THREADS, R::BYTES, (hipStream_t)stream>>>((const bf16_t *)A, nullptr, C, M, N, K, lda, ldb, ldc, K, 0, 1, ep);
     TSASR_CHECK_LAUNCH("tsasr_gemm_bf16_nt_batched");
+    return 0;
+}
+
+/* Front-end block 2 as implicit GEMMs (see conv_s2_fwd_kernel): x [B,T,F,Ci] bf16 channels-last; Wm [128, 9*Ci] = the 3x3 filter as
+ * [Co, (kt, kf, ci)], W2 [128, Ci] the 1x1 filter (both bf16); b1 / b2 fp32 [128]; y1 = conv3x3_s2(x) + b1, y2 = conv1x1_s2(x) + b2, both
+ * [B,T',F',128] bf16. causal: padding rule of the causal front-end (csrc/frontend.hip). Co == 128, Ci % 64 == 0, Ci <= 128. */
+int tsasr_conv3x3s2_fwd(const void *x, const void *Wm, const float *b1, const void *W2, const float *b2, void *y1, void *y2, int B, int T, int F,
+                        int Ci, int Co, int causal, void *stream) {
+    TSASR_CHECK_ARG(x && Wm && b1 && W2 && b2 && y1 && y2, "tsasr_conv3x3s2_fwd: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T >= 2 && F >= 2 && Co == 128 && Ci % 64 == 0 && Ci >= 64 && Ci <= 128, "tsasr_conv3x3s2_fwd: unsupported shape (Ci=%d Co=%d)", Ci, Co);
+    ConvGeom g{B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, Ci, causal ? 1 : 0, causal ? 2 : 0};
+    const long long P = (long long)B * g.To * g.Fo;
+    TSASR_CHECK_ARG(P < (1ll << 31) && (long long)B * T * F < (1ll << 31), "tsasr_conv3x3s2_fwd: more than 2^31 positions");
+    const int lds = RING_STAGES * (RingTile<128, false>::BYTES * 2) + (Ci / GB_K) * RingTile<128, false>::BYTES;
+    (void)hipFuncSetAttribute((const void *)conv_s2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    conv_s2_fwd_kernel<<<(unsigned)((P + 127) / 128), RING_THREADS, lds, (hipStream_t)stream>>>((const bf16_t *)x, (const bf16_t *)Wm, b1, (const bf16_t *)W2, b2,
+                                                                                               (bf16_t *)y1, (bf16_t *)y2, g, P, causal ? 7 : 4);
+    TSASR_CHECK_LAUNCH("tsasr_conv3x3s2_fwd");
+    return 0;
+}
+
+static int conv_wgrad_splits(long long P, int Nout) {
+    const int tiles = (Nout / 64) * 2;
+    int s = std::max(1, 768 / tiles);
+    const long long max_s = std::max<long long>(1, P / (4 * GB_K));
+    return (int)std::min<long long>(std::min<long long>(s, max_s), 64);
+}
+size_t tsasr_conv3x3s2_wgrad_workspace_bytes(int B, int T, int F, int Ci) {
+    const long long P = (long long)B * ((T - 1) / 2 + 1) * ((F - 1) / 2 + 1);
+    return align_up((size_t)conv_wgrad_splits(P, 9 * Ci) * 128 * 9 * Ci * sizeof(float), 256) +
+           align_up((size_t)conv_wgrad_splits(P, Ci) * 128 * Ci * sizeof(float), 256);
+}
+/* dWm [128, 9*Ci] = dy1^T . patches(x), dW2 [128, Ci] = dy2^T . centre tap (fp32, OVERWRITTEN; the workspace holds the split-K slabs, added
+ * in fixed order by two small launches). dy1, dy2 [P, 128] bf16. */
+int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    TSASR_CHECK_ARG(dy1 && dy2 && x && dWm && dW2 && workspace, "tsasr_conv3x3s2_wgrad: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T >= 2 && F >= 2 && Co == 128 && Ci % 64 == 0 && Ci >= 64 && Ci <= 128, "tsasr_conv3x3s2_wgrad: unsupported shape (Ci=%d Co=%d)", Ci, Co);
+    TSASR_CHECK_ARG(workspace_bytes >= tsasr_conv3x3s2_wgrad_workspace_bytes(B, T, F, Ci), "tsasr_conv3x3s2_wgrad: workspace too small");
+    ConvGeom g{B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, Ci, causal ? 1 : 0, causal ? 2 : 0};
+    const long long P = (long long)B * g.To * g.Fo;
+    TSASR_CHECK_ARG(P < (1ll << 31) && (long long)B * T * F < (1ll << 31), "tsasr_conv3x3s2_wgrad: more than 2^31 positions");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int lds = RING_STAGES * 2 * RingTile<64, true>::BYTES;
+    float *slab1 = (float *)workspace;
+    const int s1 = conv_wgrad_splits(P, 9 * Ci), s2 = conv_wgrad_splits(P, Ci);
+    float *slab2 = (float *)((char *)workspace + align_up((size_t)s1 * 128 * 9 * Ci * sizeof(float), 256));
+    const int kc1 = (int)(((P + s1 - 1) / s1 + GB_K - 1) / GB_K * GB_K), kc2 = (int)(((P + s2 - 1) / s2 + GB_K - 1) / GB_K * GB_K);
+    const int z1 = (int)((P + kc1 - 1) / kc1), z2 = (int)((P + kc2 - 1) / kc2);
+    conv_s2_wgrad_kernel<<<(unsigned)((9 * Ci / 64) * 2 * z1), RING_THREADS, lds, st>>>((const bf16_t *)dy1, (const bf16_t *)x, slab1, g, P, 0, 9 * Ci, kc1, z1);
+    conv_s2_wgrad_kernel<<<(unsigned)((Ci / 64) * 2 * z2), RING_THREADS, lds, st>>>((const bf16_t *)dy2, (const bf16_t *)x, slab2, g, P, (causal ? 7 : 4) * Ci, Ci, kc2, z2);
+    // the split-K slabs are added right away, in fixed order (the caller permutes dWm into the reference's filter layout next)
+    gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * 9 * Ci / 4, 256), 256, 0, st>>>(slab1, dWm, 128, 9 * Ci, 9 * Ci, z1, (long long)128 * 9 * Ci, 0);
+    gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * Ci / 4, 256), 256, 0, st>>>(slab2, dW2, 128, Ci, Ci, z2, (long long)128 * Ci, 0);
+    TSASR_CHECK_LAUNCH("tsasr_conv3x3s2_wgrad");
     return 0;
 }
 

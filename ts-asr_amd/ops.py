@@ -1578,6 +1578,18 @@ class _FrontendC1Fn(torch.autograd.Function):
                 _pgrad(prm[3], dpar[Co * 11:]), None)
 
 
+CONV_IMPLICIT = os.environ.get("TSASR_CONV_IMPLICIT", "1") != "0"      # front-end block 2 through the implicit-GEMM kernels (tests / A-B runs switch it off: the im2col path)
+
+
+def _pgrad_view(dwm, Co, Ci, dtype):
+    """dWm [Co, (kt, kf, ci)] fp32 -> the reference's [Co, ci, kF, kT] filter gradient."""
+    return dwm.view(Co, 3, 3, Ci).permute(0, 3, 2, 1).to(dtype)
+
+
+def _pgrad_view2(dw2f, shape, dtype):
+    return dw2f.view(shape).to(dtype)
+
+
 class _FrontendConvFn(torch.autograd.Function):
     """Wider blocks: HIP tap gather (im2col, padding rule folded in) + library GEMMs + HIP inverse gather (col2im)."""
 
@@ -1589,14 +1601,25 @@ class _FrontendConvFn(torch.autograd.Function):
         Co = w1.shape[0]
         To, Fo = _out_len(T), _out_len(Fq)
         P = B * To * Fo
-        A = torch.empty(P, 9 * Ci, dtype=xc.dtype, device=xc.device)
-        with prof.region("frontend_im2col"):
-            C.check(C.lib().tsasr_frontend_im2col(C.ptr(xc), C.ptr(A), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
-                    "tsasr_frontend_im2col")
         wm = w1.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype).contiguous()   # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]
         w2m = w2.reshape(Co, Ci).to(xc.dtype).contiguous()
         centre = 7 if causal else 4                                      # the tap that reads x[2t', 2f']
         hip = xc.dtype == torch.bfloat16 and Ci % 8 == 0 and Co % 8 == 0
+        implicit = hip and CONV_IMPLICIT and Co == 128 and Ci in (64, 128)
+        if implicit:   # implicit GEMM: the loader waves gather the patch rows - no [P, 9*Ci] matrix in HBM, nothing but x kept for the backward
+            y1 = torch.empty(B, To, Fo, Co, dtype=xc.dtype, device=xc.device)
+            y2 = torch.empty(B, To, Fo, Co, dtype=xc.dtype, device=xc.device)
+            with prof.region("conv3x3s2_fwd", 2.0 * P * Co * 10 * Ci):
+                C.check(C.lib().tsasr_conv3x3s2_fwd(C.ptr(xc), C.ptr(wm), C.ptr(_f32(b1).contiguous()), C.ptr(w2m), C.ptr(_f32(b2).contiguous()),
+                                                    C.ptr(y1), C.ptr(y2), B, T, Fq, Ci, Co, int(causal), C.stream_ptr()), "tsasr_conv3x3s2_fwd")
+            ctx.save_for_backward(xc, wm, w2m)
+            ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape, hip)
+            ctx.biases, ctx.implicit = (b1, b2), True
+            return y1, y2
+        A = torch.empty(P, 9 * Ci, dtype=xc.dtype, device=xc.device)
+        with prof.region("frontend_im2col"):
+            C.check(C.lib().tsasr_frontend_im2col(C.ptr(xc), C.ptr(A), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
+                    "tsasr_frontend_im2col")
         if hip:   # HIP GEMMs: y1 = A . wm^T ; y2 = A[:, centre tap] . w2m^T (strided rows, lda = 9*Ci)
             # bias in the GEMM epilogue (mode 1 with no activation, no dropout): no separate pass over the 41 MB outputs
             y1 = gemm_bf16_fused(A, wm, P, Co, 9 * Ci, 9 * Ci, 9 * Ci, 0, 0, 1, bias=_f32(b1).contiguous()).view(B, To, Fo, Co)
@@ -1608,6 +1631,7 @@ class _FrontendConvFn(torch.autograd.Function):
             Ac = A.view(P, 9, Ci)[:, centre, :]
             y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
             y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
+        ctx.implicit = False
         ctx.save_for_backward(A, wm, w2m)
         ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape, hip)
         ctx.biases = (b1, b2)
@@ -1617,8 +1641,24 @@ class _FrontendConvFn(torch.autograd.Function):
     def backward(ctx, dy1, dy2):
         A, wm, w2m = ctx.saved_tensors
         causal, (B, T, Fq, Ci), Co, centre, dw1t, db1t, dw2t, db2t, w2shape, hip = ctx.cfg
-        P = A.shape[0]
+        P = B * _out_len(T) * _out_len(Fq)
         g1, g2 = dy1.reshape(P, Co).contiguous(), dy2.reshape(P, Co).contiguous()
+        if ctx.implicit:    # A is x itself: the filter gradients gather their patch rows in the loader waves; the data gradient is dA + col2im
+            xc = A
+            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=xc.device)
+            dw2f = torch.empty(Co, Ci, dtype=torch.float32, device=xc.device)
+            ws = _ws(C.lib().tsasr_conv3x3s2_wgrad_workspace_bytes(B, T, Fq, Ci), xc.device)
+            with prof.region("conv3x3s2_wgrad", 2.0 * P * Co * 10 * Ci):
+                C.check(C.lib().tsasr_conv3x3s2_wgrad(C.ptr(g1), C.ptr(g2), C.ptr(xc), C.ptr(dwm), C.ptr(dw2f), B, T, Fq, Ci, Co, int(causal),
+                                                      C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_conv3x3s2_wgrad")
+            dA = gemm_bf16(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)                                         # g1 . wm
+            dR = gemm_bf16(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
+            db1, db2 = _pgrad(ctx.biases[0], colsum(g1)), _pgrad(ctx.biases[1], colsum(g2))
+            dx = torch.empty(B, T, Fq, Ci, dtype=xc.dtype, device=xc.device)
+            with prof.region("frontend_col2im"):
+                C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
+                        "tsasr_frontend_col2im")
+            return dx, _pgrad_view(dwm, Co, Ci, dw1t), db1, _pgrad_view2(dw2f, w2shape, dw2t), db2, None
         if hip:
             dwm = gemm_bf16(g1, A, Co, 9 * Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32)              # g1^T . A
             dw2 = gemm_bf16(g2, A[:, centre * Ci:], Co, Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32).view(w2shape).to(dw2t)
