@@ -306,9 +306,10 @@ def main():
                      "allreduce_busbw_GBps": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1),
                      "rehearsal_on_one_gpu": os.environ.get("TSASR_DIST_BACKEND") == "gloo"}
     nonfinite = brain.flush_nonfinite()
-    # per-launch durations: plain mean of the HIP-event brackets of every instrumented launch (no fastest-of-N, no subtraction of the
-    # empty event-pair time: the figure errs on the slow side of rocprofv3's kernel durations, profiles/r02_kernel_trace.md)
-    kern = prof.collect(subtract_overhead=False, repeats=3 if graphed else args.steps, fastest=False)
+    # per-launch durations: mean of the HIP-event brackets of every instrumented launch, NET of the empty event-pair time measured in
+    # this process (prof.event_overhead_ms x 0.8, ~3 us: the bracket's own two timestamp packets) - without it the brackets read 17 us
+    # where rocprofv3 (profiles/r04_kernel_trace.md) reads 11.7 us for the same launches; no fastest-of-N
+    kern = prof.collect(subtract_overhead=True, repeats=3 if graphed else args.steps, fastest=False)
 
     if rank == 0:
         frames = world * B_LOCAL * T_MEL * args.steps
@@ -341,7 +342,7 @@ def main():
             roof = {"kernel": dom, "bound": "mfma", "achieved": fam[dom]["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fam[dom]["TFLOPps"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                     "algorithmic_flops_per_launch": fam[dom]["avg_GFLOP_per_launch"] * 1e9, "avg_launch_ms": fam[dom]["avg_ms"],
-                    "note": "dominant kernel = the rocprofv3 kernel name (template instantiation) with the largest share of the step among the hand-written launches; achieved = sum of 2*M*N*K of its launches / sum of their HIP-event durations on the launch stream (plain mean over 3 instrumented eager steps of this process, nothing subtracted)"}
+                    "note": "dominant kernel = the rocprofv3 kernel name (template instantiation) with the largest share of the step among the hand-written launches; achieved = sum of 2*M*N*K of its launches / sum of their HIP-event durations on the launch stream (mean over 3 instrumented eager steps of this process, net of the measured empty event-pair time: event_pair_overhead_ms)", "event_pair_overhead_ms": round(prof.out_overhead[0], 5)}
         elif dom is not None and dom in ab:
             ach = ab[dom] / (fam[dom]["avg_ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
