@@ -212,7 +212,7 @@ def main():
     dp = importlib.import_module(PKG + ".dp")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") always, except for the one-GPU rehearsal of the multi-rank code path (tools/ddp_rehearsal.sh)
+        # RCCL ("nccl") always, except for the one-GPU rehearsal of the multi-rank code path (`python bench.py --gpus N` with fewer visible GPUs)
         dp.ddp_init_group({"distributed_launch": True, "distributed_backend": os.environ.get("TSASR_DIST_BACKEND", "nccl")})
     prof = importlib.import_module(PKG + ".prof")
     batch_mod = importlib.import_module(PKG + ".batch")

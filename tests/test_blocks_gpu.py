@@ -483,6 +483,27 @@ def test_lstm_exact_fp32_vs_float64_and_stepwise(ops, B, U, I, H):
         assert torch.equal(torch.cat(outs, 1), out.detach()) and torch.equal(hid[0], hn.detach()) and torch.equal(hid[1], cn.detach())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["sum", "prod"])
+def test_speaker_injection_kernels(ops, dtype, mode):
+    """tsasr_inject_fwd / _bwd (the `sum` / `prod` injections, models/conformer.py:247-253) against the broadcast expression in float64:
+    values, dsrc and the time-summed dspk; odd T, D not a multiple of 64."""
+    B, Tn, D = 3, 37, 72
+    g = torch.Generator().manual_seed(3)
+    src, spk, dout = torch.randn(B, Tn, D, generator=g), torch.randn(B, 1, D, generator=g), torch.randn(B, Tn, D, generator=g)
+    a, b = src.to(dtype).double().requires_grad_(), spk.to(dtype).double().requires_grad_()
+    ref = a * b if mode == "prod" else a + b
+    ref.backward(dout.to(dtype).double())
+    x, y = src.to(DEV).to(dtype).requires_grad_(), spk.to(DEV).to(dtype).requires_grad_()
+    assert ops.inject_ok(x, y)
+    out = ops.inject(x, y, mode)
+    out.backward(dout.to(DEV).to(dtype))
+    tol = 1e-6 if dtype == torch.float32 else 6e-3     # bf16: one rounding of each output (and of the 37-term sum)
+    for got, want in ((out, ref), (x.grad, a.grad), (y.grad, b.grad)):
+        rel = float((got.detach().double().cpu() - want.detach()).norm() / want.detach().norm())
+        assert rel < tol, (mode, rel)
+
+
 def test_fused_attention_dropout_consistency(ops):
     """With dropout the backward must regenerate the forward's mask: check d(out)/d(V) . dout == out . dout structure via
     finite differences on V (out is linear in V for a fixed mask)."""

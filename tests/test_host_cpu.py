@@ -326,7 +326,7 @@ def test_no_packed_fp32_instructions_in_device_code(tmp_path):
     halves picked by op_sel) of one wave occasionally return wrong values while ANOTHER hardware queue's MFMA kernel runs beside it:
     round 1 met it as run-to-run different low bits of one `v_pk_add_f32 op_sel` sum, round 3 as one corrupted FFT frame of the log-mel
     kernel per ~40 launches beside the per-step LSTM kernels - in eager two-stream runs and in hipGraph replays alike, 0 of 128,000
-    launches once the instructions are gone (profiles/r03_notes.md section 1, tools/lds_overlap.py, tools/fbank_corunner.py). The library
+    launches once the instructions are gone (profiles/r03_notes.md section 1). The library
     is therefore compiled with the subtarget feature off (csrc/Makefile, NOPK); this check disassembles every gfx950 code object of the
     built library and accepts no packed-fp32 arithmetic at all."""
     import glob

@@ -32,7 +32,7 @@ if [ -s $O/rccl_timeline.txt ]; then
   {
     echo "# $TAG: real RCCL collectives captured in the step's hipGraph (ONE-rank communicator, one GPU)"
     echo
-    echo "rocprofv3 --kernel-trace of \`tools/rccl_single_rank_check.py\` (tools/profile_rccl.sh): the gradient arena is told there are two ranks, so"
+    echo "rocprofv3 --kernel-trace of \`tests/helpers/rccl_single_rank_check.py\`: the gradient arena is told there are two ranks, so"
     echo "every bucket all-reduce of the step is issued through csrc/comm.hip (bare ncclAllReduce on the communication stream), captured into"
     echo "the hipGraph with the rest of the step and replayed. On a one-rank communicator RCCL's all-reduce kernel is \`oneRankReduce\`. This"
     echo "shows capture + replay + placement beside backward; it does NOT validate N > 1 (no multi-GPU box in the development loop)."

@@ -14,5 +14,6 @@ python tools/trace_summary.py $db --steps 17 --top 80 > $O/trace_summary.txt
 python tools/stream_timeline.py $db --names > $O/timeline.txt 2>&1 || true
 python tools/stream_timeline.py $db --dump 2.60 2.90 > $O/dump_fwd_layer.txt 2>&1 || true      # one mixture layer forward ...
 python tools/stream_timeline.py $db --dump 5.20 5.60 > $O/dump_bwd_layer.txt 2>&1 || true      # ... and backward, kernel by kernel
+python tools/stream_timeline.py $db --dump 1.40 2.10 > $O/dump_fwd_beside_lstm.txt 2>&1 || true  # the layers that run beside the persistent LSTM forward
 rm -rf $O/prof
 tail -4 $O/bench_prof.log | cut -c1-300

@@ -1211,7 +1211,7 @@ template <int BM, int BN, bool AT, bool BT, int OUT_MODE>
 static void launch(const void *A, const void *B, void *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int splits,
                    int kchunk, long long slab_stride, hipStream_t st, const EpiArgs &ep) {
     dim3 grid((unsigned)(cdiv(N, BN) * cdiv(M, BM) * splits));   // 1-D: tile coordinates come from the XCD-aware remap
-    // measured (tools/gemm_bench.py, tools/fwd_sweep.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles and
+    // measured (tools/gemm_bench.py, interleaved A/B): the DMA ring wins once a workgroup walks >= 16 k-tiles and
     // for the smaller macro-tiles at any K (3 workgroups per CU); the register-staged loop wins for 128x128 at short K (K = 256)
     const bool ring = g_use_ring && (K % GB_K == 0) && (kchunk % GB_K == 0) && (g_use_ring == 2 || min(K, kchunk) >= 1024 || BM * BN < 128 * 128) &&
                       (AT ? M >= 8 : true) && (BT ? N >= 8 : true);
@@ -1278,7 +1278,7 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
     const long long t0 = (long long)cdiv(M, 128) * cdiv(N, 128), t1 = (long long)cdiv(M, 128) * cdiv(N, 64),
                     t2 = (long long)cdiv(M, 64) * cdiv(N, 64);
     // the largest macro-tile that still gives every CU work: 128x128 needs >= 2 tiles per CU (below that the 128x64 ring kernel
-    // wins by 5-20% at N <= 768: tools/fwd_sweep.py), 128x64 needs ~one per CU
+    // wins by 5-20% at N <= 768), 128x64 needs ~one per CU
     static const int thr0 = 512, thr1 = 192;
     p.tile = t0 >= thr0 ? 0 : (t1 >= thr1 ? 1 : 2);
     const long long tiles = p.tile == 0 ? t0 : (p.tile == 1 ? t1 : t2);
@@ -1288,7 +1288,7 @@ static GemmPlan plan(int M, int N, int K, int out_f32) {
         // weight gradients: few output tiles, long inner dimension -> split it (fp32 slabs, reduced in fixed order). Both operands
         // are k-major, i.e. every fragment comes through ds_read_b64_tr_b16, and that path - not the DMA, not VALU, not MFMA - is
         // what bounds these kernels (the same tiles read with ds_read_b128, wrong results, run in 21.5 us instead of 30.1 us).
-        // Macro-tile / split sweeps (tools/wgrad_sweep.py) stay within 10% of this choice in isolation and within noise in the step.
+        // Macro-tile / split sweeps stay within 10% of this choice in isolation and within noise in the step.
         // target: 3 workgroups per CU. Measured on the whole step (A/B in one process group, same box): 256 -> 19.0 ms, 384 -> 18.0,
         // 512 -> 17.65, 640 / 768 -> 17.4, 896 -> 17.85, 1024 -> 17.8 (more slabs = more bytes for the batched reduction).
         static const int target = 768;

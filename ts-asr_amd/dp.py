@@ -165,7 +165,7 @@ class GradArena:
         # gradient contributions per parameter and backward pass (a weight used by two GEMMs - the two halves of the `cat` injection's
         # projection - reports twice): recorded on the unordered first pass; a bucket is complete when ALL of them are in. Counting
         # parameters instead sent layer 0's bucket one contribution early and the late one landed on top of the averaged gradient -
-        # ranks drifted apart (tools/dp_gloo_gpu_check.py)
+        # ranks drifted apart (tests/helpers/dp_gloo_gpu_check.py)
         self._contrib, self._contrib_step = {}, {}
         self._handles, self.sent_log, self._next_send = [], [], 0
         self.aux_streams, self._main_stream = [], None

@@ -1591,7 +1591,9 @@ def _pgrad_view2(dw2f, shape, dtype):
 
 
 class _FrontendConvFn(torch.autograd.Function):
-    """Wider blocks: HIP tap gather (im2col, padding rule folded in) + library GEMMs + HIP inverse gather (col2im)."""
+    """A ConvBlock's two convolutions for C_in > 1 (SB/lobes/models/convolution.py:178-266): bf16, C_in in {64, 128}, C_out = 128 = implicit GEMMs
+    (csrc/gemm.hip conv_s2_*: the ring kernels' loader waves gather the 3x3 patch rows; forward and filter gradients; the data gradient is
+    dy . Wm + the inverse gather col2im). Other shapes / fp32: the tap gather (im2col, padding rule folded in) + the HIP GEMMs + col2im."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, causal):
