@@ -646,7 +646,9 @@ __global__ void joint_bwd_reduce_kernel(const float *__restrict__ slab_w, const 
 // ============================================================================================
 struct RnntWs {
     float *lpb, *lpe_in, *lpe_out, *alpha, *beta, *lse, *logp;
-    int U1P, K;
+    int U1P, K;      // padded columns per frame; columns per lane of the ONE-wave layout
+    int KT, NW;      // the lattice kernel's plan: columns per thread, waves per (utterance, direction)
+    int R, sh;       // rows per utterance plane; column -> skew shift (31: no skew)
 };
 
 static int rnnt_K(int U1) {
@@ -655,16 +657,51 @@ static int rnnt_K(int U1) {
     return K;
 }
 
+// Lattice plan: columns per thread x waves of rnnt_alphabeta_kernel, and whether the planes are stored SKEWED.
+// A lattice step is an anti-diagonal: thread g (columns KT*g ..) works on frame t = s - g (alpha) resp. t + g = const (beta). Stored frame-major
+// (row t), the 64 lanes of a wave touch 64 different rows per load / store - 64 cache lines per wave-instruction through the CU's one address
+// path: at B = 1, T' = 4000, U = 1920 the four waves spent 1.36 us per step on six such instructions (5.8 ms per direction, "17 GB/s"). Stored at
+// row t + g(u) instead (g(u) = u / KT; G - 1 more rows per utterance), a step's operands and results are ONE contiguous row for the whole
+// workgroup, in both directions. The layout is private to this file: rnnt_lp writes it, rnnt_grad reads it through ws_at().
+// TSASR_RNNT_SKEW: 0 never, 1 (default) when the lattice runs on more than one wave, 2 always;  TSASR_RNNT_WAVES caps the waves.
+static void rnnt_plan(int U1, int *KT, int *NW, int *skew) {
+    static const int max_waves = getenv("TSASR_RNNT_WAVES") ? std::max(1, atoi(getenv("TSASR_RNNT_WAVES"))) : 8;
+    static const int skew_mode = getenv("TSASR_RNNT_SKEW") ? atoi(getenv("TSASR_RNNT_SKEW")) : 1;
+    const int K = rnnt_K(U1);
+    int nw = 1;
+    if (K >= 8) {                                  // at least 2 columns per thread
+        nw = std::min(max_waves, K / 2);
+        while (nw & (nw - 1)) nw &= nw - 1;        // power of two
+    }
+    *KT = K / nw;
+    *NW = nw;
+    *skew = skew_mode == 2 || (skew_mode == 1 && nw > 1);
+}
+
+static size_t rnnt_plane_floats(int B, int T, int U1) {
+    int kt, nw, skew;
+    rnnt_plan(U1, &kt, &nw, &skew);
+    return (size_t)B * (T + (skew ? 64 * nw - 1 : 0)) * 64 * rnnt_K(U1);
+}
+
 static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
     RnntWs w;
+    int skew;
     w.K = rnnt_K(U1);
     w.U1P = 64 * w.K;
-    const size_t n = (size_t)B * T * w.U1P;
+    rnnt_plan(U1, &w.KT, &w.NW, &skew);
+    w.R = T + (skew ? 64 * w.NW - 1 : 0);
+    w.sh = 31;
+    if (skew) { w.sh = 0; while ((1 << w.sh) < w.KT) ++w.sh; }
+    const size_t n = rnnt_plane_floats(B, T, U1);
     float *p = reinterpret_cast<float *>(ws);
     w.lpb = p; w.lpe_in = p + n; w.lpe_out = p + 2 * n; w.alpha = p + 3 * n; w.beta = p + 4 * n; w.lse = p + 5 * n;
     w.logp = p + 6 * n;
     return w;
 }
+
+// element (b, t, u) of a lattice plane
+__device__ __forceinline__ size_t ws_at(const RnntWs &w, int b, int t, int u) { return ((size_t)b * w.R + t + (u >> w.sh)) * w.U1P + u; }
 
 __device__ __forceinline__ float logaddexp_f(float a, float b) {
     const float m = fmaxf(a, b);
@@ -711,13 +748,13 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
         s += dpp_mov<0x141>(s);  vb += dpp_mov<0x141>(vb);  vl += dpp_mov<0x141>(vl);
         if (sub == 0) {
             const float lse = m + __logf(s);
-            const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+            const size_t o = ws_at(w, b, t, u);
             w.lse[o] = lse;
             w.lpb[o] = vb - lse;
             if (u < Ub) {
                 const float e = vl - lse;
                 w.lpe_out[o] = e;
-                w.lpe_in[o + 1] = e;
+                w.lpe_in[ws_at(w, b, t, u + 1)] = e;
             }
         }
         return;
@@ -749,13 +786,13 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
     s += dpp_mov<0x141>(s);
     if (sub == 0) {
         const float lse = m + __logf(s);
-        const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+        const size_t o = ws_at(w, b, t, u);
         w.lse[o] = lse;
         w.lpb[o] = rowp[blank] - lse;
         if (u < Ub) {
             const float e = rowp[min(max(targets[(size_t)b * ldt + u], 0), V - 1)] - lse;
             w.lpe_out[o] = e;
-            w.lpe_in[o + 1] = e;
+            w.lpe_in[ws_at(w, b, t, u + 1)] = e;
         }
     }
 }
@@ -775,7 +812,7 @@ __device__ __forceinline__ void ab_step_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int K, int NW>
+template <int K, int NW, bool SKEW>
 __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const int32_t *__restrict__ tlen,
                                                                  const int32_t *__restrict__ ulen, float *__restrict__ costs,
                                                                  int Tn, int U1) {
@@ -784,8 +821,9 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1, g = threadIdx.x, l = g & 63, wave = g >> 6;
     const int U1P = w.U1P;
     const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
-    const size_t base = (size_t)b * Tn * U1P + (size_t)K * g;
+    const size_t base = (size_t)b * w.R * U1P + (size_t)K * g;
     const int nsteps = Tb + G - 1;
+    const int rmax = w.R - 1;     // SKEW: frame t of this thread's columns is row t + g, and a step touches ONE row for the whole workgroup
     float prev[K], cur[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) prev[i] = cur[i] = NEG_INF;
@@ -798,8 +836,9 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
     if (dir == 0) {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
             const int t = min(max(ss - g, 0), Tb - 1);
-            const float *pb = w.lpb + base + (size_t)(t > 0 ? t - 1 : 0) * U1P;
-            const float *pe = w.lpe_in + base + (size_t)t * U1P;
+            // SKEW: rows ss - 1 and ss whatever the thread's frame is (outside its frames the values are not used)
+            const float *pb = w.lpb + base + (size_t)(SKEW ? min(max(ss - 1, 0), rmax) : (t > 0 ? t - 1 : 0)) * U1P;
+            const float *pe = w.lpe_in + base + (size_t)(SKEW ? min(ss, rmax) : t) * U1P;
 #pragma unroll
             for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
         };
@@ -832,7 +871,9 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                     if (u > Ub) a = NEG_INF;
                     nv[i] = a;
                 }
-                float *pa = w.alpha + base + (size_t)tc * U1P;
+                // SKEW: outside its frames a thread writes the slot of a frame that does not exist (row s, its own columns) or, in the
+                // clamped rows past the last step, its unchanged last value over itself
+                float *pa = w.alpha + base + (size_t)(SKEW ? min(s, rmax) : tc) * U1P;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     cur[i] = valid ? nv[i] : cur[i];
@@ -853,15 +894,16 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
 #pragma unroll
         for (int i = 0; i < K; ++i)
             if (K * g + i == Ub) {
-                const float lp = cur[i] + w.lpb[base + (size_t)(Tb - 1) * U1P + i];
+                const float lp = cur[i] + w.lpb[base + (size_t)(Tb - 1 + (SKEW ? g : 0)) * U1P + i];
                 w.logp[b] = lp;
                 costs[b] = -lp;
             }
     } else {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
             const int t = min(max(Tb - 1 - (ss - (G - 1 - g)), 0), Tb - 1);
-            const float *pb = w.lpb + base + (size_t)t * U1P;
-            const float *pe = w.lpe_out + base + (size_t)t * U1P;
+            const int row = SKEW ? min(max(Tb + G - 2 - ss, 0), rmax) : t;      // t + g is the same for every thread of a step
+            const float *pb = w.lpb + base + (size_t)row * U1P;
+            const float *pe = w.lpe_out + base + (size_t)row * U1P;
 #pragma unroll
             for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
         };
@@ -889,7 +931,7 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                     if (u > Ub) v = NEG_INF;
                     nv[i] = v;
                 }
-                float *pbeta = w.beta + base + (size_t)tc * U1P;
+                float *pbeta = w.beta + base + (size_t)(SKEW ? min(max(Tb + G - 2 - s, 0), rmax) : tc) * U1P;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     cur[i] = valid ? nv[i] : cur[i];
@@ -925,7 +967,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict_
         for (int c = sub * 4; c < ldl; c += 32) *reinterpret_cast<float4 *>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const size_t o = ((size_t)b * Tn + t) * w.U1P + u;
+    const size_t o = ws_at(w, b, t, u);
     const float logp = w.logp[b], a = w.alpha[o], be = w.beta[o], lse = w.lse[o], lpb = w.lpb[o];
     const float gs = gscale[b];
     const float c0 = a + be - logp - lse;
@@ -936,7 +978,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict_
     float gemit = 0.f;
     if (u < Ub) {
         lab = min(max(targets[(size_t)b * ldt + u], 0), V - 1);
-        gemit = __expf(a + w.lpe_out[o] + w.beta[o + 1] - logp);
+        gemit = __expf(a + w.lpe_out[o] + w.beta[ws_at(w, b, t, u + 1)] - logp);
     }
     const float *rowp = logits + row * ldl;
     for (int c = sub * 4; c < ldl; c += 32) {
@@ -959,38 +1001,22 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict_
 
 template <int K, int NW>
 static void launch_ab(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
-    rnnt_alphabeta_kernel<K, NW><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    if (w.sh != 31) rnnt_alphabeta_kernel<K, NW, true><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    else rnnt_alphabeta_kernel<K, NW, false><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
 }
 
-// columns per lane of the one-wave layout -> (columns per thread, waves): TSASR_RNNT_WAVES caps the waves (1 = always one wave)
-static void launch_alphabeta(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
-    // measured at B = 1, T' = 4000, U = 1920 (32 columns per lane in one wave): 1 wave 50.5 ms, 2 waves 12.7, 4 waves 6.2, 8 waves 8.9,
-    // 16 waves 15.3 - with four waves the kernel streams its 100 MB of log-probabilities and alphas at what ONE CU pulls from HBM
-    // (~17 GB/s); more waves only add barrier arrivals per step. (Spreading one utterance over several CUs is the next step.)
-    static const int max_waves = 4;
-    const int waves = std::min(max_waves, w.K >= 8 ? w.K / 4 : 1);
-    switch (w.K) {
-        case 1: launch_ab<1, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 2: launch_ab<2, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 4: launch_ab<4, 1>(w, tlen, ulen, costs, B, T, U1, st); break;
-        case 8:
-            if (waves >= 4) launch_ab<2, 4>(w, tlen, ulen, costs, B, T, U1, st);
-            else if (waves >= 2) launch_ab<4, 2>(w, tlen, ulen, costs, B, T, U1, st);
-            else launch_ab<8, 1>(w, tlen, ulen, costs, B, T, U1, st);
-            break;
-        case 16:
-            if (waves >= 8) launch_ab<2, 8>(w, tlen, ulen, costs, B, T, U1, st);
-            else if (waves >= 4) launch_ab<4, 4>(w, tlen, ulen, costs, B, T, U1, st);
-            else launch_ab<16, 1>(w, tlen, ulen, costs, B, T, U1, st);
-            break;
-        default:
-            if (waves >= 16) launch_ab<2, 16>(w, tlen, ulen, costs, B, T, U1, st);
-            else if (waves >= 8) launch_ab<4, 8>(w, tlen, ulen, costs, B, T, U1, st);
-            else if (waves >= 4) launch_ab<8, 4>(w, tlen, ulen, costs, B, T, U1, st);
-            else if (waves >= 2) launch_ab<16, 2>(w, tlen, ulen, costs, B, T, U1, st);
-            else launch_ab<32, 1>(w, tlen, ulen, costs, B, T, U1, st);
-            break;
-    }
+// (columns per thread, waves) from rnnt_plan. Measured at B = 1, T' = 4000, U = 1920 with frame-major planes (round 2): 1 wave 50.5 ms, 2 waves
+// 12.7, 4 waves 6.2, 8 waves 8.9, 16 waves 15.3 - every added wave brought its own 64-line loads and stores; with skewed planes see rnnt_plan.
+static int launch_alphabeta(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
+#define AB_CASE(K_, NW_) if (w.KT == K_ && w.NW == NW_) { launch_ab<K_, NW_>(w, tlen, ulen, costs, B, T, U1, st); return 0; }
+    AB_CASE(1, 1) AB_CASE(2, 1) AB_CASE(4, 1) AB_CASE(8, 1) AB_CASE(16, 1) AB_CASE(32, 1)
+    AB_CASE(4, 2) AB_CASE(8, 2) AB_CASE(16, 2)
+    AB_CASE(2, 4) AB_CASE(4, 4) AB_CASE(8, 4)
+    AB_CASE(2, 8) AB_CASE(4, 8)
+    AB_CASE(2, 16)
+#undef AB_CASE
+    tsasr_set_error("tsasr_rnnt_loss_fwd: no lattice kernel for %d columns per thread x %d waves", w.KT, w.NW);
+    return TSASR_E_INVALID;
 }
 
 // ============================================================================================
@@ -1132,8 +1158,7 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
 
 size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0) return 0;
-    const size_t n = (size_t)B * T * 64 * rnnt_K(U1);
-    return align_up((6 * n + (size_t)B) * sizeof(float), 256);
+    return align_up((6 * rnnt_plane_floats(B, T, U1) + (size_t)B) * sizeof(float), 256);
 }
 
 int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen, const int32_t *ulen,
@@ -1149,7 +1174,7 @@ int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, co
     RnntWs w = rnnt_carve(workspace, B, T, U1);
     const long long rows = (long long)B * T * U1;
     rnnt_lp_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(logits, targets, ldt, tlen, ulen, w, B, T, U1, V, ldl, blank);
-    launch_alphabeta(w, tlen, ulen, costs, B, T, U1, st);
+    if (int rc = launch_alphabeta(w, tlen, ulen, costs, B, T, U1, st)) return rc;
     TSASR_CHECK_LAUNCH("tsasr_rnnt_loss_fwd");
     return 0;
 }
