@@ -83,6 +83,12 @@ int tsasr_rnnt_loss_bwd(const float *logits, const int32_t *targets, int ldt, co
                         const int32_t *ulen, const float *gscale /* [B] */, float *dlogits,
                         int B, int T, int U1, int V, int ldl, int blank,
                         const void *workspace, size_t workspace_bytes, void *stream);
+/* Lab / test switch, no reference counterpart: how the next tsasr_rnnt_loss_* calls lay out and walk the alpha / beta lattice (-1 = the
+ * default of each): skew 0 / 1 / 2 = frame-major planes always / anti-diagonal ("skewed") planes when a lattice runs on more than one
+ * wave / always; waves = cap on the waves of a one-workgroup lattice; mc = 0 never split a lattice over workgroups, 1 / 2 / 4 = split
+ * whenever the blocks fit on the chip, that many columns per thread. Changes tsasr_rnnt_loss_workspace_bytes; the forward and backward of
+ * one loss must run under the same plan. Every plan returns the same bits (tests/test_rnnt_gpu.py). */
+void tsasr_rnnt_lattice_plan(int skew, int waves, int mc);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -110,6 +110,42 @@ def test_loss_and_grad(rn, B, T, U1, V, tlen, ulen):
         assert np.all(g[b, tlen[b]:] == 0) and np.all(g[b, :, ulen[b] + 1:] == 0)
 
 
+PLAN_CASES = [
+    (3, 70, 520, 7, [70, 41, 9], [519, 300, 64]),       # K = 16: ragged in both directions, one utterance shorter than the 64-step ramp
+    (1, 200, 1100, 5, [200], [1099]),                    # K = 32: the long-form layout (16 column blocks when split)
+    (2, 5, 300, 6, [5, 1], [299, 0]),                    # K = 8: fewer frames than one prefetch window; an empty target
+]
+
+
+@pytest.mark.parametrize("B,T,U1,V,tlen,ulen", PLAN_CASES)
+def test_lattice_plans_give_the_same_bits(rn, B, T, U1, V, tlen, ulen):
+    """Every way csrc/rnnt.hip walks a long lattice - frame-major planes with 4 waves (round 3), anti-diagonal planes with 4 / 8 / 16 waves,
+    one single-wave workgroup per block of 64 / 128 / 256 columns with the edge values handed from block to block through global memory -
+    returns the same costs and gradients bit for bit, and they match the float64 oracle."""
+    C = importlib.import_module("ts-asr_amd._capi")
+    rng = np.random.default_rng(B * 977 + U1)
+    lg = (rng.standard_normal((B, T, U1, V)) * 2).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, U1 - 1)).astype(np.int32)
+    costs_ref, grads_ref = RR.rnnt_costs_grads(lg, tg, tlen, ulen, 0)
+    plans = [(0, 4, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 1, 0), (1, 8, 1), (1, 8, 2), (1, 8, 4), (-1, -1, -1)]
+    outs = []
+    try:
+        for plan in plans:
+            C.lib().tsasr_rnnt_lattice_plan(*plan)
+            x = torch.from_numpy(lg).to(DEV).requires_grad_()
+            costs = rn.rnnt_costs(x, torch.from_numpy(tg).to(DEV), torch.tensor(tlen, device=DEV, dtype=torch.int32),
+                                  torch.tensor(ulen, device=DEV, dtype=torch.int32), 0)
+            costs.sum().backward()
+            outs.append((costs.detach().cpu().numpy(), x.grad.cpu().numpy()))
+    finally:
+        C.lib().tsasr_rnnt_lattice_plan(-1, -1, -1)
+    np.testing.assert_allclose(outs[0][0], costs_ref, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(outs[0][1], grads_ref, atol=3e-5, rtol=max(1e-3, 5e-5 * (T + U1)))
+    for plan, (c, g) in zip(plans[1:], outs[1:]):
+        assert np.array_equal(c, outs[0][0]), plan
+        assert np.array_equal(g, outs[0][1]), plan
+
+
 def test_loss_rejects_bad_arguments(rn):
     C = importlib.import_module("ts-asr_amd._capi")
     lg = torch.zeros(1, 2, 3, 5, device=DEV)

@@ -645,9 +645,9 @@ __global__ void joint_bwd_reduce_kernel(const float *__restrict__ slab_w, const 
 // loss
 // ============================================================================================
 struct RnntWs {
-    float *lpb, *lpe_in, *lpe_out, *alpha, *beta, *lse, *logp;
+    float *lpb, *lpe_in, *lpe_out, *alpha, *beta, *lse, *logp, *xch;
     int U1P, K;      // padded columns per frame; columns per lane of the ONE-wave layout
-    int KT, NW;      // the lattice kernel's plan: columns per thread, waves per (utterance, direction)
+    int KT, NW, NC;  // the lattice kernel's plan: columns per thread, waves per workgroup, column blocks (workgroups) per (utterance, direction)
     int R, sh;       // rows per utterance plane; column -> skew shift (31: no skew)
 };
 
@@ -657,17 +657,30 @@ static int rnnt_K(int U1) {
     return K;
 }
 
-// Lattice plan: columns per thread x waves of rnnt_alphabeta_kernel, and whether the planes are stored SKEWED.
+// Lattice plan: columns per thread x waves x column blocks of rnnt_alphabeta_kernel, and whether the planes are stored SKEWED.
 // A lattice step is an anti-diagonal: thread g (columns KT*g ..) works on frame t = s - g (alpha) resp. t + g = const (beta). Stored frame-major
 // (row t), the 64 lanes of a wave touch 64 different rows per load / store - 64 cache lines per wave-instruction through the CU's one address
 // path: at B = 1, T' = 4000, U = 1920 the four waves spent 1.36 us per step on six such instructions (5.8 ms per direction, "17 GB/s"). Stored at
 // row t + g(u) instead (g(u) = u / KT; G - 1 more rows per utterance), a step's operands and results are ONE contiguous row for the whole
-// workgroup, in both directions. The layout is private to this file: rnnt_lp writes it, rnnt_grad reads it through ws_at().
-// TSASR_RNNT_SKEW: 0 never, 1 (default) when the lattice runs on more than one wave, 2 always;  TSASR_RNNT_WAVES caps the waves.
-static void rnnt_plan(int U1, int *KT, int *NW, int *skew) {
-    static const int max_waves = getenv("TSASR_RNNT_WAVES") ? std::max(1, atoi(getenv("TSASR_RNNT_WAVES"))) : 8;
-    static const int skew_mode = getenv("TSASR_RNNT_SKEW") ? atoi(getenv("TSASR_RNNT_SKEW")) : 1;
+// lattice, in both directions. The layout is private to this file: rnnt_lp writes it, rnnt_grad reads it through ws_at().
+//   U1 <= 256 (the benchmark's U = 120): one wave per lattice, frame-major planes (skewing them costs rnnt_lp / rnnt_grad their coalescing:
+//            +10 - 20 us per step at configs[1], measured);
+//   longer targets: skewed planes, up to 8 waves in one workgroup per lattice (2.5 ms at B = 1, T' = 4000, U = 1920: the CU's VALUs, ~0.55 us per
+//            step for 2048 columns); a single long utterance (2 B NC <= 32 workgroups): one single-wave workgroup per block of 128 columns
+//            instead (rnnt_alphabeta_kernel MC: 1.9 ms; at B = 8, T' = 1000, U = 400 the 8-wave form was faster, 0.72 against 0.75 ms).
+// tsasr_rnnt_lattice_plan() overrides the choice (tests run all three forms against each other, bit for bit; tools/rnnt_bench.py).
+static int g_plan_skew = -1, g_plan_waves = -1, g_plan_mc = -1;      // -1: default
+static void rnnt_plan(int B, int U1, int *KT, int *NW, int *NC, int *skew) {
+    const int max_waves = g_plan_waves > 0 ? g_plan_waves : 8;
+    const int skew_mode = g_plan_skew >= 0 ? g_plan_skew : 1;        // 0 never, 1 when the lattice runs on more than one wave, 2 always
+    const int mc_cols = g_plan_mc >= 0 ? g_plan_mc : 2;              // 0: never split a lattice over workgroups; 1, 2, 4: columns per thread of a split one
+    const int mc_limit = g_plan_mc > 0 ? 2048 : 32;                  // (forced: whatever still fits on the chip at once)
     const int K = rnnt_K(U1);
+    *NC = 1;
+    if (K >= 8 && skew_mode != 0 && (mc_cols == 1 || mc_cols == 2 || mc_cols == 4) && (long long)2 * B * (K / mc_cols) <= mc_limit) {
+        *KT = mc_cols; *NW = 1; *NC = K / mc_cols; *skew = 1;
+        return;
+    }
     int nw = 1;
     if (K >= 8) {                                  // at least 2 columns per thread
         nw = std::min(max_waves, K / 2);
@@ -679,9 +692,14 @@ static void rnnt_plan(int U1, int *KT, int *NW, int *skew) {
 }
 
 static size_t rnnt_plane_floats(int B, int T, int U1) {
-    int kt, nw, skew;
-    rnnt_plan(U1, &kt, &nw, &skew);
-    return (size_t)B * (T + (skew ? 64 * nw - 1 : 0)) * 64 * rnnt_K(U1);
+    int kt, nw, nc, skew;
+    rnnt_plan(B, U1, &kt, &nw, &nc, &skew);
+    return (size_t)B * (T + (skew ? 64 * nw * nc - 1 : 0)) * 64 * rnnt_K(U1);
+}
+static size_t rnnt_xch_floats(int B, int T, int U1) {
+    int kt, nw, nc, skew;
+    rnnt_plan(B, U1, &kt, &nw, &nc, &skew);
+    return nc > 1 ? (size_t)2 * B * nc * (T + 1) : 0;
 }
 
 static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
@@ -689,24 +707,29 @@ static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
     int skew;
     w.K = rnnt_K(U1);
     w.U1P = 64 * w.K;
-    rnnt_plan(U1, &w.KT, &w.NW, &skew);
-    w.R = T + (skew ? 64 * w.NW - 1 : 0);
+    rnnt_plan(B, U1, &w.KT, &w.NW, &w.NC, &skew);
+    w.R = T + (skew ? 64 * w.NW * w.NC - 1 : 0);
     w.sh = 31;
     if (skew) { w.sh = 0; while ((1 << w.sh) < w.KT) ++w.sh; }
     const size_t n = rnnt_plane_floats(B, T, U1);
     float *p = reinterpret_cast<float *>(ws);
     w.lpb = p; w.lpe_in = p + n; w.lpe_out = p + 2 * n; w.alpha = p + 3 * n; w.beta = p + 4 * n; w.lse = p + 5 * n;
     w.logp = p + 6 * n;
+    w.xch = w.logp + align_up((size_t)B, 64);
     return w;
 }
 
 // element (b, t, u) of a lattice plane
 __device__ __forceinline__ size_t ws_at(const RnntWs &w, int b, int t, int u) { return ((size_t)b * w.R + t + (u >> w.sh)) * w.U1P + u; }
 
+// log(e^a + e^b) for a, b finite or -inf (never NaN / +inf): the lattice recursion's one operation, ~10 dependent instructions.
+// Both -inf: min - max is NaN and the clamp (IEEE maxNum) returns -200, so e = 0 and the result is m = -inf without a compare / select;
+// d < -200 underflows to e = 0 either way. v_exp_f32 / v_log_f32 directly: 1 + e lies in [1, 2], where the denormal pre-scaling and the
+// split-constant correction of the library logf (14 more instructions per cell in the ISA of round 3) have nothing to do.
 __device__ __forceinline__ float logaddexp_f(float a, float b) {
     const float m = fmaxf(a, b);
-    const float d = fminf(a, b) - m;  // <= 0, or NaN when both are -inf
-    return (m == NEG_INF) ? NEG_INF : m + __logf(1.f + __expf(d));
+    const float d = fmaxf(fminf(a, b) - m, -200.f);
+    return fmaf(__builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(d * 1.44269504089f)), 0.69314718056f, m);
 }
 
 // (1) fused log-softmax per lattice cell: 8 lanes per cell, float4 per lane and chunk
@@ -812,38 +835,117 @@ __device__ __forceinline__ void ab_step_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int K, int NW, bool SKEW>
+// MC ("multi-CU", long targets in small batches: one CU's VALUs bound the lattice at ~0.55 us per step for 2048 columns): the columns of ONE
+// lattice are cut into NC blocks of 64*K, one single-wave workgroup each - no LDS, no barrier - pipelined along the skew: block c runs the
+// same steps 64*c later. The one value per step that crosses a block boundary (alpha(t, last column of block c-1) resp. beta(t, first column
+// of block c+1)) goes through a global array `xch` [pair][block][t] that the host fills with NaN bits before the launch: the producer's edge
+// lane writes it with an agent-scope store, the consumer fetches 64 frames at a time, 16 steps before it needs them, and spins only while a
+// NaN is left among the frames it is about to use (a lattice value is never NaN). Workgroup ids are stage-major, and a stage waits only for
+// the stage before it, which the dispatcher has started earlier: no deadlock; a bounded spin: no hang (the costs come out NaN instead).
+constexpr int AB_SPIN_LIMIT = 1 << 16;      // x ~3 us per poll: 0.2 s per block at worst
+
+__device__ __forceinline__ unsigned xch_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xch_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The waiting path's loads (same cache policy as xch_load: sc1, served at device scope) as asm that is complete when it returns: hipcc does not
+// see a memory operation in it. With ordinary loads in that conditional path, the join behind it left the compiler unsure how many operations
+// are in flight in EVERY later step, and its counted waits for the prefetched operands came out as vmcnt(7) ... vmcnt(0): the window drained
+// per step. (base: wave-uniform; off: byte offsets)
+__device__ __forceinline__ void xch_poll2(const unsigned *base, unsigned off_a, unsigned off_b, unsigned &a, unsigned &b) {
+    asm volatile("global_load_dword %0, %2, %4 sc1\n\tglobal_load_dword %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(off_a), "v"(off_b), "s"(base) : "memory");
+}
+__device__ __forceinline__ void xch_load4_sync(const unsigned *base, const unsigned *off, unsigned *out) {
+    asm volatile("global_load_dword %0, %4, %8 sc1\n\tglobal_load_dword %1, %5, %8 sc1\n\tglobal_load_dword %2, %6, %8 sc1\n\t"
+                 "global_load_dword %3, %7, %8 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(base)
+                 : "memory");
+}
+
+template <int K, int NW, bool SKEW, bool MC>
 __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const int32_t *__restrict__ tlen,
                                                                  const int32_t *__restrict__ ulen, float *__restrict__ costs,
                                                                  int Tn, int U1) {
+    static_assert(!MC || (NW == 1 && SKEW), "multi-CU lattices: one wave per column block, skewed planes");
     constexpr int G = 64 * NW;
     __shared__ float edge_lds[2][NW > 1 ? NW : 1];
-    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1, g = threadIdx.x, l = g & 63, wave = g >> 6;
+    const int NC = MC ? w.NC : 1, npairs = gridDim.x / NC;
+    const int pair = MC ? blockIdx.x % npairs : blockIdx.x, stage = MC ? blockIdx.x / npairs : 0;
+    const int b = pair >> 1, dir = pair & 1, g = threadIdx.x, l = g & 63, wave = g >> 6;
+    const int cb = MC ? (dir == 0 ? stage : NC - 1 - stage) : 0;        // column block; the pipeline runs left to right for alpha, right to left for beta
+    const int gc = cb * 64 + g;                                          // thread index within the lattice: owns columns K*gc ..
     const int U1P = w.U1P;
     const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
-    const size_t base = (size_t)b * w.R * U1P + (size_t)K * g;
+    if (MC && cb * 64 * K > Ub) return;                                  // a block wholly beyond the last label: nothing in it is read
+    const size_t base = (size_t)b * w.R * U1P + (size_t)K * gc;
     const int nsteps = Tb + G - 1;
-    const int rmax = w.R - 1;     // SKEW: frame t of this thread's columns is row t + g, and a step touches ONE row for the whole workgroup
+    const int rmax = w.R - 1;     // SKEW: frame t of this thread's columns is row t + gc, and a step touches ONE row for the whole workgroup
+    const int roff = cb * 64;     // ... = local step + roff
     float prev[K], cur[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) prev[i] = cur[i] = NEG_INF;
     float edge = NEG_INF;  // boundary value handed to the neighbour thread
+    // MC: the neighbour block's edge value is one more per-step operand, requested PF steps ahead like the log-probabilities (every lane
+    // asks for the edge lane's frame: one address per wave-instruction) - the steps stay one straight line with counted waits. A value that
+    // has not arrived (NaN bits) sends the wave into xch_wait: it sleeps until the neighbour is XCH_LEAD steps ahead, then asks again for the
+    // whole window; after that the pipeline runs with that lead and the wait is not entered again.
+    // (rows of Tn + 1 words: the last one takes the edge lane's stores from steps outside its frames, so that the store needs no guard)
+    unsigned *xch_out = nullptr;
+    const unsigned *xch_in = nullptr;
+    if (MC) {
+        unsigned *x = reinterpret_cast<unsigned *>(w.xch) + ((size_t)pair * NC) * (Tn + 1);
+        const int up = dir == 0 ? cb - 1 : cb + 1;                      // the block this one waits for
+        xch_out = x + (size_t)cb * (Tn + 1);                            // (nobody reads the row of a block without a successor)
+        xch_in = xch_out;
+        if (up >= 0 && up < NC && up * 64 * K <= Ub) xch_in = x + (size_t)up * (Tn + 1);
+    }
+    const bool has_in = MC && xch_in != xch_out;
+    // frame of the consuming edge lane (alpha: lane 0, beta: lane 63) at local step ss, clamped into the utterance
+    auto xch_idx = [&](int ss) { return min(max(dir == 0 ? ss : Tb - 1 - ss, 0), Tb - 1); };
+    auto xch_ptr = [&](int ss) { return xch_in + xch_idx(ss); };
     // The per-step operands (log-probabilities of blank / label for this thread's K columns at its current frame) are requested PF
     // steps ahead, unconditionally (frame index clamped): fetched inside the guarded step they cost one L2 round trip per step,
     // and the steps are strictly sequential (310 us for 313 steps before; the arithmetic of a step is ~50 cycles).
-    constexpr int PF = 8;
+    constexpr int PF = 8, XCH_LEAD = PF + 16;      // (MC: 5 memory operations per step, vmcnt counts to 63; PF = 12 measured equal)
+    // The window is filled by PF "null steps" s = -PF .. -1 of the ramp-up loop itself (no thread has a frame there; they only request the
+    // operands of steps 0 .. PF-1), not by a prologue of loads: hipcc counts its s_waitcnt vmcnt(N) from the state at the loop's entry, and
+    // behind a prologue of bare loads (no stores between them) every step's first wait allowed 15 operations in flight instead of the 22 (40
+    // with the exchange) a step really has behind its operands - the loads of the last 3 steps had to land, not those of 8 steps ago.
     float qb[PF][K], qe[PF][K];
+    unsigned qx[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        qx[d] = 0u;
+#pragma unroll
+        for (int i = 0; i < K; ++i) qb[d][i] = qe[d][i] = 0.f;
+    }
+    // step s0 + d waits for its edge value; on return every slot of the window has been requested again (slot j holds step s0 + j for
+    // j >= d, step s0 + PF + j for j < d: those were refilled by the steps before this one)
+    auto xch_wait = [&](int s0, int d) {
+        static_assert(PF % 4 == 0, "xch_load4_sync");
+        int spins = 0;
+        unsigned v, vf;
+        do {
+            __builtin_amdgcn_s_sleep(16);
+            xch_poll2(xch_in, 4u * xch_idx(s0 + d), 4u * xch_idx(s0 + d + XCH_LEAD), v, vf);
+        } while ((v == 0xffffffffu || vf == 0xffffffffu) && ++spins < AB_SPIN_LIMIT);
+        unsigned off[PF], out[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) off[j] = 4u * xch_idx(j >= d ? s0 + j : s0 + PF + j);
+#pragma unroll
+        for (int j = 0; j < PF; j += 4) xch_load4_sync(xch_in, off + j, out + j);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) qx[j] = out[j];
+    };
     if (dir == 0) {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
             const int t = min(max(ss - g, 0), Tb - 1);
             // SKEW: rows ss - 1 and ss whatever the thread's frame is (outside its frames the values are not used)
-            const float *pb = w.lpb + base + (size_t)(SKEW ? min(max(ss - 1, 0), rmax) : (t > 0 ? t - 1 : 0)) * U1P;
-            const float *pe = w.lpe_in + base + (size_t)(SKEW ? min(ss, rmax) : t) * U1P;
+            const float *pb = w.lpb + base + (size_t)(SKEW ? min(max(ss + roff - 1, 0), rmax) : (t > 0 ? t - 1 : 0)) * U1P;
+            const float *pe = w.lpe_in + base + (size_t)(SKEW ? min(ss + roff, rmax) : t) * U1P;
 #pragma unroll
             for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
         };
-#pragma unroll
-        for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
         // a chunk of PF steps; GUARD = false when every thread has a valid frame in every step of the chunk (G-1 <= s < Tb). The guarded
         // form is STRAIGHT-LINE code too: a thread outside its frames computes on a clamped frame and keeps its old values by select, and
         // stores them again at the clamped frame (before its first frame: -inf into alpha(0, u), overwritten in order by the same thread
@@ -860,20 +962,33 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                 const int tc = GUARD ? min(max(t, 0), Tb - 1) : t;
                 float left = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (NW > 1 && l == 0 && wave > 0) left = edge_lds[(s + 1) & 1][wave - 1];          // written in step s-1
-                float nv[K];
+                if (MC) {
+                    unsigned xs = __builtin_amdgcn_readfirstlane(qx[d]);
+                    if (has_in && xs == 0xffffffffu && s < Tb) {
+                        xch_wait(s0, d);
+                        xs = __builtin_amdgcn_readfirstlane(qx[d]);
+                    }
+                    left = (has_in && l == 0) ? __uint_as_float(xs) : left;
+                }
+                // Off the dependent chain: the no-emit operand (alpha(0,0) = 0 enters as "no-emit = 0, emit = -inf") and the emit
+                // log-probability with the lattice's edges folded in as -inf operands (columns beyond Ub, column 0: both operands -inf give
+                // -inf). On the chain per column: one add and logaddexp_f. Straight-line: no branch around a cell.
+                float ne[K], qm[K], nv[K];
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
-                    const int u = K * g + i;
-                    const float noemit = (t > 0) ? prev[i] + qb[d][i] : NEG_INF;
+                    const int u = K * gc + i;
+                    ne[i] = (t > 0) ? prev[i] + qb[d][i] : (u == 0 ? 0.f : NEG_INF);
+                    qm[i] = (u > 0) ? qe[d][i] : NEG_INF;
+                    if (u > Ub) ne[i] = qm[i] = NEG_INF;
+                }
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
                     const float lft = (i == 0) ? left : nv[i > 0 ? i - 1 : 0];
-                    const float emit = (u > 0) ? lft + qe[d][i] : NEG_INF;
-                    float a = (t == 0 && u == 0) ? 0.f : logaddexp_f(noemit, emit);
-                    if (u > Ub) a = NEG_INF;
-                    nv[i] = a;
+                    nv[i] = logaddexp_f(ne[i], lft + qm[i]);
                 }
                 // SKEW: outside its frames a thread writes the slot of a frame that does not exist (row s, its own columns) or, in the
                 // clamped rows past the last step, its unchanged last value over itself
-                float *pa = w.alpha + base + (size_t)(SKEW ? min(s, rmax) : tc) * U1P;
+                float *pa = w.alpha + base + (size_t)(SKEW ? min(max(s + roff, 0), rmax) : tc) * U1P;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     cur[i] = valid ? nv[i] : cur[i];
@@ -882,33 +997,40 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                 }
                 edge = cur[K - 1];
                 if (NW > 1 && l == 63) edge_lds[s & 1][wave] = edge;
+                if (MC) {     // every lane stores the edge lane's value to the edge lane's slot: one dword, no branch
+                    const int te = s - 63;
+                    xch_store(xch_out + ((te >= 0 && te < Tb) ? te : Tn), __builtin_amdgcn_readlane(__float_as_uint(edge), 63));
+                }
+                if (MC) qx[d] = xch_load(xch_ptr(s + PF));
                 fetch(s + PF, qb[d], qe[d]);
                 if (NW > 1) ab_step_barrier();
             }
         };
-        for (int s0 = 0; s0 < nsteps; s0 += PF) {     // (a last partial chunk runs to its end: the steps past nsteps hold no valid frame)
-            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});
-            else chunk(s0, std::true_type{});
-        }
+        // Ramp-up, steady state (every thread on a valid frame: s0 >= G-1 and s0 + PF < Tb), ramp-down as THREE loops of one body each (a
+        // last partial chunk runs to its end: the steps past nsteps hold no valid frame). As one loop choosing between the two forms per
+        // chunk, the join in front of the back-edge copied the whole prefetch window between the two forms' registers - 32 v_mov_b64 behind an
+        // s_waitcnt vmcnt(0) that drained the loads just requested: one memory round trip per 8 steps (~0.2 - 0.3 us per step at T' = 4000).
+        int s0 = -PF;
+        for (; s0 < nsteps && !(s0 >= G - 1 && s0 + PF < Tb); s0 += PF) chunk(s0, std::true_type{});
+        for (; s0 < nsteps && s0 + PF < Tb; s0 += PF) chunk(s0, std::false_type{});
+        for (; s0 < nsteps; s0 += PF) chunk(s0, std::true_type{});
         // the thread that owns column Ub still holds alpha(Tb-1, Ub)
 #pragma unroll
         for (int i = 0; i < K; ++i)
-            if (K * g + i == Ub) {
-                const float lp = cur[i] + w.lpb[base + (size_t)(Tb - 1 + (SKEW ? g : 0)) * U1P + i];
+            if (K * gc + i == Ub) {
+                const float lp = cur[i] + w.lpb[base + (size_t)(Tb - 1 + (SKEW ? gc : 0)) * U1P + i];
                 w.logp[b] = lp;
                 costs[b] = -lp;
             }
     } else {
         auto fetch = [&](int ss, float (&vb)[K], float (&ve)[K]) {
             const int t = min(max(Tb - 1 - (ss - (G - 1 - g)), 0), Tb - 1);
-            const int row = SKEW ? min(max(Tb + G - 2 - ss, 0), rmax) : t;      // t + g is the same for every thread of a step
+            const int row = SKEW ? min(max(Tb + G - 2 - ss + roff, 0), rmax) : t;      // t + gc is the same for every thread of a step
             const float *pb = w.lpb + base + (size_t)row * U1P;
             const float *pe = w.lpe_out + base + (size_t)row * U1P;
 #pragma unroll
             for (int i = 0; i < K; ++i) { vb[i] = pb[i]; ve[i] = pe[i]; }
         };
-#pragma unroll
-        for (int d = 0; d < PF; ++d) fetch(d, qb[d], qe[d]);
         auto chunk = [&](int s0, auto guard_tag) {       // straight-line in both forms, as in the alpha direction
             constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
@@ -919,19 +1041,29 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                 const int tc = GUARD ? min(max(t, 0), Tb - 1) : t;
                 float right = __builtin_amdgcn_update_dpp(NEG_INF, edge, 0x130, 0xf, 0xf, false);  // wave_shl:1
                 if (NW > 1 && l == 63 && wave < NW - 1) right = edge_lds[(s + 1) & 1][wave + 1];
-                float nv[K];
+                if (MC) {
+                    unsigned xs = __builtin_amdgcn_readfirstlane(qx[d]);
+                    if (has_in && xs == 0xffffffffu && s < Tb) {
+                        xch_wait(s0, d);
+                        xs = __builtin_amdgcn_readfirstlane(qx[d]);
+                    }
+                    right = (has_in && l == 63) ? __uint_as_float(xs) : right;
+                }
+                float ne[K], qm[K], nv[K];     // as in the alpha direction; beta(Tb-1, Ub) = lp_blank enters as "no-emit = lp_blank, emit = -inf"
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const int u = K * gc + i;
+                    const float lb = qb[d][i];
+                    ne[i] = (t < Tb - 1) ? prev[i] + lb : (u == Ub ? lb : NEG_INF);
+                    qm[i] = (u < Ub) ? qe[d][i] : NEG_INF;
+                    if (u > Ub) ne[i] = NEG_INF;
+                }
 #pragma unroll
                 for (int i = K - 1; i >= 0; --i) {
-                    const int u = K * g + i;
-                    const float lb = qb[d][i];
-                    const float noemit = (t < Tb - 1) ? prev[i] + lb : NEG_INF;
                     const float rgt = (i == K - 1) ? right : nv[i < K - 1 ? i + 1 : K - 1];
-                    const float emit = (u < Ub) ? rgt + qe[d][i] : NEG_INF;
-                    float v = (t == Tb - 1 && u == Ub) ? lb : logaddexp_f(noemit, emit);
-                    if (u > Ub) v = NEG_INF;
-                    nv[i] = v;
+                    nv[i] = logaddexp_f(ne[i], rgt + qm[i]);
                 }
-                float *pbeta = w.beta + base + (size_t)(SKEW ? min(max(Tb + G - 2 - s, 0), rmax) : tc) * U1P;
+                float *pbeta = w.beta + base + (size_t)(SKEW ? min(max(Tb + G - 2 - s + roff, 0), rmax) : tc) * U1P;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     cur[i] = valid ? nv[i] : cur[i];
@@ -940,14 +1072,19 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
                 }
                 edge = cur[0];
                 if (NW > 1 && l == 0) edge_lds[s & 1][wave] = edge;
+                if (MC) {
+                    const int te = Tb - 1 - (s - 63);
+                    xch_store(xch_out + ((te >= 0 && te < Tb) ? te : Tn), __builtin_amdgcn_readlane(__float_as_uint(edge), 0));
+                }
+                if (MC) qx[d] = xch_load(xch_ptr(s + PF));
                 fetch(s + PF, qb[d], qe[d]);
                 if (NW > 1) ab_step_barrier();
             }
         };
-        for (int s0 = 0; s0 < nsteps; s0 += PF) {
-            if (s0 >= G - 1 && s0 + PF < Tb) chunk(s0, std::false_type{});
-            else chunk(s0, std::true_type{});
-        }
+        int s0 = -PF;
+        for (; s0 < nsteps && !(s0 >= G - 1 && s0 + PF < Tb); s0 += PF) chunk(s0, std::true_type{});
+        for (; s0 < nsteps && s0 + PF < Tb; s0 += PF) chunk(s0, std::false_type{});
+        for (; s0 < nsteps; s0 += PF) chunk(s0, std::true_type{});
     }
 }
 
@@ -1001,21 +1138,36 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float *__restrict_
 
 template <int K, int NW>
 static void launch_ab(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
-    if (w.sh != 31) rnnt_alphabeta_kernel<K, NW, true><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
-    else rnnt_alphabeta_kernel<K, NW, false><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    if (w.sh != 31) rnnt_alphabeta_kernel<K, NW, true, false><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    else rnnt_alphabeta_kernel<K, NW, false, false><<<2 * B, 64 * NW, 0, st>>>(w, tlen, ulen, costs, T, U1);
+}
+template <int K>
+static int launch_ab_mc(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
+    // every exchange word "not there yet" (NaN bits) before the first workgroup starts
+    if (hipMemsetAsync(w.xch, 0xff, rnnt_xch_floats(B, T, U1) * sizeof(float), st) != hipSuccess) {
+        tsasr_set_error("tsasr_rnnt_loss_fwd: clearing the lattice exchange buffer failed");
+        return TSASR_E_LAUNCH;
+    }
+    rnnt_alphabeta_kernel<K, 1, true, true><<<2 * B * w.NC, 64, 0, st>>>(w, tlen, ulen, costs, T, U1);
+    return 0;
 }
 
-// (columns per thread, waves) from rnnt_plan. Measured at B = 1, T' = 4000, U = 1920 with frame-major planes (round 2): 1 wave 50.5 ms, 2 waves
-// 12.7, 4 waves 6.2, 8 waves 8.9, 16 waves 15.3 - every added wave brought its own 64-line loads and stores; with skewed planes see rnnt_plan.
+// (columns per thread, waves, blocks) from rnnt_plan. Measured at B = 1, T' = 4000, U = 1920 with frame-major planes (round 2): 1 wave 50.5 ms,
+// 2 waves 12.7, 4 waves 6.2, 8 waves 8.9, 16 waves 15.3 - every added wave brought its own 64-line loads and stores; skewed: profiles/r04_notes.md.
 static int launch_alphabeta(RnntWs w, const int32_t *tlen, const int32_t *ulen, float *costs, int B, int T, int U1, hipStream_t st) {
-#define AB_CASE(K_, NW_) if (w.KT == K_ && w.NW == NW_) { launch_ab<K_, NW_>(w, tlen, ulen, costs, B, T, U1, st); return 0; }
+    if (w.NC > 1) {
+        if (w.KT == 1) return launch_ab_mc<1>(w, tlen, ulen, costs, B, T, U1, st);
+        if (w.KT == 2) return launch_ab_mc<2>(w, tlen, ulen, costs, B, T, U1, st);
+        if (w.KT == 4) return launch_ab_mc<4>(w, tlen, ulen, costs, B, T, U1, st);
+    }
+#define AB_CASE(K_, NW_) if (w.NC == 1 && w.KT == K_ && w.NW == NW_) { launch_ab<K_, NW_>(w, tlen, ulen, costs, B, T, U1, st); return 0; }
     AB_CASE(1, 1) AB_CASE(2, 1) AB_CASE(4, 1) AB_CASE(8, 1) AB_CASE(16, 1) AB_CASE(32, 1)
     AB_CASE(4, 2) AB_CASE(8, 2) AB_CASE(16, 2)
     AB_CASE(2, 4) AB_CASE(4, 4) AB_CASE(8, 4)
     AB_CASE(2, 8) AB_CASE(4, 8)
     AB_CASE(2, 16)
 #undef AB_CASE
-    tsasr_set_error("tsasr_rnnt_loss_fwd: no lattice kernel for %d columns per thread x %d waves", w.KT, w.NW);
+    tsasr_set_error("tsasr_rnnt_loss_fwd: no lattice kernel for %d columns per thread x %d waves x %d blocks", w.KT, w.NW, w.NC);
     return TSASR_E_INVALID;
 }
 
@@ -1156,9 +1308,15 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
     return 0;
 }
 
+/* Lab / test switch: how the next tsasr_rnnt_loss_* calls lay out and walk the lattice (see rnnt_plan; -1 = default for each):
+ * skew 0 / 1 / 2 = frame-major planes always / skewed when a lattice runs on more than one wave / always; waves = cap on the waves of a
+ * one-workgroup lattice; mc = 0 never split a lattice over workgroups, 1 / 2 / 4 = split whenever it fits, that many columns per thread.
+ * Changes tsasr_rnnt_loss_workspace_bytes; forward and backward of one loss must run under the same plan. Every plan gives the same bits. */
+void tsasr_rnnt_lattice_plan(int skew, int waves, int mc) { g_plan_skew = skew; g_plan_waves = waves; g_plan_mc = mc; }
+
 size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0) return 0;
-    return align_up((6 * rnnt_plane_floats(B, T, U1) + (size_t)B) * sizeof(float), 256);
+    return align_up((6 * rnnt_plane_floats(B, T, U1) + align_up((size_t)B, 64) + rnnt_xch_floats(B, T, U1)) * sizeof(float), 256);
 }
 
 int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen, const int32_t *ulen,
