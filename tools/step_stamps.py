@@ -2,7 +2,7 @@
 """When does each phase of the captured training step REALLY start? TSASR_STAMPS=1 makes the recipe drop one-thread kernels that store the
 device wall clock at phase boundaries (prof.stamp), on whatever stream is current there; they are captured with the step and replayed
 with it, so the times below come from an ordinary, unprofiled replay (rocprofv3's kernel trace shows a more serial schedule than the
-one that runs without it). usage: python tools/step_stamps.py [replays to show]"""
+one that runs without it). usage: python tools/step_stamps.py [replays to show] [--config scratch|none|pretrained|longform]"""
 import importlib
 import os
 import sys
@@ -14,8 +14,13 @@ import torch  # noqa: E402
 
 bench = importlib.import_module("bench")
 prof = importlib.import_module(bench.PKG + ".prof")
+cfg = "scratch"
+if "--config" in sys.argv:
+    i = sys.argv.index("--config")
+    cfg = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 shows = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-wl = bench.WORKLOADS["scratch"]
+wl = bench.WORKLOADS[cfg]
 dev = "cuda:0"
 torch.cuda.set_device(0)
 batch_mod = importlib.import_module(bench.PKG + ".batch")

@@ -22,6 +22,7 @@ Stage = core.Stage
 # a high-priority side stream - were measured equal or slower and are gone: profiles/r02_notes.md section 5.)
 _OVERLAP_MODE = os.environ.get("TSASR_OVERLAP", "1")
 _OVERLAP_DEFAULT = _OVERLAP_MODE != "0"
+_PRED_STREAM_MIN_U = int(os.environ.get("TSASR_PRED_STREAM_MIN_U", "512"))      # tokens from which the predictor gets a stream of its own
 
 
 class TSASR(core.Brain):
@@ -96,6 +97,12 @@ class TSASR(core.Brain):
             self._aux_streams.append(self._side)      # Brain joins it after backward
         return self._side
 
+    def _pred_stream(self):
+        if getattr(self, "_third", None) is None:
+            self._third = torch.cuda.Stream(device=self.device)
+            self._aux_streams.append(self._third)
+        return self._third
+
     def _flush_main_wgrads(self, grad):
         """Tensor hook on the speaker embedding: fires (on the side stream) when the speaker branch's backward is about to start, i.e.
         when the mixture encoder's and front-end's backward have been enqueued on the main stream. Their queued weight gradients
@@ -139,11 +146,23 @@ class TSASR(core.Brain):
                 # because runs with it forked deviated once in ~100; the cause was found in round 3 and is not a stream-ordering
                 # matter: packed-fp32 instructions of one kernel returning wrong values while the per-step LSTM kernels ran beside it
                 # (profiles/r03_notes.md section 1; the library no longer contains such instructions). "2" = speaker branch only.
-                if _OVERLAP_MODE != "2":
+                # Long targets (configs[4]: U = 1920, a 4.4 ms walk of 1920 dependent steps at B = 1): behind the speaker branch the
+                # predictor ends 1.1 ms after the mixture encoder and the joint waits for it; on a stream of its own it starts with the
+                # step. Short targets keep the one side stream: at configs[1] a third stream cost 0.1 ms (profiles/r04_notes.md section 4).
+                own = _OVERLAP_MODE != "2" and tokens_bos.shape[1] >= _PRED_STREAM_MIN_U
+                if _OVERLAP_MODE != "2" and not own:
                     dec_out = self._predictor(tokens_bos, tokens_bos_lens)
                     prof.stamp("predictor forward done [side]")
                     if prof.STAMPS and dec_out.requires_grad:
                         dec_out.register_hook(lambda g: prof.stamp("predictor backward starts [side]"))
+            if own:
+                third = self._pred_stream()
+                third.wait_stream(cur)
+                with torch.cuda.stream(third):
+                    dec_out = self._predictor(tokens_bos, tokens_bos_lens)
+                    prof.stamp("predictor forward done [third]")
+                    if prof.STAMPS and dec_out.requires_grad:
+                        dec_out.register_hook(lambda g: prof.stamp("predictor backward starts [third]"))
 
             def speaker_embs():
                 prof.stamp("mixture reaches the injection [main]")
@@ -177,6 +196,8 @@ class TSASR(core.Brain):
             dec_out = self._predictor(tokens_bos, tokens_bos_lens)
         else:
             cur.wait_stream(side)
+            if own:
+                cur.wait_stream(third)
             dec_out.record_stream(cur)
 
         # joiner + transducer_head fused (train_librispeechmix_scratch.py:132-135)
