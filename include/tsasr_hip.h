@@ -358,6 +358,15 @@ int tsasr_add_layernorm_bwd(const void *dy, const void *dout, const void *s, con
                             void *dres, void *dx, float *dgamma, float *dbeta, float *dbias, long long M, int D, float alpha, float p,
                             unsigned long long seed, const unsigned long long *seed_dev, const int32_t *valid_lens, int Trows,
                             int io_dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* The same seam with the GEMM that produces x in front of it, in one launch: x = A[M,K] . W[N,K]^T (bf16, never written) for N = K = 256 -
+ * the attention's out_proj (SB/nnet/attention.py:549-553) and the convolution module's last point-wise convolution (Conformer.py:76-98)
+ * followed by `x + skip` / `x + conv(..)` and the LayerNorm that reads the sum (Conformer.py:243-259). (s, y, mean, rstd) are bit-identical
+ * to tsasr_gemm_bf16 + tsasr_add_layernorm_fwd; the backward is tsasr_add_layernorm_bwd + the GEMM's. lda / ldw: row strides in elements. */
+int tsasr_linear_add_layernorm_ok(long long M, int N, int K, long long lda, long long ldw);
+int tsasr_linear_add_layernorm_fwd(const void *A, long long lda, const void *W, long long ldw, const float *bias, const void *res, void *s,
+                                   void *y, float *mean, float *rstd, const float *gamma, const float *beta, long long M, int N, int K,
+                                   float alpha, float p, unsigned long long seed, const unsigned long long *seed_dev,
+                                   const int32_t *valid_lens, int Trows, float eps, void *stream);
 /* Two LayerNorms in a row with the residual tail in front - norm2 of a Conformer layer and the next layer's first LayerNorm (or the
  * encoder's final norm): Conformer.py:194-217,259, models/conformer.py:223-233. (s, y, z) bit-identical to tsasr_add_layernorm_fwd +
  * tsasr_layernorm_fwd; the backward takes dz and (optionally) the gradients reaching y and s along other paths. */

@@ -207,6 +207,47 @@ def test_add_layer_norm_equals_dropout_add_then_layernorm(ops, dtype, D, p, lens
     close(a[1].grad, r[1].grad, tol, rtol=1e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("M,Tn,p,lens,conv_w", [(8000, 250, 0.1, True, False), (8000, 250, 0.0, False, True), (4000, 125, 0.1, False, False),
+                                               (77, 11, 0.1, True, True), (32, 32, 0.0, False, False), (1, 1, 0.1, True, False)])
+def test_linear_add_layer_norm_equals_gemm_then_row_kernel(ops, M, Tn, p, lens, conv_w):
+    """csrc/linear_ln.hip (projection + residual tail + LayerNorm in one launch, N = K = 256) against the GEMM and the row kernel it replaces,
+    same dropout seed: (s, y) and every gradient bit for bit - full tiles, a ragged last tile, fewer rows than a tile, a Conv1d(k=1) weight."""
+    D = 256
+    B = M // Tn
+    g = torch.Generator().manual_seed(M + 7)
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    xin, res, w, b, gam, bet = mk(B, Tn, D), mk(B, Tn, D), mk(D, D) / 16, mk(D), 1 + 0.1 * mk(D), 0.1 * mk(D)
+    if conv_w:
+        w = w.unsqueeze(-1)
+    ds, dy = mk(B, Tn, D), mk(B, Tn, D)
+    vl = torch.randint(1, Tn + 1, (B,), generator=g, dtype=torch.int32).to(DEV) if lens else None
+    trows = Tn if lens else 0
+    seed = 4321 if p > 0 else 0
+
+    def leaves():
+        return [t.to(DEV).to(torch.bfloat16 if i < 2 else torch.float32).requires_grad_() for i, t in enumerate((xin, res, w, b, gam, bet))]
+
+    a = leaves()
+    assert ops._gemm_ok(a[0], a[2])
+    s1, y1 = ops._LinearAddLayerNormFn.apply(a[0], a[2], a[3], a[1], a[4], a[5], 0.5, p, seed, vl, trows, 1e-5)
+    torch.autograd.backward([s1, y1], [ds.to(DEV).bfloat16(), dy.to(DEV).bfloat16()])
+    r = leaves()
+    s2, y2 = ops._AddLayerNormFn.apply(ops._LinearFn.apply(r[0], r[2]), r[3], r[1], r[4], r[5], 0.5, p, seed, vl, trows, 1e-5)
+    torch.autograd.backward([s2, y2], [ds.to(DEV).bfloat16(), dy.to(DEV).bfloat16()])
+    assert torch.equal(s1, s2) and torch.equal(y1, y2)
+    for u, v, name in zip(a, r, ("dxin", "dres", "dW", "dbias", "dgamma", "dbeta")):
+        assert torch.equal(u.grad, v.grad), name
+    # and the public entry takes the fused path for this shape (the switch falls back to the pair)
+    ln = torch.nn.LayerNorm(D).to(DEV)
+    s3, y3 = ops.linear_add_layer_norm(a[0].detach(), a[2].detach(), a[3].detach(), a[1].detach(), ln, 1.0, 0.0, False, vl)
+    old, ops.LINEAR_LN_FUSED = ops.LINEAR_LN_FUSED, False
+    try:
+        s4, y4 = ops.linear_add_layer_norm(a[0].detach(), a[2].detach(), a[3].detach(), a[1].detach(), ln, 1.0, 0.0, False, vl)
+    finally:
+        ops.LINEAR_LN_FUSED = old
+    assert torch.equal(s3, s4) and torch.equal(y3, y4)
+
+
 # ---------------------------------------------------------------------------------------------- blocks vs reference golden
 @pytest.mark.parametrize("tag,causal", [("conv", False), ("conv_causal", True)])
 def test_convolution_module_vs_reference(nn_, golden, tag, causal):

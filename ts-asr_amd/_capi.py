@@ -39,6 +39,9 @@ _PROTOS = {
     "tsasr_joint_bwd": (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "tsasr_rnnt_loss_workspace_bytes": (c_size_t, [c_int] * 3),
     "tsasr_rnnt_lattice_plan": (None, [c_int] * 3),
+    "tsasr_linear_add_layernorm_ok": (c_int, [c_ll, c_int, c_int, c_ll, c_ll]),
+    "tsasr_linear_add_layernorm_fwd": (c_int, [c_void_p, c_ll, c_void_p, c_ll] + [c_void_p] * 8 + [c_ll, c_int, c_int, c_float, c_float,
+                                               c_ull, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "tsasr_rnnt_loss_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_rnnt_loss_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_ll, c_int, c_float, c_float, c_int, c_void_p]),

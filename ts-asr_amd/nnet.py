@@ -523,12 +523,13 @@ class ConvolutionModule(nn.Module):
             valid_lens = (~mask.squeeze(-1)).sum(-1).to(torch.int32)
         return self.forward_add(x, None, valid_lens)
 
-    def core(self, y):
-        """Everything between the module's LayerNorm and its last bias/dropout: y = LN(x) -> [.., D] (bias of after_conv[2] not added)."""
+    def core(self, y, last=True):
+        """Everything between the module's LayerNorm and its last bias/dropout: y = LN(x) -> [.., D] (bias of after_conv[2] not added);
+        last=False stops in front of the last point-wise convolution (the caller fuses it with what follows)."""
         y = ops.matmul_nt(y, self.bottleneck[0].weight)     # 1x1 conv D->2D: the [2D, D, 1] Parameter itself (bias below)
         y = ops.convmod_core(y, self.bottleneck[0].bias, self.conv.weight, self.conv.bias, self.after_conv[0].weight,
                              self.after_conv[0].bias, self.causal, 1e-5, self.slope)                # bias+GLU+depthwise+LN+act
-        return ops.matmul_nt(y, self.after_conv[2].weight)
+        return ops.matmul_nt(y, self.after_conv[2].weight) if last else y
 
     def forward_add(self, x, res, valid_lens=None):
         """res + module(x) with dropout, pad masking and the residual add fused into the last pass."""
@@ -584,9 +585,10 @@ class ConformerEncoderLayer(nn.Module):
         x, y = ops.add_layer_norm(h, pff1[3].bias, x, self.norm1.norm, 0.5, p, tr)                  # x + .5*drop(ffn1) ; norm1
         causal = self.causal or src_mask is not None
         o, attn = mha._context(y, pos_embs, valid_lens, (max(self.chunk_size, 1) if causal else 0), need_attn, pk=pk)   # pk: mha.project_pos(pos_embs), made ahead by the encoder
-        x, y = ops.add_layer_norm(ops.matmul_nt(o, mha.out_proj.weight), mha.out_proj.bias, x, conv.layer_norm)   # + skip ; conv LN
-        c = conv.core(y)
-        x, y = ops.add_layer_norm(c, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)          # + conv ; ffn2 LN
+        # the two seams whose GEMM has K = d_model: projection, residual tail and LayerNorm in one launch (csrc/linear_ln.hip)
+        x, y = ops.linear_add_layer_norm(o, mha.out_proj.weight, mha.out_proj.bias, x, conv.layer_norm)               # + skip ; conv LN
+        c = conv.core(y, last=False)
+        x, y = ops.linear_add_layer_norm(c, conv.after_conv[2].weight, conv.after_conv[2].bias, x, ln2, 1.0, conv.dropout, tr, valid_lens)   # + conv ; ffn2 LN
         h = ops.ffn_core(y, pff2[0].weight, pff2[0].bias, pff2[3].weight, self.slope, p, tr)
         if next_ln is not None and ops.add_layer_norm2_supported(h):
             x, z = ops.add_layer_norm2(h, pff2[3].bias, x, self.norm2.norm, next_ln, 0.5, p, tr, eps2=next_ln.eps)

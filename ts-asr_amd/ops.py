@@ -1282,6 +1282,86 @@ def add_layer_norm(x, bias, res, ln, alpha=1.0, p=0.0, training=False, valid_len
     return _AddLayerNormFn.apply(x, bias, res, ln.weight, ln.bias, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, eps)
 
 
+LINEAR_LN_FUSED = os.environ.get("TSASR_LINEAR_LN", "1") != "0"     # (tests / A-B: "0" = the GEMM and the row kernel as two launches)
+
+
+class _LinearAddLayerNormFn(torch.autograd.Function):
+    """(s, y) of add_layer_norm applied to x = xin . W^T without x ever being written: csrc/linear_ln.hip (bf16, N = K = 256: the attention's
+    out_proj and the convolution module's last point-wise convolution). Same bits as matmul_nt + add_layer_norm; the backward is theirs."""
+
+    @staticmethod
+    def forward(ctx, xin, weight, bias, res, gamma, beta, alpha, p, seed, valid_lens, trows, eps):
+        C.require_gpu(xin, res, gamma, beta)
+        ctx.set_materialize_grads(False)
+        N, K = weight.shape[0], weight.shape[1]
+        x2 = xin.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w16 = _bf16_weight(weight).view(N, K) if weight.dim() == 3 else _bf16_weight(weight)
+        if w16.stride(1) != 1 or w16.stride(0) % 8 != 0 or w16.data_ptr() % 16 != 0:
+            w16 = w16.contiguous()
+        r = res.contiguous()
+        M = x2.shape[0]
+        b = None if bias is None else _f32(bias).contiguous()
+        g, bt = _f32(gamma).contiguous(), _f32(beta).contiguous()
+        s_out, y = torch.empty_like(r), torch.empty_like(r)
+        mean = torch.empty(M, dtype=torch.float32, device=r.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=r.device)
+        with prof.region("linear_add_layernorm_fwd"):
+            C.check(C.lib().tsasr_linear_add_layernorm_fwd(C.ptr(x2), x2.stride(0), C.ptr(w16), w16.stride(0), C.ptr(b), C.ptr(r), C.ptr(s_out),
+                                                           C.ptr(y), C.ptr(mean), C.ptr(rstd), C.ptr(g), C.ptr(bt), M, N, K, float(alpha), float(p),
+                                                           seed, C.ptr(seed_state(r.device)), C.ptr(valid_lens), int(trows), float(eps),
+                                                           C.stream_ptr()), "tsasr_linear_add_layernorm_fwd")
+        ctx.save_for_backward(x2, w16, s_out, g, mean, rstd, valid_lens)
+        ctx.cfg = (float(alpha), float(p), seed, int(trows), bias, gamma, beta, weight, xin.shape)
+        return s_out, y
+
+    @staticmethod
+    def backward(ctx, ds_in, dy):
+        x2, w16, s_out, g, mean, rstd, valid_lens = ctx.saved_tensors
+        alpha, p, seed, trows, bias_param, gamma, beta, weight, xshape = ctx.cfg
+        D = s_out.shape[-1]
+        M = s_out.numel() // D
+        if dy is None:
+            dy = torch.zeros_like(s_out)
+        dy = dy.contiguous()
+        ds_in = None if ds_in is None else ds_in.contiguous()
+        dres, dx = torch.empty_like(s_out), torch.empty_like(s_out)
+        dg = torch.empty(D, dtype=torch.float32, device=s_out.device)
+        dbt = torch.empty_like(dg)
+        db = torch.empty_like(dg) if bias_param is not None else None
+        _keep(dg, dbt, db)
+        ws = _ws(C.lib().tsasr_add_layernorm_bwd_workspace_bytes(M, D), s_out.device)
+        with prof.region("add_layernorm_bwd"):
+            C.check(C.lib().tsasr_add_layernorm_bwd(C.ptr(dy), C.ptr(ds_in), C.ptr(s_out), C.ptr(g), C.ptr(mean), C.ptr(rstd), C.ptr(dres),
+                                                    C.ptr(dx), C.ptr(dg), C.ptr(dbt), C.ptr(db), M, D, alpha, p, seed,
+                                                    C.ptr(seed_state(s_out.device)), C.ptr(valid_lens), trows, C.io_dtype(s_out),
+                                                    C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_add_layernorm_bwd")
+        N, K = weight.shape[0], weight.shape[1]
+        dx2 = dx.view(M, N)
+        dxin = _dgrad(dx2, weight, w16, M, N, K).view(xshape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = _GRAD_SINK
+            if (sink is not None and weight.is_leaf and sink.accepts(weight) and weight.grad.dtype == torch.float32
+                    and weight.grad.is_contiguous()):
+                _wgrad_into(sink, weight, weight.grad.view(N, K), dx2, x2)
+            else:
+                dw = gemm_bf16(dx2, x2, N, K, M, N, K, 1, 1, out_dtype=torch.float32).to(weight.dtype).view(weight.shape)
+        return (dxin, dw, (_pgrad(bias_param, db) if bias_param is not None else None), dres, _pgrad(gamma, dg), _pgrad(beta, dbt),
+                None, None, None, None, None, None)
+
+
+def linear_add_layer_norm(xin, weight, bias, res, ln, alpha=1.0, p=0.0, training=False, valid_lens=None, eps=1e-5):
+    """add_layer_norm(matmul_nt(xin, weight), bias, res, ln, ...): one launch where csrc/linear_ln.hip has the shape, else the pair."""
+    if (LINEAR_LN_FUSED and _gemm_ok(xin, weight) and res.dtype == torch.bfloat16 and weight.shape[0] == 256 and weight.shape[1] == 256
+            and res.shape[-1] == 256 and xin.shape[:-1] == res.shape[:-1]):
+        p = float(p) if training else 0.0
+        trows = res.shape[-2] if valid_lens is not None else 0
+        return _LinearAddLayerNormFn.apply(xin, weight, bias, res, ln.weight, ln.bias, alpha, p, next_seed() if p > 0 else 0, valid_lens, trows, eps)
+    return add_layer_norm(matmul_nt(xin, weight), bias, res, ln, alpha, p, training, valid_lens, eps)
+
+
 class _AddLayerNorm2Fn(torch.autograd.Function):
     """(y, z) = (LN(s; g1, b1), LN(y; g2, b2)), s = res + alpha*timemask(dropout(x + bias)): _AddLayerNormFn followed by _LayerNormResFn
     in one launch each way (norm2 of a Conformer layer + the next layer's first LayerNorm, or the encoder's final norm), same bits."""
