@@ -254,8 +254,6 @@ int tsasr_gemm_big_bm(int M, int N, int K) {
     static const int on = getenv("TSASR_GEMM_BIG") ? atoi(getenv("TSASR_GEMM_BIG")) : 1;
     if (!on || N % GBG_BN != 0 || K % GBG_BK != 0 || N < 1024 || K > 1024 || M < 256) return 0;
     const int tn = N / GBG_BN;
-    static const int force_bm = getenv("TSASR_GEMM_BIG_BM") ? atoi(getenv("TSASR_GEMM_BIG_BM")) : 0;
-    if (force_bm == 128 && cdiv(M, 128) * tn >= 96) return 128;
     if (cdiv(M, 256) * tn >= 200) return 256;
     if (cdiv(M, 128) * tn >= 96) return 128;
     return 0;
