@@ -430,7 +430,7 @@ int tsasr_mean_pool_fwd(const void *x, const float *rel, void *out, int B, int T
 int tsasr_mean_pool_bwd(const void *dout, const float *rel, void *dx, int B, int T, int D, int io_dtype, void *stream);
 int tsasr_abs_lengths(const float *const *rel, int *const *out, const int *dim, const int *mode, int n, int B, void *stream);
 /* Speaker-embedding injection modes `sum` / `prod` (models/conformer.py:247-253; mode 0 / 1): out [B,T,D] = src [B,T,D] (+ | *) spk [B,1,D],
- * D % 8 == 0; backward in one pass over dout: dsrc [B,T,D], dspk [B,1,D] (sums over t in a fixed order). (`cat` = column ranges of
+ * D % 8 == 0; backward in one pass over dout: dsrc [B,T,D] (mode 0: may be NULL - it equals dout), dspk [B,1,D] (sums over t in a fixed order). (`cat` = column ranges of
  * tsasr_gemm_bf16*, `cross_attention` = tsasr_attn_f32_* between GEMMs.) */
 int tsasr_inject_fwd(const void *src, const void *spk, void *out, int B, int T, int D, int mode, int io_dtype, void *stream);
 int tsasr_inject_bwd(const void *dout, const void *src, const void *spk, void *dsrc, void *dspk, int B, int T, int D, int mode, int io_dtype,

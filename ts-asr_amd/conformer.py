@@ -173,7 +173,8 @@ class ConformerEncoder(nn.Module):
             D = self.d_model
             w, b = self.cat_proj.w.weight, self.cat_proj.w.bias
             if ops.linear_cols_ok(src, w, 0, D) and ops.linear_cols_ok(spk, w, D, D):   # the two column halves of the ONE weight, in place
-                return ops.linear_cols(src, w, None, 0, D) + ops.linear_cols(spk, w, b, D, D)   # [B,T,D] + [B,1,D]
+                a, s = ops.linear_cols(src, w, None, 0, D), ops.linear_cols(spk, w, b, D, D)    # [B,T,D], [B,1,D]
+                return ops.inject(a, s, "sum") if ops.inject_ok(a, s) else a + s                # (the broadcast add and its sum over time: HIP)
             return ops.linear(src, w[:, :D], None) + ops.linear(spk, w[:, D:], b)  # [B,T,D] + [B,1,D]
         if self.injection_mode == "cross_attention":
             klen = abs_lengths_round(spk_len, spk.shape[-2]) if spk_len is not None else None

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void inject_bwd_kernel(const T *__restrict__ d
                 st1(dsrc + e, g * sp);
             } else {
                 acc += g;
-                st1(dsrc + e, g);
+                if (dsrc) st1(dsrc + e, g);     // (sum: the gradient of src IS dout - the host passes NULL and hands dout on)
             }
         }
     red[sl][threadIdx.x & 63] = acc;
@@ -104,10 +104,10 @@ int tsasr_inject_fwd(const void *src, const void *spk, void *out, int B, int T, 
     return 0;
 }
 
-/* dsrc [B,T,D], dspk [B,1,D] from dout [B,T,D] (src, spk read only in mode 1) */
+/* dsrc [B,T,D], dspk [B,1,D] from dout [B,T,D] (src, spk read only in mode 1; mode 0: dsrc may be NULL - it equals dout) */
 int tsasr_inject_bwd(const void *dout, const void *src, const void *spk, void *dsrc, void *dspk, int B, int T, int D, int mode, int io_dtype,
                      void *stream) {
-    TSASR_CHECK_ARG(dout && dsrc && dspk && B > 0 && T > 0 && D > 0 && (mode == 0 || (mode == 1 && src && spk)), "tsasr_inject_bwd: bad arguments");
+    TSASR_CHECK_ARG(dout && dspk && (dsrc || mode == 0) && B > 0 && T > 0 && D > 0 && (mode == 0 || (mode == 1 && src && spk)), "tsasr_inject_bwd: bad arguments");
     dim3 grid(cdiv(D, 64), B);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32) {

@@ -1476,11 +1476,12 @@ class _InjectFn(torch.autograd.Function):
         B, T, D = ctx.shape
         srcc, spkc = ctx.saved_tensors if ctx.mode == 1 else (None, None)
         dout = dout.contiguous()
-        dsrc, dspk = torch.empty_like(dout), torch.empty(B, 1, D, dtype=dout.dtype, device=dout.device)
+        dsrc = torch.empty_like(dout) if ctx.mode == 1 else None      # sum: the gradient of src is dout itself, nothing to write
+        dspk = torch.empty(B, 1, D, dtype=dout.dtype, device=dout.device)
         with prof.region("inject_bwd"):
             C.check(C.lib().tsasr_inject_bwd(C.ptr(dout), C.ptr(srcc), C.ptr(spkc), C.ptr(dsrc), C.ptr(dspk), B, T, D, ctx.mode,
                                              C.io_dtype(dout), C.stream_ptr()), "tsasr_inject_bwd")
-        return dsrc, dspk, None
+        return (dout if dsrc is None else dsrc), dspk, None
 
 
 def inject_ok(src, spk):
