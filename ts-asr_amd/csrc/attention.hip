@@ -29,7 +29,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "common.h"
+#include "attn_common.h"
 
 #ifndef AT_NW
 #define AT_NW 4           // waves per workgroup (forward and query-major backward kernels)
@@ -42,38 +42,10 @@
 #define AT_LD 72          // LDS row stride in bf16 (144 B: 16-byte slots rotate by 9 per row -> conflict-free b128 reads)
 #define AT_BAND (AT_QB + AT_KT)  // 192 band rows per tile (191 used)
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
 // Loads in these kernels are ALWAYS issued (clamped addresses) and masked afterwards: a conditional load lives in its own basic
 // block and is waited for where it stands, so a prologue of 160 guarded element loads or a staging loop of six guarded row
 // pieces costs that many serialized memory round trips (the same finding as in csrc/rnnt.hip's backward kernels).
 
-// `causal` argument of every kernel: 0 = no look-ahead mask; 1 = the reference's look-ahead mask (a frame sees keys j <= i:
-// Transformer.py:890-914 via models/conformer.py:279-280); C > 1 = BUILD EXTENSION "chunk = C frames" (BASELINE.json configs[4]):
-// block-causal, a frame sees its whole chunk of C frames and everything before it. Last key query i may attend:
-__device__ __forceinline__ int causal_limit(int i, int causal) { return causal <= 1 ? i : (i / causal + 1) * causal - 1; }
-
-// Opaque to the optimiser: the value must exist in a register HERE. Used on LDS reads whose only consumer sits behind a mask test:
-// left alone, hipcc sinks each read into the branch that uses it - 16 guarded reads = 16 serialized LDS round trips per 32 x 32 score
-// block (s_and_saveexec / ds_read / s_waitcnt lgkmcnt(0) each; "a guarded load is a serialized load") - 49 % of the forward
-// kernel's cycles sat in that phase.
-__device__ __forceinline__ float pin(float x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-// The same for a whole batch of reads: ONE point where all of them must exist, so they are issued back to back and waited for once
-// (pin() on each read in turn made each one a round trip of its own: ds_read / s_waitcnt lgkmcnt(0) pairs in the ISA).
-__device__ __forceinline__ void pin_all(float (&a)[8]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-__device__ __forceinline__ void pin_all(float (&a)[16]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
-}
-
-// four consecutive elements in one store (8 bytes of bf16, 16 of fp32)
-__device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
-__device__ __forceinline__ void st4(bf16_t *p, float a, float b, float c, float d) { *reinterpret_cast<uint2 *>(p) = make_uint2(pk_bf16(a, b), pk_bf16(c, d)); }
 // sum over the 32 lanes of this lane's half of the wave (hh = lane >> 5): DPP inside the 16-lane rows, two readlanes per half
 __device__ __forceinline__ float half_sum(float v, int hh) {
     v += dpp_mov<0xB1>(v);
@@ -251,7 +223,7 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
     float m_run = -INFINITY, l_run = 0.f;
     const unsigned thr = drop_thr16(pdrop);
     const float keep_scale = drop_scale16(thr);
-    const DropKey dkey = drop_key(seed);
+    const unsigned row_state = attn_row_state((unsigned long long)(b * H + h) * Tn + iq, drop_key(seed));
 
     int j_end = len;
     if (causal) j_end = min(j_end, causal_limit(i0 + AT_QB - 1, causal) + 1);  // keys beyond the last query's limit are never attended
@@ -346,9 +318,9 @@ __global__ __launch_bounds__(AT_TH) void relpos_attn_fwd_kernel(const T *__restr
             bf16x8 pb[2];
             unsigned km[4] = {0xfu, 0xfu, 0xfu, 0xfu};   // keep-bits of this lane's four runs of four consecutive keys
             if (pdrop > 0.f) {
-                const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
+                const unsigned kw = attn_keep16(row_state, jb >> 5, hh, thr);      // the attention dropout stream (csrc/attn_common.h)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) km[q] = drop_keep4(idx0 + 8 * q, dkey, thr);
+                for (int q = 0; q < 4; ++q) km[q] = (kw >> (4 * q)) & 0xfu;
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -478,11 +450,6 @@ __global__ __launch_bounds__(256) void relpos_attn_merge_kernel(const float *__r
 //     rounding, 2^-11 relative, is far below that of the bf16 operands).
 // Same arithmetic, masks, dropout stream and outputs as relpos_attn_fwd_kernel.
 // =====================================================================================================================
-__device__ __forceinline__ void at_dma16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 
 template <int QH>   // queries per workgroup: 128 (keys padded to 256, 2 key parts) or 64 (keys padded to 128, 4 key parts)
 __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
@@ -564,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
     float m_run = -INFINITY, l_run = 0.f;
     const unsigned thr = drop_thr16(pdrop);
     const float keep_scale = drop_scale16(thr);
-    const DropKey dkey = drop_key(seed);
+    const unsigned row_state = attn_row_state((unsigned long long)(b * H + h) * Tn + iq, drop_key(seed));
     const int lim_q = causal ? causal_limit(iq, causal) : 0x3fffffff;
     const int lim_blk = causal ? causal_limit(min(i0 + 32 * qb + 31, Tn - 1), causal) : 0x3fffffff;   // last key any query of this wave attends
     const int j_lim = min(len - 1, lim_q);      // last key this lane's query attends ...
@@ -637,10 +604,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short_kernel(const bf1
         bf16x8 pb[2];
         unsigned kw = 0xffffu;   // keep-bits of this lane's 16 keys (bit g = accumulator element g)
         if (pdrop > 0.f) {
-            const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
-            kw = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) kw |= drop_keep4(idx0 + 8 * q, dkey, thr) << (4 * q);
+            kw = attn_keep16(row_state, jb >> 5, hh, thr);
             // kept for the backward (tsasr_relpos_attn_keepbits): it then reads one 16-byte word per query row instead of hashing again
             // (the hashes are ~5 us of its 52 us at T' = 250)
             if (keepbits && iq < Tn) keepbits[(((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + (jb >> 5)] = (unsigned short)kw;
@@ -823,7 +787,7 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
     dqu[0] = dqu[1] = dqv[0] = dqv[1] = (f32x16){0};
     const unsigned thr = drop_thr16(pdrop);
     const float keep_scale = drop_scale16(thr);
-    const DropKey dkey = drop_key(seed);
+    const unsigned row_state = attn_row_state((unsigned long long)(b * H + h) * Tn + iq, drop_key(seed));
     const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
     // dG^T fragment masks: element (band row rl = 16 sp + 8 hh + e, query r) of a 32-key sub-block exists iff 0 <= rl + r - 31 < 32; as bf16-pair
@@ -933,10 +897,7 @@ __global__ __launch_bounds__(AT_TH * KG) void relpos_attn_bwd_q_kernel(const T *
                     const unsigned pair = (sb >> 1) == 0 ? kbw.x : (sb >> 1) == 1 ? kbw.y : (sb >> 1) == 2 ? kbw.z : kbw.w;
                     kw = (sb & 1) ? (pair >> 16) : (pair & 0xffffu);
                 } else {
-                    const unsigned long long idx0 = (((unsigned long long)(b * H + h) * Tn + iq) * Tn) + jb + 4 * hh;
-                    kw = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) kw |= drop_keep4(idx0 + 8 * q, dkey, thr) << (4 * q);
+                    kw = attn_keep16(row_state, jb >> 5, hh, thr);
                 }
             }
             auto probs = [&](auto full_tag) {       // full: every key of the sub-block exists for every query of the wave
@@ -1403,6 +1364,14 @@ __global__ __launch_bounds__(256) void dpk_reduce_group_kernel(const DpkJob *__r
 }
 
 extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
+// csrc/attention_short.hip
+extern "C" int tsasr_attn_short_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, void *out,
+                                    float *lse, int B, int T, int H, float scale, int causal, float pdrop, unsigned long long seed,
+                                    const unsigned long long *seed_dev, void *keepbits, hipStream_t st);
+static int attn_short_version() {   // TSASR_ATTN_SHORT = 1: round 3's short-sequence forward (A/B); default 2
+    static const int v = [] { const char *e = getenv("TSASR_ATTN_SHORT"); return e ? atoi(e) : 2; }();
+    return v;
+}
 
 // ---- key parts for long sequences in small batches (forward and query-major backward) -------------------------------------------
 // One workgroup per (utterance, head, 128 queries) leaves the chip under-filled when B * H * T/128 < CUs, and under a causal mask the
@@ -1570,6 +1539,11 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
     static const int use_short = 1;
     unsigned short *kb = (unsigned short *)g_attn_keepbits;     // one-shot (tsasr_relpos_attn_keepbits); only the short-sequence kernel writes them
     g_attn_keepbits = nullptr;
+    if (use_short && io_dtype == TSASR_BF16 && Dh == 64 && T <= 256 && T >= 2 && attn_short_version() >= 2) {
+        tsasr_attn_short_fwd(qkv, pk, bias_u, bias_v, key_lens, out, lse, B, T, H, scale, causal, pdrop, seed, seed_dev, kb, st);
+        TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
+        return 0;
+    }
     if (use_short && io_dtype == TSASR_BF16 && Dh == 64 && T <= 256 && T >= 2) {
         if (T > 128) {
             constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 4096;   // K, V (256 rows), band (384 rows), 8 fp16 G tiles

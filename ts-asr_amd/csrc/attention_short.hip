@@ -1,0 +1,453 @@
+// Relative-position attention for SHORT sequences (2 <= T <= 256, bf16, Dh = 64): the mixture encoder's T' = 250 and the speaker
+// encoder's T' = 125 at BASELINE configs[1]. Same arithmetic, masks, dropout stream and outputs as the streaming kernels of
+// csrc/attention.hip (reference: RelPosMHAXL.forward, vendor/speechbrain/speechbrain/nnet/attention.py:586-633, rel_shift :468-483).
+//
+// What is different from the streaming kernels (and from round 3's relpos_attn_fwd_short_kernel, which this file replaces):
+//   * everything a workgroup needs comes in by LDS-DMA in GROUPS that follow the order of use (query rows + first key block + the band
+//     rows the first score blocks touch; then, per 32-key step, the next K block, the V block of the step before and 32 more band rows):
+//     the first MFMA starts when ~half of the bytes have landed, the rest lands behind the score blocks (one counted s_waitcnt vmcnt +
+//     s_barrier per step; groups are issued two steps ahead). Round 3 waited for all 112 KB first: 31 % of the kernel.
+//   * the vector work per score element is cut to the bone (it, not the MFMAs, set the pace: 24 + 19 % of the cycles):
+//       - G (band product) tiles cross LDS as fp16 PAIRS: v_cvt_pk_f16_f32 on the way in, ds_read_u16_d16 / _d16_hi on the way out, and
+//         the skewed value is added to the AC accumulator by v_fma_mix_f32 (no conversion instruction);
+//       - exp(scale * x - m) = exp2(fma(x, scale * log2 e, -m')) - one fma, one v_exp_f32;
+//       - the running maximum is only raised when a row's new maximum exceeds it by 2^6 (wave-uniform branch): the rescale of the
+//         32 O accumulators and of l happens once or twice per row instead of once per 32 keys (p <= 2^6: no loss in fp32 / bf16);
+//       - row sums are kept per half-wave and combined once at the end;
+//       - dropout: one 24-bit-multiply word per two keys (csrc/attn_common.h), pair masks by two packed 16-bit operations, applied
+//         to the bf16 PAIR after the conversion (one AND per two elements); 1 / (1 - p) is folded into the final 1 / l;
+//       - P.V of a step runs at the head of the NEXT step, behind that step's AC / G MFMAs (its V block arrives with that group).
+//   * the dropout keep-bits the backward reads (tsasr_relpos_attn_keepbits) leave as ONE 8-byte store per lane.
+#include <type_traits>
+
+#include "attn_common.h"
+
+namespace {
+
+constexpr float AT2_THR_LOG2 = 6.f;     // the running maximum is raised when a new row maximum exceeds it by this many powers of two
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {     // own DMA pieces landed (all but the N youngest), then every wave's
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// x + (float) half of the packed fp16 pair, as fma(half, one, x) with `one` opaque to the optimiser: hipcc then selects v_fma_mix_f32 (the
+// conversion rides in the operand). NOT inline asm: these read MFMA results, and hipcc pads the MFMA -> VALU wait states only for
+// instructions it can see (guide 5.7 item 2) - the asm form of this file's first version read the accumulators early (NaN).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float add_h_lo(float x, unsigned pair, float one) { return __builtin_fmaf((float)__builtin_bit_cast(f16x2, pair)[0], one, x); }
+__device__ __forceinline__ float add_h_hi(float x, unsigned pair, float one) { return __builtin_fmaf((float)__builtin_bit_cast(f16x2, pair)[1], one, x); }
+__device__ __forceinline__ unsigned pk_f16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2)); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// one 8-row x 128-byte LDS-DMA piece of a [rows][64] bf16 tile through a buffer descriptor (base = the tile's row 0 / column 0 in global
+// memory, 32-bit offsets): lane (prow = lane >> 3, pos = lane & 7) fetches 16 bytes of source row src_row + prow into LDS slot (prow, pos).
+// voff_lane = prow * stride + (swizzled chunk << 4) is the lane's constant part (the caller keeps one per tile kind); a piece whose eight
+// rows all exist costs one vector add on top of scalar arithmetic, a piece that straddles the first / last row clamps per lane.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma_buf16(i32x4 srd, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_piece(i32x4 srd, int stride_b, unsigned chunk_lane, int src_row, int lo, int hi, unsigned col_b, unsigned lds_dst, int lane) {
+    // source row of this lane = clamp(src_row + prow, lo, hi) = src_row + med3(prow, lo - src_row, hi - src_row): three full-rate vector operations
+    const int prow = lane >> 3;
+    const int rel = min(max(prow, lo - src_row), hi - src_row);
+    const unsigned voff = __umul24((unsigned)rel & 0xffffffu, (unsigned)stride_b) + chunk_lane + (unsigned)(src_row * stride_b);
+    dma_buf16(srd, voff, col_b, lds_dst);
+}
+template <int OFF>
+__device__ __forceinline__ void g_store_pair(unsigned addr, unsigned pair, bool dup) {      // fp16 pair -> rows OFF/64 and OFF/64 + 1 of a [32][32] fp16 tile
+    asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(addr), "v"(pair), "n"(OFF), "n"(OFF + 64) : "memory");
+    if (dup) asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(addr), "v"(pair), "n"(OFF + 4096), "n"(OFF + 4096 + 64) : "memory");
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// Forward. workgroup = (b, h, QH queries), 8 waves = (query blocks of 32) x (key parts): 4 x 2 for QH = 128 (T > 128: keys padded to
+// 256, two parts of 128), 2 x 4 for QH = 64 (keys padded to 128, four parts of 32); a lane owns ONE query (accumulators: rows = keys /
+// band rows / head dims, column = query), the key parts of a query block are merged through LDS at the end.
+// =====================================================================================================================
+template <int QH>
+__global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
+                                                                        const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                        const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
+                                                                        float *__restrict__ lse, int Tn, int H, float scale, int causal,
+                                                                        float pdrop, unsigned long long seed,
+                                                                        const unsigned long long *__restrict__ seed_dev,
+                                                                        unsigned short *__restrict__ keepbits /*[B*H*T][2][8] or NULL*/) {
+    constexpr int Dh = 64, NQB = QH / 32, NKP = 8 / NQB, TPAD = 2 * QH, KP = TPAD / NKP, NSUB = KP / 32, NB = QH + TPAD;
+    constexpr int K_OFF = 0, V_OFF = TPAD * 128, P_OFF = 2 * TPAD * 128, G_OFF = P_OFF + NB * 128;
+    constexpr int Q_OFF = G_OFF, UV_OFF = G_OFF + QH * 128;      // the query rows and the two bias rows live in the G scratch until they are read
+    static_assert(QH * 128 + 512 <= 8 * 6144, "query staging fits the G scratch");
+    // band rows of group 0: what step 0 needs (NB - 32 (NSUB - 1) rows), rounded up to whole rounds of 8 pieces; the rest rides in group 1
+    constexpr int NBA = NSUB == 1 ? NB : (((NB - 32 * (NSUB - 1)) / 8 + 7) / 8) * 64, NBB = NB - NBA;
+    static_assert(QH / 8 % 8 == 0 && NKP * 4 % 8 == 0 && NBA / 8 % 8 == 0 && NBB / 8 % 8 == 0 && NBA <= NB, "every round of 8 pieces has one kind");
+    constexpr int G0_W = (QH / 8 + NKP * 4 + NBA / 8) / 8 + 2, G1_W = (2 * NKP * 4 + NBB / 8) / 8, GS_W = 2 * NKP * 4 / 8, GL_W = NKP * 4 / 8;   // pieces per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (seed_dev) seed += *seed_dev;
+    // blockIdx.x -> (query tile, (b, h)): the query tiles of one (b, h) get block ids 8 apart, i.e. the same XCD under round-robin
+    // dispatch - they fetch the same K / V rows (speed only: any placement is correct)
+    const int nqt = (Tn + QH - 1) / QH, npair = gridDim.x / nqt;
+    int qt, pair;
+    if ((npair & 7) == 0) {
+        const int k = blockIdx.x >> 3;
+        qt = k % nqt;
+        pair = (k / nqt) * 8 + (blockIdx.x & 7);
+    } else {
+        qt = blockIdx.x % nqt;
+        pair = blockIdx.x / nqt;
+    }
+    const int b = pair / H, h = pair % H, i0 = qt * QH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+    const int qb = wave % NQB, kp = wave / NQB;
+    const int D = H * Dh;
+    const long long row_stride = 3LL * D;
+    const bf16_t *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
+    const bf16_t *p_base = pk + (long long)h * Dh;
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const int r_lo = (Tn - 1) - (i0 + QH - 1);      // band row R of the workgroup <-> table row r_lo + R (clamped: out-of-table rows only meet masked keys)
+
+#ifdef AT_PROFILE
+    long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
+#define ATS_STAMP(i) do { const long long n_ = clock64(); sacc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define ATS_STAMP(i)
+#endif
+    // DMA groups (pieces of 8 rows; piece index = wave + 8 n, so every n of a group has ONE kind of piece for all waves):
+    //   g0 = Q, K block 0 of every part, band rows [0, NBA), the two bias rows; g1 = V block 0, K block 1, band rows [NBA, NB);
+    //   g(s) = V block s-1, K block s; g(NSUB) = V block NSUB-1.
+    const int prow = lane >> 3, pos = lane & 7;
+    const unsigned par = (wave & 1) * 4;          // (row0 >> 1) & 4 of this wave's pieces: piece rows are 8 * (wave + 8 n + const * 2)
+    const int qs_b = (int)row_stride * 2, ps_b = D * 2;
+    const unsigned voff_q = (pos ^ (prow >> 1) ^ par) << 4;                 // K / Q / band tiles: swizzle (row >> 1) & 7
+    const unsigned voff_v = (pos ^ (((prow >> 1) & 1) << 2)) << 4;          // V tile: swizzle ((row >> 1) & 1) << 2
+    const unsigned voff_p = voff_q;
+    const i32x4 srd_q = make_srd(q_base, (unsigned)(Tn * qs_b) - (unsigned)(h * 3 * Dh * 2));
+    const i32x4 srd_p = make_srd(p_base, (unsigned)((2 * Tn - 1) * ps_b) - (unsigned)(h * Dh * 2));
+    auto issue_group = [&](int g) {      // g is a compile-time constant at every call site (unrolled)
+        if (g == 0) {
+#pragma unroll
+            for (int n = 0; n < G0_W - 2; ++n) {
+                const int pc = wave + 8 * n;
+                if (8 * n < QH / 8)
+                    dma_piece(srd_q, qs_b, voff_q, i0 + pc * 8, 0, Tn - 1, 0u, __builtin_amdgcn_readfirstlane(lds0 + Q_OFF + pc * 1024), lane);
+                else if (8 * n < QH / 8 + NKP * 4) {
+                    const int e = pc - QH / 8, row = (e >> 2) * KP + (e & 3) * 8;
+                    dma_piece(srd_q, qs_b, voff_q, row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
+                } else {
+                    const int row = (pc - QH / 8 - NKP * 4) * 8;
+                    dma_piece(srd_p, ps_b, voff_p, r_lo + row, 0, 2 * Tn - 2, 0u, __builtin_amdgcn_readfirstlane(lds0 + P_OFF + row * 128), lane);
+                }
+            }
+            at_dma4(bias_u + h * Dh + lane, __builtin_amdgcn_readfirstlane(lds0 + UV_OFF));          // (every wave: identical bytes)
+            at_dma4(bias_v + h * Dh + lane, __builtin_amdgcn_readfirstlane(lds0 + UV_OFF + 256));
+        } else if (g < NSUB) {
+#pragma unroll
+            for (int n = 0; n < (g == 1 ? G1_W : GS_W); ++n) {
+                const int pc = wave + 8 * n;
+                if (8 * n < NKP * 4) {
+                    const int row = (pc >> 2) * KP + 32 * (g - 1) + (pc & 3) * 8;
+                    dma_piece(srd_q, qs_b, voff_v, row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
+                } else if (8 * n < 2 * NKP * 4) {
+                    const int e = pc - NKP * 4, row = (e >> 2) * KP + 32 * g + (e & 3) * 8;
+                    dma_piece(srd_q, qs_b, voff_q, row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
+                } else {
+                    const int row = NBA + (pc - 2 * NKP * 4) * 8;
+                    dma_piece(srd_p, ps_b, voff_p, r_lo + row, 0, 2 * Tn - 2, 0u, __builtin_amdgcn_readfirstlane(lds0 + P_OFF + row * 128), lane);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < GL_W; ++n) {
+                const int pc = wave + 8 * n;
+                const int row = (pc >> 2) * KP + 32 * (NSUB - 1) + (pc & 3) * 8;
+                dma_piece(srd_q, qs_b, voff_v, row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
+            }
+        }
+    };
+    // every group is issued up front (a wave has nothing else to do until group 0 has landed; the pieces of the later groups then
+    // arrive behind the first steps); pieces per wave still in flight when group g must have landed:
+    constexpr int W_AFTER0 = (NSUB > 1 ? G1_W + (NSUB - 2) * GS_W : 0) + GL_W;
+    issue_group(0);
+    issue_group(1);
+    if constexpr (NSUB > 2) issue_group(2);
+    if constexpr (NSUB > 3) issue_group(3);
+    if constexpr (NSUB > 1) issue_group(NSUB);
+    ATS_STAMP(0);   // DMA issue
+    wait_vm_barrier<W_AFTER0>();                         // group 0 is in LDS
+    ATS_STAMP(1);   // wait for group 0
+
+    // ---- this lane's query: Q + u, Q + v as B operands (dims 16s + 8hh + [0,8))
+    const int iq = i0 + 32 * qb + r;
+    bf16x8 qu[4], qv[4];
+    {
+        const char *q_lds = smem + Q_OFF + (32 * qb + r) * 128;
+        const int sw = ((32 * qb + r) >> 1) & 7;
+        const float *u_lds = reinterpret_cast<const float *>(smem + UV_OFF), *v_lds2 = u_lds + 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 qw = *reinterpret_cast<const uint4 *>(q_lds + (((2 * s + hh) ^ sw) << 4));
+            float q8[8], u8[8], v8[8];
+            q8[0] = __uint_as_float(qw.x << 16); q8[1] = __uint_as_float(qw.x & 0xffff0000u);
+            q8[2] = __uint_as_float(qw.y << 16); q8[3] = __uint_as_float(qw.y & 0xffff0000u);
+            q8[4] = __uint_as_float(qw.z << 16); q8[5] = __uint_as_float(qw.z & 0xffff0000u);
+            q8[6] = __uint_as_float(qw.w << 16); q8[7] = __uint_as_float(qw.w & 0xffff0000u);
+            ld8(u_lds + 16 * s + 8 * hh, u8);
+            ld8(v_lds2 + 16 * s + 8 * hh, v8);
+            qu[s] = bf16x8_of(pk_bf16(q8[0] + u8[0], q8[1] + u8[1]), pk_bf16(q8[2] + u8[2], q8[3] + u8[3]), pk_bf16(q8[4] + u8[4], q8[5] + u8[5]),
+                              pk_bf16(q8[6] + u8[6], q8[7] + u8[7]));
+            qv[s] = bf16x8_of(pk_bf16(q8[0] + v8[0], q8[1] + v8[1]), pk_bf16(q8[2] + v8[2], q8[3] + v8[3]), pk_bf16(q8[4] + v8[4], q8[5] + v8[5]),
+                              pk_bf16(q8[6] + v8[6], q8[7] + v8[7]));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has its query: the G scratch may be written
+    ATS_STAMP(1);
+
+    f32x16 o_acc[2];
+    o_acc[0] = (f32x16){0};
+    o_acc[1] = (f32x16){0};
+    const float c2 = scale * 1.4426950408889634f;          // exp(scale * x) = exp2(c2 * x)
+    const float thr_raw = AT2_THR_LOG2 / c2;
+    float one = 1.f;
+    asm volatile("" : "+v"(one));                          // (see add_h_lo)
+    float m_run = -1e30f, l_run = 0.f;                     // (m in units of the raw score; l: this HALF-wave's share of the row sum)
+    const unsigned thr = drop_thr16(pdrop);
+    const float keep_scale = drop_scale16(thr);
+    const bool drop = pdrop > 0.f;
+    const unsigned row_state = attn_row_state((unsigned long long)(b * H + h) * Tn + iq, drop_key(seed));
+    const int lim_q = causal ? causal_limit(iq, causal) : 0x3fffffff;
+    const int lim_blk = causal ? causal_limit(min(i0 + 32 * qb + 31, Tn - 1), causal) : 0x3fffffff;   // last key any query of this wave attends
+    const int j_lim = min(len - 1, lim_q);      // last key this lane's query attends ...
+    int j_all = j_lim;                          // ... and the last one EVERY query of the wave attends
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) j_all = min(j_all, __shfl_xor(j_all, o));
+    j_all = __builtin_amdgcn_readfirstlane(j_all);
+    const char *k_lds = smem + K_OFF, *v_lds = smem + V_OFF, *p_lds = smem + P_OFF;
+    const int fr_swz = (r >> 1) & 7;   // fragment rows are 32-aligned + r: the swizzle term of a b128 fragment read is the lane's own
+    const int grp = lane >> 4, mhalf = grp & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+
+    // G tiles of this wave: three slots of [32 band rows][32 queries] fp16. The window of a step (64 band rows: block `sub` below block
+    // `sub + 1`) must be CONTIGUOUS for the skewed read (its addresses are base + immediate): even steps read slots [0][1], odd steps
+    // slots [1][2], where slot 2 duplicates slot 0 (a block computed at an odd step is stored twice).
+    const unsigned g_addr = lds0 + G_OFF + wave * 6144;
+    auto g_block = [&](int Rblk, unsigned dst0, bool dup) {   // G^T rows Rblk .. Rblk+31 = Pband . (Q+v)^T -> fp16 at byte offset dst0 (and dst0 + 4096)
+        f32x16 g_acc = {0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(p_lds + (Rblk + r) * 128 + (((2 * s + hh) ^ fr_swz) << 4));
+            g_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, qv[s], g_acc, 0, 0, 0);
+        }
+        const unsigned a = g_addr + dst0 + (4 * hh) * 64 + 2 * r;      // accumulator element g <-> band row (g&3) + 8(g>>2) + 4hh, column r
+#define AT2_GSTORE(G) g_store_pair<(((G) & 3) + 8 * ((G) >> 2)) * 64>(a, pk_f16(g_acc[G], g_acc[(G) + 1]), dup)
+        AT2_GSTORE(0); AT2_GSTORE(2); AT2_GSTORE(4); AT2_GSTORE(6); AT2_GSTORE(8); AT2_GSTORE(10); AT2_GSTORE(12); AT2_GSTORE(14);   // rows of g and g + 1 are adjacent
+#undef AT2_GSTORE
+    };
+    const int j_first = kp * KP;
+    int j_last = min(min((kp + 1) * KP, len), lim_blk + 1);    // keys [j_first, j_last) are live for this wave
+    if (i0 + 32 * qb >= Tn) j_last = j_first;                   // a query block beyond the sequence
+    const int nsub = j_last > j_first ? (j_last - j_first + 31) / 32 : 0;      // wave-uniform
+    const int Rb0 = j_first - 32 * qb + QH - 32;                // band block of step 0 (rows Rb0 .. Rb0 + 31), the new block of step s: Rb0 + 32 (s + 1)
+    if (nsub > 0) g_block(Rb0, 0, false);
+
+    bf16x8 pb[2];                       // probabilities of the previous step (B operand of its P.V, run at the head of the next step)
+    unsigned kbits[(NSUB + 1) / 2];     // keep-bits of the steps, two per register
+#pragma unroll
+    for (int i = 0; i < (NSUB + 1) / 2; ++i) kbits[i] = 0;
+    auto pv = [&](int sub) {            // O^T += V^T . P^T ; A = V^T through the transposing read (k order of pb = accumulator row order)
+        const int jb = j_first + 32 * sub;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row_lo = jb + 16 * s + 4 * hh + q4, row_hi = row_lo + 8, col = 32 * db + 16 * mhalf + 4 * p4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4 *)(v_lds + row_lo * 128 + (((col >> 3) ^ (((row_lo >> 1) & 1) << 2)) << 4) + (col & 7) * 2));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds_bf16x4 *)(v_lds + row_hi * 128 + (((col >> 3) ^ (((row_hi >> 1) & 1) << 2)) << 4) + (col & 7) * 2));
+                bf16x8 va;
+                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3]; va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[s], o_acc[db], 0, 0, 0);
+            }
+    };
+    auto step = [&](auto sub_tag) {
+        constexpr int sub = decltype(sub_tag)::value;
+        // group `sub` has landed (K block, band rows, the V block of the step before); group sub + 2 goes out behind the barrier
+        if constexpr (sub > 0) {
+            // ONE more rendezvous: everything has landed before step 1. A barrier per step kept the two waves of a SIMD in the same phase
+            // (both in their MFMAs, then both in their softmax: nothing overlapped, 29 % of the cycles were spent at the barriers);
+            // behind this one the waves run free and drift into each other's shadows.
+            if constexpr (sub == 1) wait_vm_barrier<0>();
+        }
+        ATS_STAMP(5);   // group waits + barriers of the steps
+        const bool live = sub < nsub;                    // wave-uniform
+        const int jb = j_first + 32 * sub;
+        f32x16 s_acc = {0};
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(k_lds + (jb + r) * 128 + (((2 * s + hh) ^ fr_swz) << 4));
+                s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qu[s], s_acc, 0, 0, 0);
+            }
+            g_block(Rb0 + 32 * (sub + 1), (sub & 1) ? 0u : 2048u, (sub & 1) != 0);
+        }
+        if constexpr (sub > 0) {
+            if (sub - 1 < nsub) pv(sub - 1);
+        }
+        ATS_STAMP(2);   // DMA issue of the group two steps ahead, AC + G MFMAs, G store, P.V of the step before
+        if (!live) return;
+        // ---- raw scores of this lane's query: 16 keys jb + (g&3) + 8(g>>2) + 4hh ; BD via the skewed read of the fp16 window
+        // (16 registers, one value each in the low half: two d16 loads in flight into the two halves of ONE register lose the first one)
+        unsigned bd[16];
+        {
+            const unsigned a = g_addr + ((sub & 1) ? 2048u : 0u) + (31 - r + 4 * hh) * 64 + 2 * r;
+            asm volatile(
+                "ds_read_u16 %0, %16 offset:0\n\tds_read_u16 %1, %16 offset:64\n\t"
+                "ds_read_u16 %2, %16 offset:128\n\tds_read_u16 %3, %16 offset:192\n\t"
+                "ds_read_u16 %4, %16 offset:512\n\tds_read_u16 %5, %16 offset:576\n\t"
+                "ds_read_u16 %6, %16 offset:640\n\tds_read_u16 %7, %16 offset:704\n\t"
+                "ds_read_u16 %8, %16 offset:1024\n\tds_read_u16 %9, %16 offset:1088\n\t"
+                "ds_read_u16 %10, %16 offset:1152\n\tds_read_u16 %11, %16 offset:1216\n\t"
+                "ds_read_u16 %12, %16 offset:1536\n\tds_read_u16 %13, %16 offset:1600\n\t"
+                "ds_read_u16 %14, %16 offset:1664\n\tds_read_u16 %15, %16 offset:1728\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(bd[0]), "=&v"(bd[1]), "=&v"(bd[2]), "=&v"(bd[3]), "=&v"(bd[4]), "=&v"(bd[5]), "=&v"(bd[6]), "=&v"(bd[7]),
+                  "=&v"(bd[8]), "=&v"(bd[9]), "=&v"(bd[10]), "=&v"(bd[11]), "=&v"(bd[12]), "=&v"(bd[13]), "=&v"(bd[14]), "=&v"(bd[15])
+                : "v"(a)
+                : "memory");
+        }
+        float t[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t[g] = add_h_lo(s_acc[g], bd[g], one);
+        if (jb + 31 > j_all) {          // (wave-uniform) some key of the block is masked for some query: key padding, look-ahead mask, T % 32
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t[g] = (jb + (g & 3) + 8 * (g >> 2) + 4 * hh > j_lim) ? -INFINITY : t[g];
+        }
+        float mx = fmaxf(fmaxf(t[0], t[1]), t[2]);
+#pragma unroll
+        for (int g = 3; g < 15; g += 2) mx = fmaxf(fmaxf(mx, t[g]), t[g + 1]);
+        mx = fmaxf(mx, t[15]);
+        mx = fmaxf(mx, other_half(mx));
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + thr_raw) != 0) {      // rare after the first block: raise the running maximum
+            const float m_new = fmaxf(m_run, mx), alpha = fast_exp2((m_run - m_new) * c2);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) o_acc[db][g] *= alpha;
+        }
+        const float mc = m_run * c2;
+        float p[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) p[g] = fast_exp2(__builtin_fmaf(t[g], c2, -mc));
+        l_run += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) + (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
+        unsigned pw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pw[k] = pk_bf16(p[2 * k], p[2 * k + 1]);
+        if (drop) {
+            unsigned km[8];
+            attn_pair_masks(row_state, jb >> 5, hh, thr, km);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pw[k] &= km[k];
+            kbits[sub >> 1] |= attn_keep_bits(km) << (16 * (sub & 1));
+        }
+        pb[0] = bf16x8_of(pw[0], pw[1], pw[2], pw[3]);
+        pb[1] = bf16x8_of(pw[4], pw[5], pw[6], pw[7]);
+        ATS_STAMP(3);   // skewed read, softmax, dropout, P fragments
+    };
+    step(std::integral_constant<int, 0>{});
+    if constexpr (NSUB > 1) step(std::integral_constant<int, 1>{});
+    if constexpr (NSUB > 2) step(std::integral_constant<int, 2>{});
+    if constexpr (NSUB > 3) step(std::integral_constant<int, 3>{});
+    static_assert(NSUB <= 4, "steps are unrolled by hand");
+    if constexpr (NSUB == 1) wait_vm_barrier<0>();      // the V block (NSUB > 1: landed before step 1)
+    ATS_STAMP(5);
+    if (NSUB - 1 < nsub) pv(NSUB - 1);
+    ATS_STAMP(4);   // last P.V
+    // keep-bits for the backward: [row][hh][8 blocks of 32 keys] u16; this wave's NSUB blocks are consecutive
+    if (drop && keepbits && iq < Tn && nsub > 0) {
+        unsigned short *kb = keepbits + (((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + kp * NSUB;
+        if constexpr (NSUB == 4) *reinterpret_cast<uint2 *>(kb) = make_uint2(kbits[0], kbits[1]);
+        else if constexpr (NSUB == 2) *reinterpret_cast<unsigned *>(kb) = kbits[0];
+        else *kb = (unsigned short)kbits[0];
+    }
+    // ---- merge the key parts of each query block: parts kp > 0 hand (m, l, O) to part 0 through LDS (K / V / band are dead now)
+    l_run += other_half(l_run);
+    __syncthreads();
+    ATS_STAMP(6);   // barrier before the merge
+    float *mrg = reinterpret_cast<float *>(smem);   // [(kp - 1) * NQB + qb][64 dims x 32 queries | m[32] | l[32]]
+    constexpr int MSZ = 64 * 32 + 64;
+    static_assert((NKP - 1) * NQB * MSZ * 4 <= G_OFF, "merge buffers fit the dead K / V / band region");
+    if (kp > 0) {
+        float *mine = mrg + ((kp - 1) * NQB + qb) * MSZ;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mine[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] = o_acc[db][g];
+        if (hh == 0) { mine[2048 + r] = m_run; mine[2048 + 32 + r] = l_run; }
+    }
+    __syncthreads();
+    if (kp > 0) return;
+#pragma unroll
+    for (int part = 1; part < NKP; ++part) {
+        const float *oth = mrg + ((part - 1) * NQB + qb) * MSZ;
+        const float m_o = oth[2048 + r], l_o = oth[2048 + 32 + r];
+        const float m_new = fmaxf(m_run, m_o);
+        const float a_me = fast_exp2((m_run - m_new) * c2), a_o = fast_exp2((m_o - m_new) * c2);
+        l_run = l_run * a_me + l_o * a_o;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                o_acc[db][g] = o_acc[db][g] * a_me + oth[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] * a_o;
+    }
+    if (iq < Tn) {
+        const float inv = l_run > 0.f ? (drop ? keep_scale : 1.f) / l_run : 0.f;
+        bf16_t *orow = out + ((long long)b * Tn + iq) * D + (long long)h * Dh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * db + 8 * q + 4 * hh;
+                st4(orow + d, o_acc[db][4 * q] * inv, o_acc[db][4 * q + 1] * inv, o_acc[db][4 * q + 2] * inv, o_acc[db][4 * q + 3] * inv);
+            }
+        if (hh == 0 && lse) lse[((long long)b * H + h) * Tn + iq] = m_run * scale + __logf(l_run);
+    }
+#ifdef AT_PROFILE
+    ATS_STAMP(7);   // merge + epilogue
+    if (blockIdx.x == 0 && tid == 0 && lse)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(lse)[i] = sacc[i];   // (profile build: clobbers the first lse values)
+#endif
+}
+
+extern "C" {
+
+/* The short-sequence forward (bf16, Dh = 64, 2 <= T <= 256): called by tsasr_relpos_attn_fwd_ws (csrc/attention.hip). */
+int tsasr_attn_short_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, void *out, float *lse,
+                         int B, int T, int H, float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev,
+                         void *keepbits, hipStream_t st) {
+    if (T > 128) {
+        constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 6144;   // K, V (256 rows), band (384 rows), 8 x 3 fp16 G slots
+        (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
+        relpos_attn_fwd_short2_kernel<128><<<dim3(cdiv(T, 128) * H * B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
+                                                                                      (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev,
+                                                                                      (unsigned short *)keepbits);
+    } else {
+        constexpr int LDSS = (2 * 128 + 64 + 128) * 128 + 8 * 6144;
+        (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_short2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
+        relpos_attn_fwd_short2_kernel<64><<<dim3(cdiv(T, 64) * H * B), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens,
+                                                                                    (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev,
+                                                                                    (unsigned short *)keepbits);
+    }
+    return 0;
+}
+
+}  // extern "C"
