@@ -19,7 +19,8 @@ C = importlib.import_module("ts-asr_amd._capi")
 DEV = "cuda:0"
 FWD_PHASES = ("DMA issue (groups 0, 1)", "wait for group 0, query fragments", "DMA issue ahead, AC + G MFMAs, G store, P.V of the step before", "skewed read, softmax, dropout, P",
               "last P.V", "group waits + barriers of the steps", "barrier before the merge", "merge + epilogue")
-BWD_PHASES = ("prologue", "staging", "S, dP, G MFMAs + G store", "skewed read, p, dS, stores, inverse skew", "dQ MFMAs", "wave barrier", "epilogue")
+BWD_PHASES = ("row loads, DMA issue, operand fragments", "wait for the tiles", "S, dP, G MFMAs + G store", "skewed read, p, dS", "P_d / dS stores, inverse skew", "dQ MFMAs",
+              "merge of the key parts", "dQ store, bias partial sums")
 
 
 def load(path):
@@ -82,7 +83,7 @@ def run(L, label, B, T, pdrop, H=4, Dh=64, iters=50, prof=False):
         f = lse.view(-1)[:16].view(torch.int64).cpu().tolist()
         bwd()
         torch.cuda.synchronize()
-        b_ = ws[H * 512:H * 512 + 56].view(torch.int64).cpu().tolist()      # wave 1's row of the partial-sum slab
+        b_ = ws[:64].view(torch.int64).cpu().tolist()      # wave 0's row of the partial-sum slab
         for title, names, vals in (("forward (short kernel)", FWD_PHASES, f), ("backward query-major pass", BWD_PHASES, b_)):
             tot = max(1, sum(vals))
             print(f"  {title}: {tot} cycles in workgroup (0,0,0), wave 1 (forward: wave 0)")

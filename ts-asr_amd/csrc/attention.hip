@@ -1368,6 +1368,12 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 extern "C" int tsasr_attn_short_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, void *out,
                                     float *lse, int B, int T, int H, float scale, int causal, float pdrop, unsigned long long seed,
                                     const unsigned long long *seed_dev, void *keepbits, hipStream_t st);
+extern "C" int tsasr_attn_short_bwd_q(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *out,
+                                      const void *dout, const float *lse, void *dqkv, void *pd, void *ds, float *slab, int Tp, int B, int T, int H,
+                                      float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev,
+                                      const void *keepbits, hipStream_t st);
+extern "C" int tsasr_attn_short_bwd_kv(const void *qkv, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *dout, const void *pd,
+                                       const void *ds, void *dqkv, void *qv_out, int B, int T, int Tp, int H, int causal, hipStream_t st);
 static int attn_short_version() {   // TSASR_ATTN_SHORT = 1: round 3's short-sequence forward (A/B); default 2
     static const int v = [] { const char *e = getenv("TSASR_ATTN_SHORT"); return e ? atoi(e) : 2; }();
     return v;
@@ -1477,7 +1483,9 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     // is bound by the CU's VALU / LDS instruction throughput, not by latency a second wave could cover. Off.
     static const int kg_env = 1;
     const bool two = kg_env == 2 && Tn > AT_KT;
-    if (two) {
+    if (sizeof(T) == 2 && Dh == 64 && Tn <= 256 && Tn >= 2 && nparts == 1 && attn_short_version() >= 2) {
+        tsasr_attn_short_bwd_q(qkv, pk, bias_u, bias_v, key_lens, out, dout, lse, dqkv, pd, ds, slab, Tp, B, Tn, H, scale, causal, pdrop, seed, seed_dev, kbq, st);
+    } else if (two) {
         (void)hipFuncSetAttribute((const void *)relpos_attn_bwd_q_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_q));
         relpos_attn_bwd_q_kernel<T, 2><<<dim3(cdiv(Tn, AT_QB) * nparts, H, B), 2 * AT_TH, 2 * lds_q, st>>>(
             (const T *)qkv, (const T *)pk, bias_u, bias_v, key_lens, (const T *)out, (const T *)dout, lse, (T *)dqkv, pd, ds, slab, Tp, B, Tn, H, Dh, scale,
@@ -1491,8 +1499,11 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     if (nparts > 1)
         relpos_attn_dq_merge_kernel<T><<<(unsigned)(((long long)B * H * Tn * 16 + 255) / 256), 256, 0, st>>>(dq_part, key_lens, (T *)dqkv, B, Tn, H, Dh, causal,
                                                                                                           nparts, part_keys);
-    relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
-                                                                          qv, Tn, Tp, H, Dh, causal);
+    if (sizeof(T) == 2 && Dh == 64 && Tn <= 256 && Tn >= 2 && nparts == 1 && attn_short_version() >= 2)
+        tsasr_attn_short_bwd_kv(qkv, bias_u, bias_v, key_lens, dout, pd, ds, dqkv, qv, B, Tn, Tp, H, causal, st);
+    else
+        relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
+                                                                              qv, Tn, Tp, H, Dh, causal);
     if (g_dpk_defer) {   // queued: both passes run in tsasr_relpos_dpk_flush (workspace, key_lens and dpk stay alive until then)
         DpkJob j{ds, qv, key_lens, part, dpk, B, Tn, Tp, H, Dh, causal, bg, isplit, i_span, G * isplit, cdiv(R, 64),
                  sizeof(T) == 2 ? TSASR_BF16 : TSASR_F32, 0, cdiv(R, 64) * H * G * isplit, 0, std::min(1024, cdiv(R * H * 64, 256))};
