@@ -268,8 +268,9 @@ void tsasr_relpos_attn_keepbits(void *bits);
  * Global-norm clipping + AdamW over the flat parameter arena: replaces SB/core.py:1082-1093
  * (torch.nn.utils.clip_grad_norm_ -> torch.optim.AdamW.step) with two launches; the norm stays on the device.
  * p, g, m, v: flat fp32 [n]; p_bf16 (may be NULL): bf16 shadow of p rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t} (graph-capturable Noam schedule).
- * norm_out (may be NULL): DEVICE float = L2 norm of g before clipping; skipped_out (may be NULL): DEVICE float, += 1 when that norm is not finite - the update is then SKIPPED
- * (parameters and moments untouched; the reference's clip_grad_norm_ would write NaN into every weight, SB/core.py:1082-1093).
+ * norm_out (may be NULL): DEVICE float = L2 norm of g before clipping. skipped_out: NULL = the reference's behaviour on a non-finite norm (SB/core.py:1072-1093: the step is
+ * applied - clip_grad_norm_'s factor is NaN / 0 - and only the non-finite loss is counted); a DEVICE float = such a step is SKIPPED (parameters and moments untouched) and
+ * counted there (+= 1): the build's `skip_nonfinite_step: True` option.
  * ------------------------------------------------------------------------------------------ */
 /* dst[i] += src[i] for `count` small fp32 vectors in one launch; table (DEVICE) = [count src ptrs][count dst ptrs][count int32 lengths]. */
 int tsasr_accumulate_many(const void *table, int count, void *stream);

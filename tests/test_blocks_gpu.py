@@ -2,6 +2,8 @@
 (tests/golden/c1_blocks.npz: RelPosMHAXL, ConvolutionModule, FFN, ConformerEncoderLayer - outputs AND gradients) and vs
 plain fp32 torch formulas for the row kernels."""
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -571,6 +573,57 @@ def test_fused_attention_dropout_consistency(ops):
     assert float((out3 - out.detach()).abs().max()) > 1e-2
 
 
+@pytest.mark.parametrize("Tn,p", [(250, 0.1), (125, 0.5)])
+def test_attention_dropout_stream_statistics(ops, Tn, p):
+    """The attention dropout stream (csrc/attn_common.h: one 24-bit-multiply word per two keys on a strong per-row hash). The keep-bits the
+    short-sequence forward hands to the backward ARE the mask: they equal the numpy twin (tests/helpers/attn_mask.py) bit for bit, the
+    keep rate is 1 - p to sampling error (p quantised to 1/65536), and neighbours along a row, along a column, along both diagonals and
+    32 keys apart (same position of consecutive blocks) are uncorrelated."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import attn_mask
+    B, H, Dh = 8, 4, 64
+    D = H * Dh
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, Tn, 3 * D, generator=g).to(DEV, torch.bfloat16)
+    pk = torch.randn(2 * Tn - 1, D, generator=g).to(DEV, torch.bfloat16)
+    u, v = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    L = ops.C.lib()
+    kb = torch.zeros(L.tsasr_relpos_attn_keepbits_bytes(B, Tn, H), dtype=torch.uint8, device=DEV)
+    out, lse = torch.empty(B, Tn, D, dtype=torch.bfloat16, device=DEV), torch.empty(B, H, Tn, device=DEV)
+    seed = 0x1234567
+    L.tsasr_relpos_attn_keepbits(ops.C.ptr(kb))
+    assert L.tsasr_relpos_attn_fwd(ops.C.ptr(qkv), ops.C.ptr(pk), ops.C.ptr(u), ops.C.ptr(v), None, ops.C.ptr(out), ops.C.ptr(lse), B, Tn, H, Dh, 1.0 / D ** 0.5,
+                                   0, p, seed, None, ops.C.BF16, ops.C.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    bits = kb.view(torch.int16).cpu().numpy().view(np.uint16).reshape(B * H * Tn, 2, 8)        # [row][hh][block of 32 keys]
+    j = np.arange(Tn)
+    jl = j & 31
+    hh, gidx = (jl >> 2) & 1, (jl & 3) + 4 * (jl >> 3)                                         # accumulator element g of key jl: (g&3) + 8(g>>2) + 4hh
+    got = ((bits[:, hh, j >> 5] >> gidx[None, :].astype(np.uint16)) & 1).astype(bool).reshape(B, H, Tn, Tn)
+    ref = attn_mask.keep_mask(B, H, Tn, p, seed)
+    assert np.array_equal(got, ref)
+    m = got.reshape(B * H * Tn, Tn).astype(np.float64)
+    n = m.size
+    sig = (p * (1 - p) / n) ** 0.5
+    assert abs(m.mean() - (1 - p)) < 5 * sig + 1e-5
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std()))
+
+    lim = 6 / n ** 0.5
+    for d in (1, 2, 4, 8, 16, 32):
+        assert abs(corr(m[:, :-d], m[:, d:])) < lim, d
+    mm = got.reshape(B * H, Tn, Tn).astype(np.float64)
+    assert abs(corr(mm[:, :-1], mm[:, 1:])) < lim and abs(corr(mm[:, :-1, :-1], mm[:, 1:, 1:])) < lim and abs(corr(mm[:, :-1, 1:], mm[:, 1:, :-1])) < lim
+    # and the mask does what a mask does: with V = 1 the output is the kept probability mass / (1 - p)
+    qkv1 = qkv.clone()
+    qkv1.view(B, Tn, H, 3 * Dh)[..., 2 * Dh:] = 1.0
+    L.tsasr_relpos_attn_fwd(ops.C.ptr(qkv1), ops.C.ptr(pk), ops.C.ptr(u), ops.C.ptr(v), None, ops.C.ptr(out), ops.C.ptr(lse), B, Tn, H, Dh, 1.0 / D ** 0.5,
+                            0, p, seed, None, ops.C.BF16, ops.C.stream_ptr())
+    assert abs(float(out.float().mean()) - 1.0) < 0.02
+
+
 @pytest.mark.parametrize("Tn,causal,ragged", [(250, False, True), (96, True, False), (33, False, True), (256, False, False)])
 def test_attention_keepbits_from_the_forward_give_the_same_gradients(ops, Tn, causal, ragged):
     """Short bf16 sequences: the forward stores the dropout keep-bits it hashed and the backward reads them
@@ -623,9 +676,10 @@ def test_fused_clip_adamw_vs_torch():
 
 
 def test_fused_clip_adamw_skips_a_nonfinite_gradient():
-    """A NaN / Inf in the gradient makes the global norm non-finite: the kernel leaves p, m, v (and the bf16 shadow) untouched and counts
-    the skipped step in its own device float; a finite gradient afterwards updates normally and leaves the counter alone.
-    (Deviation from the reference, stated in DESIGN.md: SB/core.py:1082-1093 would let clip_grad_norm_ write NaN into every weight.)"""
+    """`skip_nonfinite_step: True` (a counter is passed): a NaN / Inf in the gradient makes the global norm non-finite, the kernel leaves p, m,
+    v (and the bf16 shadow) untouched and counts the skipped step in its own device float; a finite gradient afterwards updates normally and
+    leaves the counter alone. Without a counter (the default, `skip_nonfinite_step: False`) the step is applied as the reference applies it
+    (SB/core.py:1072-1093): torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same buffers give the same (poisoned) weights."""
     opt_mod = importlib.import_module("ts-asr_amd.optim")
     n = 4099
     g = torch.Generator().manual_seed(5)
@@ -646,8 +700,20 @@ def test_fused_clip_adamw_skips_a_nonfinite_gradient():
     assert torch.equal(torch.cat([guard[:31], guard[32:]]), torch.full((63,), 7.0, device=DEV))
     opt_mod._clip_adamw(pd, torch.randn(n, generator=g).to(DEV), m, v, norm, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0, p16=p16, skipped_out=skipped)
     assert float(skipped) == 2.0 and np.isfinite(float(norm)) and not torch.equal(pd.cpu(), p0)
-    opt_mod._clip_adamw(pd, torch.full((n,), float("nan"), device=DEV), m, v, None, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0)   # both outputs optional
-    assert bool(torch.isfinite(pd).all())
+    # reference behaviour (no counter): the update goes ahead; compare with torch on the same numbers
+    for bad in (float("nan"), float("inf")):
+        pr = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+        gr = torch.randn(n, generator=g)
+        gr[17] = bad
+        pr.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        pd2, m2, v2 = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        opt_mod._clip_adamw(pd2, gr.to(DEV), m2, v2, None, 1e-3, 0.9, 0.98, 1e-8, 0.01, 1, 5.0)   # both outputs optional
+        ref_nan, got_nan = torch.isnan(pr.detach()), torch.isnan(pd2.cpu())
+        assert torch.equal(ref_nan, got_nan) and bool(got_nan.any())                               # the same elements are poisoned
+        np.testing.assert_allclose(pd2.cpu()[~got_nan].numpy(), pr.detach()[~ref_nan].numpy(), atol=2e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize("M,N,K", [(8000, 2048, 256), (8000, 256, 2048), (250, 144, 144), (1000, 640, 256), (129, 72, 200), (2048, 256, 8000),

@@ -335,3 +335,29 @@ def test_hip_graph_cache_per_batch_shape():
     for _ in range(3):
         assert np.isfinite(float(brain.fit_batch(make_batch(tiny).to(DEV))))
     assert len(brain._graphs) == 2
+
+
+def test_a_stream_forked_by_some_shapes_only_is_part_of_every_capture(monkeypatch):
+    """The predictor gets a stream of its own for long targets only (recipes/tsasr.py _PRED_STREAM_MIN_U). Once that stream exists every later
+    step joins it after backward - also steps (and captures) whose batch is short and never forks it. Long batch, then short batch, both
+    captured and replayed in one process: no capture error, losses equal the all-eager run."""
+    rec = importlib.import_module("ts-asr_amd.recipes.tsasr")
+    inp = golden_inputs()
+    U = inp["tokens"].shape[1]
+    monkeypatch.setattr(rec, "_PRED_STREAM_MIN_U", U + 1)            # the golden batch (tokens_bos: U + 1 columns) counts as "long" ...
+    k = U // 2                                                       # ... and this one, cut to k target tokens, does not
+    tok_abs = np.minimum(np.round(inp["tokens_lens"] * U), k)
+    short = dict(inp, tokens=inp["tokens"][:, :k], tokens_bos=inp["tokens_bos"][:, :k + 1], tokens_lens=(tok_abs / k).astype(np.float32),
+                 tokens_bos_lens=((tok_abs + 1) / (k + 1)).astype(np.float32))
+    losses = {}
+    for mode in ("eager", "graph"):
+        brain, h = entry._config1_brain(DEV, "bf16")
+        brain.modules.train()
+        if mode == "graph":
+            brain.enable_hip_graph(warmup_steps=1)
+        batches = [make_batch(inp).to(DEV), make_batch(short).to(DEV)]
+        losses[mode] = [float(brain.fit_batch(batches[i % 2])) for i in range(8)]
+        assert getattr(brain, "_third", None) is not None and brain._third in brain._aux_streams
+        if mode == "graph":
+            assert len(brain._graphs) == 2
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-6)

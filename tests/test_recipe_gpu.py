@@ -28,6 +28,8 @@ def test_recipe_main_fit_and_evaluate(yaml_name, graph):
             "--syn_seconds", "2.0", "--syn_enroll_seconds", "1.0", "--syn_tokens", "12", "--hip_graph", str(graph), "--lr", "0.002",
             "--warmup_steps", "5", "--dropout", "0.0", "--beam_size", "3"] + SMALL
     losses = []
+    ops = importlib.import_module("ts-asr_amd.ops")
+    ops.LIB_FALLBACKS.clear()
     orig = core.Brain.on_stage_end
     try:
         core.Brain.on_stage_end = lambda self, stage, loss, epoch=None: losses.append((stage, loss))
@@ -44,6 +46,26 @@ def test_recipe_main_fit_and_evaluate(yaml_name, graph):
     assert isinstance(hyps, list) and len(hyps) == 4 and all(isinstance(h, list) for h in hyps)
     if graph:
         assert len(brain._graphs) >= 2                           # one captured graph per batch shape (three length buckets)
+    # fit + validation (greedy search) + evaluation (beam search) of a recipe YAML never left the hand-written kernels (ops.STATUS "LIB" rows)
+    assert ops.LIB_FALLBACKS == {}, ops.LIB_FALLBACKS
+
+
+def test_library_routes_are_counted_and_refused_in_strict_mode(monkeypatch):
+    """The routes ops.STATUS lists as LIB: an LSTM shape no kernel takes (two layers) runs the library module, is counted and announced once;
+    with ops.STRICT_HIP the same call raises TsasrHipMissing."""
+    import torch
+    ops = importlib.import_module("ts-asr_amd.ops")
+    capi = importlib.import_module("ts-asr_amd._capi")
+    rnn = torch.nn.LSTM(8, 16, num_layers=2, batch_first=True).to("cuda:0")
+    x = torch.randn(2, 5, 8, device="cuda:0")
+    ops.LIB_FALLBACKS.clear()
+    with pytest.warns(RuntimeWarning, match="library kernel"):
+        out, _ = ops.lstm(x, rnn)
+    assert out.shape == (2, 5, 16) and ops.LIB_FALLBACKS == {"lstm": 1}
+    monkeypatch.setattr(ops, "STRICT_HIP", True)
+    with pytest.raises(capi.TsasrHipMissing):
+        ops.lstm(x, rnn)
+    ops.LIB_FALLBACKS.clear()
 
 
 def _hash_arena(t):

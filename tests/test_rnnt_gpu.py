@@ -28,10 +28,16 @@ def bf(x):
     return x.to(torch.bfloat16).float()
 
 
-def joint_oracle(enc, dec, W, b, emulate_bf16):
-    """oracle/tsasr_ref.joint_logits; with emulate_bf16 the two MFMA operands are rounded as the kernel rounds them."""
+def joint_oracle(enc, dec, W, b, emulate_bf16, fp16_hidden=False):
+    """oracle/tsasr_ref.joint_logits; with emulate_bf16 the two MFMA operands are rounded as the kernel rounds them. fp16_hidden: the
+    bf16 TS-ASR joint (J = 640: csrc/rnnt.hip joint_fwd_regw_kernel) forms the hidden activation in packed fp16 - x = fp16(e + d),
+    h = max(x, fp16(x * fp16(slope))) - and multiplies it with the fp16-rounded head matrix."""
     if not emulate_bf16:
         return R.joint_logits(enc, dec, {"w.weight": W, "w.bias": b}, "")
+    if fp16_hidden:
+        x = enc.half()[:, :, None, :] + dec.half()[:, None, :, :]
+        h = torch.maximum(x, x * torch.tensor(0.01).half())
+        return h.float() @ W.half().float().t() + b
     h = bf(torch.nn.functional.leaky_relu(enc[:, :, None, :] + dec[:, None, :, :], 0.01))
     return h @ bf(W).t() + b
 
@@ -53,7 +59,7 @@ def test_joint_forward(rn, B, T, U1, J, V, dtype, mfma_fp32):
     enc, dec, W, b, _ = make(B, T, U1, J, V, 1, dtype)
     out = rn.fused_joint_logits(enc.to(DEV, dtype), dec.to(DEV, dtype), W.to(DEV), b.to(DEV))
     assert out.shape == (B, T, U1, V) and out.stride(-2) == 32
-    ref = joint_oracle(enc, dec, W, b, True)
+    ref = joint_oracle(enc, dec, W, b, True, fp16_hidden=(dtype == torch.bfloat16 and J == 640))
     # operands rounded identically -> only fp32 accumulation order differs
     torch.testing.assert_close(out.cpu(), ref, atol=2e-3, rtol=1e-3)
     # against the un-rounded fp32 oracle: bf16 operand rounding, |logit| ~ 1: 2^-8 relative per operand

@@ -52,6 +52,7 @@ class _SpeakerAttention(nn.Module):
             o = ops.attention_f32(q.transpose(1, 2), kv[:, :, 0], kv[:, :, 1], H, 1.0 / (D // H) ** 0.5, key_lens, False,
                                   self.dropout if self.training else 0.0)     # [B,T,H,Dh] / [B,S,H,Dh] strided views
             return ops.linear(o, self.att.out_proj.weight, self.att.out_proj.bias)
+        ops.lib_fallback("cross_attention injection", f"head dim {D // H} > 64")
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         s = torch.matmul(q, k.transpose(-1, -2)).float() / (D // H) ** 0.5
         if key_lens is not None:

@@ -82,6 +82,9 @@ RUN_OPT_DEFAULTS = {
     "find_unused_parameters": False, "auto_mix_prec": False, "bfloat16_mix_prec": False, "max_grad_norm": 5.0,
     "nonfinite_patience": 3, "noprogressbar": True, "ckpt_interval_minutes": 0, "grad_accumulation_factor": 1,
     "optimizer_step_limit": None, "compute_dtype": None,
+    # build options (INTEGRATION.md section "Non-finite steps"): False = the reference (a non-finite step is applied, only counted);
+    # steps between host reads of the device-side counters (the reference reads every step: 1)
+    "skip_nonfinite_step": False, "nonfinite_flush_every": 100,
 }
 
 
@@ -100,6 +103,8 @@ def parse_arguments(arg_list=None):
     p.add_argument("--bfloat16_mix_prec", default=None, action="store_true")
     p.add_argument("--max_grad_norm", type=float)
     p.add_argument("--nonfinite_patience", type=int)
+    p.add_argument("--skip_nonfinite_step", type=lambda v: str(v).lower() in ("1", "true", "yes"))
+    p.add_argument("--nonfinite_flush_every", type=int)
     p.add_argument("--grad_accumulation_factor", type=int)
     p.add_argument("--optimizer_step_limit", type=int)
     p.add_argument("--local_rank", type=int)
@@ -148,7 +153,7 @@ class Brain:
             self.compute_dtype = "bf16" if (self.auto_mix_prec and self.bfloat16_mix_prec) else "fp32"
         self.valid_step = self.step = self.optimizer_step = 0
         self.nonfinite_count, self.skipped_steps = 0, 0
-        self.nonfinite_flush_every = 100     # steps between host reads of the device-side non-finite counters (the reference checks every step)
+        self.nonfinite_flush_every = int(self.nonfinite_flush_every or 0)   # steps between host reads of the device-side non-finite counters
         self._nonfinite_dev = None
         self.avg_train_loss = 0.0
         self.grad_norm_epoch = []
@@ -205,7 +210,7 @@ class Brain:
         self.arena.aux_streams = self._aux_streams     # same list object: streams the recipe forks register themselves there
         if self.distributed:
             self.arena.broadcast_parameters()          # identical initial weights on every rank (reference: DDP's constructor broadcast)
-        self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm)
+        self.optimizer = _optim.make_optimizer(self.opt_class, params, self.arena, self.max_grad_norm, bool(self.skip_nonfinite_step))
         from . import ops as _ops
         _ops.set_grad_sink(self.arena)
 
@@ -250,6 +255,13 @@ class Brain:
         _ops.begin_step(self.device)
         prof.stamp_begin(self.device)
         prof.stamp("step starts [main]")
+        # Every stream a recipe has EVER forked is forked again here, whether this step will use it or not: the joins after backward (below,
+        # GradArena.join_streams) wait on all of them, and inside a capture a wait on a stream that is not part of the capture is an error
+        # (a stream forked only by some batch shapes - the predictor's own stream for long targets - was joined by the others unforked).
+        if torch.device(self.device).type == "cuda":
+            cur0 = torch.cuda.current_stream()
+            for s in self._aux_streams:
+                s.wait_stream(cur0)
         self.arena.begin_backward(should_step and comm)
         outputs = self.compute_forward(batch, Stage.TRAIN)
         loss = self.compute_objectives(outputs, batch, Stage.TRAIN)

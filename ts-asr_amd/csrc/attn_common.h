@@ -50,7 +50,7 @@ __device__ __forceinline__ void at_dma4(const void *gsrc, unsigned lds_dst) {
 // The mask of score element (b, h, i, j) is a pure function of (call seed, b, h, i, j). A lane of these kernels owns, per block of 32
 // keys jb .. jb+31, the 16 keys jb + 4*hh + 8*q + e (q, e = 0..3; hh = its half of the wave): eight 32-bit words, one per pair of
 // consecutive keys. Word w of query row `row` = (b*H + h)*T + i:
-//     y = S(row) + w * 0x9E3779B9 ;  y ^= y >> 15 ;  y = (y & 0xffffff) * 0xc1b3c6d (low 32 bits) ;  y ^= y >> 16
+//     y = S(row) + w * 0x9E3779B9 ;  y ^= y >> 15 ;  y = (y & 0xffffff) * 0x1b3c6d (low 32 bits) ;  y ^= y >> 16
 // with S(row) = drop_hash(row, key) - the strong per-row hash of csrc/common.h - and w = ((jb/32)*2 + hh)*8 + 2*q + (e >> 1). The even key
 // of the pair takes the low half of the word, the odd one the high half; a key is KEPT iff its half, read as a signed 16-bit number,
 // is >= thr16 - 32768 (thr16 = round(p * 65536): the keep probability is (65536 - thr16) / 65536 exactly as in drop_keep_mask).
@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned attn_row_state(unsigned long long row, DropK
 __device__ __forceinline__ unsigned attn_drop_word(unsigned row_state, unsigned w) {
     unsigned y = row_state + w * 0x9E3779B9u;
     y ^= y >> 15;
-    y = __umul24(y, 0xc1b3c6du);
+    y = __umul24(y, 0x1b3c6du);
     y ^= y >> 16;
     return y;
 }

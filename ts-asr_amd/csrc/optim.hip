@@ -56,15 +56,22 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
     __syncthreads();
     const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
-    // A non-finite gradient norm (overflow, or a poisoned activation: csrc/lstm.hip raises NaN when its inter-workgroup wait times
-    // out) must not reach the weights: fminf(1, max_norm / NaN) is 1, and AdamW would write NaN into every parameter and moment.
-    // The step is skipped instead (parameters, moments untouched); the host counts it through norm_out like a non-finite loss
-    // (the reference only counts, SB/core.py:1115-1150, and clip_grad_norm_ then poisons the model one step before it raises).
-    if (!(fabsf(norm) <= 3.0e38f)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && skipped_out) *skipped_out += 1.f;   // skipped steps since the host last cleared it
+    // A non-finite gradient norm (overflow, or a poisoned activation: csrc/lstm.hip raises NaN when its inter-workgroup wait times out).
+    // Reference behaviour (SB/core.py:1072-1093): the step is applied all the same - clip_grad_norm_'s factor max_norm / (norm + 1e-6),
+    // clamped to at most 1, is NaN for a NaN norm and 0 for an infinite one, and AdamW then writes what that gives into every parameter and
+    // moment; the non-finite LOSS was counted (check_gradients) and the run stops when nonfinite_patience is exhausted. That is what happens
+    // here when skipped_out is NULL (`skip_nonfinite_step: False`, the default). With skipped_out (`skip_nonfinite_step: True`, a build
+    // option) the step is skipped instead - parameters and moments untouched - and counted there.
+    const bool finite = fabsf(norm) <= 3.0e38f;
+    if (!finite && skipped_out) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *skipped_out += 1.f;   // skipped steps since the host last cleared it
         return;
     }
-    const float clip = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    float clip = 1.f;
+    if (max_norm > 0.f) {
+        const float c = max_norm / (norm + 1e-6f);
+        clip = (c != c) ? c : fminf(1.f, c);        // torch.clamp(c, max=1): NaN stays NaN
+    }
     const float lr = hyper[0], bc1 = hyper[1], bc2s = sqrtf(hyper[2]);
     const float step = lr / bc1, decay = 1.f - lr * wd;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 256 * 4) {
@@ -189,8 +196,9 @@ int tsasr_accumulate_many(const void *table, int count, void *stream) {
 size_t tsasr_clip_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
 
 /* p, g, m, v: flat fp32 [n] (16-byte aligned); p_bf16: optional bf16 shadow of p (GEMM operand copy), rewritten in the same pass; hyper: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}; norm_out: device float
- * (may be NULL) = total L2 norm of g before clipping; skipped_out: device float (may be NULL), += 1 when that norm is not finite - the
- * update is then skipped, parameters and moments untouched; max_norm <= 0 disables clipping. g is read, not modified. */
+ * (may be NULL) = total L2 norm of g before clipping; skipped_out: device float or NULL. NULL (reference behaviour, SB/core.py:1072-1093): a
+ * non-finite norm does not stop the update (clip factor NaN / 0 as torch.nn.utils.clip_grad_norm_ computes it). Not NULL: such a step is
+ * skipped (parameters and moments untouched) and *skipped_out += 1. max_norm <= 0 disables clipping. g is read, not modified. */
 int tsasr_clip_adamw_step(float *p, void *p_bf16, const float *g, float *m, float *v, const float *hyper, float *norm_out, float *skipped_out, long long n,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, void *workspace,
                           size_t workspace_bytes, void *stream) {

@@ -144,17 +144,29 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(const T *__restrict__ en
 // h = lrelu(enc + dec), 5.5 operations per lattice cell and joint dimension).
 // S01: 0 <= slope <= 1 (checked by the launcher; LeakyReLU's 0.01): lrelu(x) = max(x, slope * x), two operations instead of three - the same
 // values (x > 0: x >= slope * x; x <= 0: slope * x >= x).
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// 8 bf16 (one 16-byte word) -> 8 fp16 (exact for |x| < 65504 with <= 11 significant bits: every bf16 value in that range)
+__device__ __forceinline__ uint4 bf16x8_to_f16x8(uint4 v) {
+    auto cv = [](unsigned w) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}, half2_t)); };
+    return make_uint4(cv(v.x), cv(v.y), cv(v.z), cv(v.w));
+}
 template <int NKS, bool S01>
 __global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__restrict__ enc, const bf16_t *__restrict__ dec,
                                                                 const float *__restrict__ W, const float *__restrict__ bias,
                                                                 float *__restrict__ logits, int Tn, int U1, int V, int ldl, float slope) {
+    // Round 5: the hidden activation h = lrelu(enc + dec) is formed in PACKED fp16 (v_pk_add_f16 / v_pk_mul_f16 / v_pk_max_f16: 1.5
+    // vector operations per lattice cell and joint dimension instead of 5.5 - the bf16 tiles had to be unpacked to fp32, added, scaled,
+    // maxed and packed again) and the head GEMM runs on v_mfma_f32_32x32x16_f16. enc / dec / W are converted to fp16 ONCE when they are staged
+    // (bf16 -> fp16 is exact below 65504; the projections' outputs are O(1) - a value beyond fp16's range would saturate to inf, bf16
+    // kept it); x = e + d and slope * x are rounded to 11 significant bits (the bf16 form rounded h to 8).
     constexpr int J = 16 * NKS, S = J + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t *d_lds = reinterpret_cast<bf16_t *>(smem);     // [32][S]
+    _Float16 *d_lds = reinterpret_cast<_Float16 *>(smem);     // [32][S]
     const int b = blockIdx.z, u0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // the head matrix goes through the (still unused) dec-tile area once: fp32 -> bf16 rows in LDS, from there this lane's NKS pieces
+    // the head matrix goes through the (still unused) dec-tile area once: fp32 -> fp16 rows in LDS, from there this lane's NKS pieces
     // into registers (a direct per-lane fetch of 8 * NKS fp32 values had all of them in flight at once and spilled)
     for (int i = tid; i < 32 * (J / 8); i += 256) {
         const int row = i / (J / 8), c = (i % (J / 8)) * 8;
@@ -164,26 +176,29 @@ __global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__
 #pragma unroll
             for (int j = 0; j < 8; ++j) w8[j] = 0.f;
         }
-        st8(d_lds + row * S + c, w8);
+        half8_t wh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wh[j] = (_Float16)w8[j];
+        *reinterpret_cast<half8_t *>(d_lds + row * S + c) = wh;
     }
     __syncthreads();
-    bf16x8 wreg[NKS];
+    half8_t wreg[NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) wreg[s] = *reinterpret_cast<const bf16x8 *>(d_lds + r * S + 8 * h + 16 * s);
+    for (int s = 0; s < NKS; ++s) wreg[s] = *reinterpret_cast<const half8_t *>(d_lds + r * S + 8 * h + 16 * s);
     __syncthreads();
     for (int i = tid; i < 32 * (J / 8); i += 256) {
         const int row = i / (J / 8), c = (i % (J / 8)) * 8;
         uint4 v = *reinterpret_cast<const uint4 *>(dec + ((size_t)b * U1 + min(u0 + row, U1 - 1)) * J + c);
         if (u0 + row >= U1) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(d_lds + row * S + c) = v;
+        *reinterpret_cast<uint4 *>(d_lds + row * S + c) = bf16x8_to_f16x8(v);
     }
     float *b_lds = reinterpret_cast<float *>(d_lds + 32 * S + 4 * J);     // [32] head bias (0 beyond V): read per frame, not held in 16 registers
     if (tid < 32) b_lds[tid] = bias[min(tid, V - 1)] * (tid < V ? 1.f : 0.f);
     __syncthreads();
     const int tchunk = cdiv_dev(Tn, (int)gridDim.y);
     const int t_begin = blockIdx.y * tchunk, t_end = min(Tn, t_begin + tchunk);
-    const bf16_t *drow = d_lds + r * S + 8 * h;
-    bf16_t *e_w = d_lds + 32 * S + wave * J;              // [4 waves][J]: the frame's enc row, fetched once per wave, read as broadcasts
+    const _Float16 *drow = d_lds + r * S + 8 * h;
+    _Float16 *e_w = d_lds + 32 * S + wave * J;            // [4 waves][J]: the frame's enc row, fetched once per wave, read as broadcasts
     constexpr int NQ = (J + 511) / 512;                   // 16-byte pieces per lane
     uint4 stg[NQ];
     auto request = [&](int t) {
@@ -191,30 +206,30 @@ __global__ __launch_bounds__(256, 2) void joint_fwd_regw_kernel(const bf16_t *__
 #pragma unroll
         for (int q = 0; q < NQ; ++q) stg[q] = *reinterpret_cast<const uint4 *>(src + min((q * 64 + lane) * 8, J - 8));
     };
+    const _Float16 sl16 = (_Float16)slope;
+    const half8_t slope8 = {sl16, sl16, sl16, sl16, sl16, sl16, sl16, sl16};
     request(t_begin + wave);
     for (int t = t_begin + wave; t < t_end; t += 4) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c = (q * 64 + lane) * 8;
-            if (c < J) *reinterpret_cast<uint4 *>(e_w + c) = stg[q];
+            if (c < J) *reinterpret_cast<uint4 *>(e_w + c) = bf16x8_to_f16x8(stg[q]);
         }
         request(t + 4);
         __builtin_amdgcn_wave_barrier();
-        const bf16_t *erow = e_w + 8 * h;
+        const _Float16 *erow = e_w + 8 * h;
         f32x16 acc = {0};
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            float e8[8], d8[8];
-            ld8(erow + 16 * s, e8);
-            ld8(drow + 16 * s, d8);
-            float hv[8];
+            const half8_t e8 = *reinterpret_cast<const half8_t *>(erow + 16 * s), d8 = *reinterpret_cast<const half8_t *>(drow + 16 * s);
+            const half8_t x = e8 + d8;
+            half8_t hb;
+            if (S01) hb = __builtin_elementwise_max(x, x * slope8);
+            else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = e8[j] + d8[j];
-                hv[j] = S01 ? fmaxf(x, x * slope) : lrelu(x, slope);
+                for (int j = 0; j < 8; ++j) hb[j] = x[j] > (_Float16)0 ? x[j] : x[j] * sl16;
             }
-            const bf16x8 hb = bf16x8_of(pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3]), pk_bf16(hv[4], hv[5]), pk_bf16(hv[6], hv[7]));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], hb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], hb, acc, 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 2 * NKS LDS reads of a frame (it spilled 149 VGPRs)
         }
         __builtin_amdgcn_wave_barrier();                  // this frame's reads of e_w are issued before the next frame's row lands in it
@@ -1246,7 +1261,7 @@ static int device_cu_count_rnnt() {
 // what a CU issues per frame, not by latency) and every range repeats the fragment loads and the slab writes. So: split only when the
 // grid would leave CUs idle (B = 1 long-form: 120 workgroups), never below 32 frames per range; TSASR_JOINT_TSPLIT forces a value.
 static int joint_tsplit(int B, int T, int U1, int J) {
-    static const int forced = 0;
+    static const int forced = [] { const char *e = getenv("TSASR_JOINT_TSPLIT"); return e ? atoi(e) : 0; }();
     if (forced > 0) return std::min(forced, 4);
     const long long wgs = (long long)B * cdiv(U1, 32) * cdiv(J / 32, 4 * KB);
     int ts = (int)std::min<long long>(4, device_cu_count_rnnt() / std::max<long long>(wgs, 1));

@@ -22,7 +22,28 @@ STATUS = {
     "attention(fp32 parity, cross_attention injection)": "HIP (attention_f32: exact fp32)", "joint(fp32 parity)": "HIP (joint_f32)",
     "injection sum / prod": "HIP (inject)", "mix_sources": "HIP (dataio.hip)", "fbank": "HIP", "sentence_norm": "HIP",
     "relpos_attention": "HIP (forward; backward = query-major, key-major, d(pk) and partial-sum kernels)",
+    # What is NOT hand-written: shapes / modes none of the three recipes reaches. Each of these routes goes through lib_fallback(): counted in
+    # LIB_FALLBACKS, announced once (warnings), refused with TsasrHipMissing when ops.STRICT_HIP (env TSASR_STRICT_HIP=1) is set.
+    # tests/test_recipe_gpu.py asserts that a fit + evaluate of every recipe YAML leaves LIB_FALLBACKS empty.
+    "matmul(other dtypes / non-contiguous shapes no HIP GEMM takes)": "LIB (F.linear -> hipBLASLt), logged",
+    "frontend conv block 2 (fp32 with the fp32 HIP GEMM switched off)": "LIB (F.linear), logged",
+    "lstm(num_layers > 1, bidirectional, H not a multiple of 16 / > 1024)": "LIB (nn.LSTM -> MIOpen), logged",
+    "cross_attention injection with head dim > 64": "LIB (ATen matmul / softmax), logged",
+    "relpos_attention(need_weights=True: attention maps for plots)": "LIB (ATen matmul / softmax), logged",
 }
+
+STRICT_HIP = os.environ.get("TSASR_STRICT_HIP", "0") == "1"
+LIB_FALLBACKS = {}      # route -> number of calls that left the hand-written path in this process
+
+
+def lib_fallback(route, why=""):
+    """A call is about to run a library kernel instead of a hand-written one: count it, say so once, refuse it in strict mode."""
+    import warnings
+    if STRICT_HIP:
+        raise C.TsasrHipMissing(f"{route}: no hand-written gfx950 kernel takes this call ({why}); TSASR_STRICT_HIP=1 refuses the library route")
+    if route not in LIB_FALLBACKS:
+        warnings.warn(f"ts-asr_amd: {route} runs a library kernel, not a hand-written one ({why}); listed as LIB in ops.STATUS", RuntimeWarning, stacklevel=3)
+    LIB_FALLBACKS[route] = LIB_FALLBACKS.get(route, 0) + 1
 
 _seed_counter = [0]
 _seed_dev = {}
@@ -799,9 +820,19 @@ class _LinearF32Fn(torch.autograd.Function):
 _F32_HIP_GEMM = True      # fp32 (parity-mode) Linear layers on the hand-written fp32 GEMM; False: the library GEMM (tests compare the two)
 
 
-def _gemm_f32_ok(x, weight):
-    return (_F32_HIP_GEMM and x.dtype == torch.float32 and x.is_cuda and weight.dtype == torch.float32 and weight.is_cuda
+def _gemm_f32_shapes_ok(x, weight):
+    return (_F32_HIP_GEMM and x.is_cuda and weight.dtype == torch.float32 and weight.is_cuda
             and (weight.dim() == 2 or (weight.dim() == 3 and weight.shape[2] == 1)) and x.shape[-1] == weight.shape[1] and x.numel() > 0)
+
+
+def _gemm_f32_ok(x, weight):
+    return x.dtype == torch.float32 and _gemm_f32_shapes_ok(x, weight)
+
+
+def _gemm_f32_widen_ok(x, weight):
+    """bf16 activations against a matrix the bf16 GEMM does not take (N % 8 != 0: the 29-row transducer head the searchers call one lattice
+    cell at a time, SB/decoders/transducer.py:375-384): small enough to widen to fp32 and run the fp32 HIP GEMM."""
+    return x.dtype == torch.bfloat16 and x.numel() <= (1 << 16) and _gemm_f32_shapes_ok(x, weight)
 
 
 def matmul_nt(x, weight):
@@ -811,8 +842,11 @@ def matmul_nt(x, weight):
         return _LinearFn.apply(x, weight)
     if _gemm_f32_ok(x, weight):
         return _LinearF32Fn.apply(x, weight)
+    if _gemm_f32_widen_ok(x, weight):     # (the weight rounded to bf16 first: the operand every other bf16 GEMM of the mode sees - its bf16 shadow)
+        return _LinearF32Fn.apply(x.float(), weight.to(torch.bfloat16).float()).to(x.dtype)
     if weight.dim() == 3:
         weight = weight.squeeze(-1)
+    lib_fallback("matmul", f"x {x.dtype} {tuple(x.shape)}, weight {weight.dtype} {tuple(weight.shape)}")
     return F.linear(x, _w(weight, x))
 
 
@@ -825,8 +859,9 @@ def linear(x, weight, bias=None, act_slope=None, dropout_p=0.0, training=False):
         if bias is None:
             return matmul_nt(x, weight)
         if not _gemm_ok(x, weight):
-            if _gemm_f32_ok(x, weight):
-                return matmul_nt(x, weight) + bias
+            if _gemm_f32_ok(x, weight) or _gemm_f32_widen_ok(x, weight):
+                return matmul_nt(x, weight) + _w(bias, x)
+            lib_fallback("matmul", f"x {x.dtype} {tuple(x.shape)}, weight {weight.dtype} {tuple(weight.shape)}")
             return F.linear(x, _w(weight, x), _w(bias, x))
     if _gemm_ok(x, weight) and _LINEAR_EPILOGUE:
         p = float(dropout_p) if training else 0.0
@@ -1027,6 +1062,7 @@ def lstm(x, rnn, hx=None):
         b_ih, b_hh = (rnn.bias_ih_l0, rnn.bias_hh_l0) if rnn.bias else (None, None)
         out, hn, cn = _LstmF32Fn.apply(x.float(), rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, h0, c0)
         return out.to(x.dtype), (hn.unsqueeze(0), cn.unsqueeze(0))
+    lib_fallback("lstm", f"num_layers {rnn.num_layers}, bidirectional {rnn.bidirectional}, hidden {rnn.hidden_size}")
     out, hn = rnn(x.float(), hx) if hx is not None else rnn(x.float())
     return out.to(x.dtype), hn
 
@@ -1711,6 +1747,7 @@ class _FrontendConvFn(torch.autograd.Function):
             y1 = (gemm_f32(A, wm, P, Co, 9 * Ci, 9 * Ci, 9 * Ci, 0, 0) + b1.float()).view(B, To, Fo, Co)
             y2 = (gemm_f32(A[:, centre * Ci:], w2m, P, Co, Ci, 9 * Ci, Ci, 0, 0) + b2.float()).view(B, To, Fo, Co)
         else:
+            lib_fallback("frontend conv block 2", f"{xc.dtype}, fp32 HIP GEMM off")
             Ac = A.view(P, 9, Ci)[:, centre, :]
             y1 = F.linear(A, wm, b1.to(xc.dtype)).view(B, To, Fo, Co)
             y2 = F.linear(Ac, w2m, b2.to(xc.dtype)).view(B, To, Fo, Co)
@@ -2027,6 +2064,7 @@ def relpos_attention(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal
     """Fused HIP kernels (forward and backward) unless the caller wants the [B,H,T,T] weights back (plots only). ``dpk_deferrable``:
     the caller made ``pk`` with ops.matmul_nt on the HIP GEMM path and nothing else reads its gradient (see _RelPosAttnFn.backward)."""
     if need_weights:
+        lib_fallback("relpos_attention(need_weights)", "the [B,H,T,T] attention map is only materialised by the ATen route")
         return _relpos_attention_glue(qkv, pk, pos_bias_u, pos_bias_v, key_lens, H, scale, causal, dropout_p, need_weights)
     p = float(dropout_p)
     if ATTN_F32_EXACT and qkv.dtype == torch.float32:      # compute_dtype fp32 = the parity mode: no operand is rounded to bf16

@@ -19,8 +19,11 @@ _HYPER_SLOTS = 64
 class FusedClipAdamW:
     """Exposes ``param_groups`` (the Noam scheduler writes ``lr`` there) and ``step()``; state = flat m, v."""
 
-    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0, skip_nonfinite=False):
         self.arena = arena
+        # False (default) = the reference: a step whose gradient norm is not finite is applied like any other (SB/core.py:1072-1093);
+        # True: the kernel leaves parameters and moments alone for such a step and counts it (take_skipped_steps)
+        self.skip_nonfinite = bool(skip_nonfinite)
         self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
                               "params": arena.params_ordered}]
         self.max_grad_norm = float(max_grad_norm or 0.0)
@@ -66,7 +69,8 @@ class FusedClipAdamW:
         C.require_gpu(a.flat_params)
         with prof.region("clip_adamw"):
             C.check(C.lib().tsasr_clip_adamw_step(C.ptr(a.flat_params), C.ptr(a.flat_params16), C.ptr(a.grads), C.ptr(self.exp_avg),
-                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self._norm_buf[0:1]), C.ptr(self._norm_buf[1:2]), a.numel,
+                                                  C.ptr(self.exp_avg_sq), C.ptr(self._hyper_dev), C.ptr(self._norm_buf[0:1]),
+                                                  C.ptr(self._norm_buf[1:2]) if self.skip_nonfinite else None, a.numel,
                                                   float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.max_grad_norm,
                                                   C.ptr(self._ws), self._ws.numel(), C.stream_ptr()), "tsasr_clip_adamw_step")
             a.refresh_transposed()
@@ -126,9 +130,9 @@ class _WrappedTorchOptimizer:
         self.arena.zero_()
 
 
-def make_optimizer(opt_class, params, arena, max_grad_norm):
+def make_optimizer(opt_class, params, arena, max_grad_norm, skip_nonfinite=False):
     kw = opt_class.keywords if isinstance(opt_class, functools.partial) else {}
     base = opt_class.func if isinstance(opt_class, functools.partial) else opt_class
     if base is torch.optim.AdamW and not (set(kw) - {"lr", "betas", "eps", "weight_decay"}):
-        return FusedClipAdamW(arena, max_grad_norm=max_grad_norm, **kw)
+        return FusedClipAdamW(arena, max_grad_norm=max_grad_norm, skip_nonfinite=skip_nonfinite, **kw)
     return _WrappedTorchOptimizer(opt_class(params), arena, max_grad_norm)
