@@ -25,6 +25,14 @@ def test_rccl_collectives_captured_in_graph_and_replayed():
     assert "RCCL single-rank path OK" in r.stdout
 
 
+def test_bucket_collectives_are_issued_and_complete_during_backward():
+    """Overlap property of the bucketed all-reduce on one GPU (tests/helpers/rccl_overlap_check.py): with ~26 buckets of 8 MiB the first
+    collective is issued while backward runs and completes before backward ends; the captured step issues the same collectives in order."""
+    env = dict(os.environ, MASTER_PORT="29548")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_overlap_check.py")], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "RCCL overlap property OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_two_ranks_on_one_gpu_over_gloo_equal_single_process(graph):
     """Data parallel with device tensors: two ranks share the GPU, gloo carries the bucket all-reduces (tests/helpers/dp_gloo_gpu_check.py):

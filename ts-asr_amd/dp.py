@@ -168,6 +168,7 @@ class GradArena:
         # ranks drifted apart (tests/helpers/dp_gloo_gpu_check.py)
         self._contrib, self._contrib_step = {}, {}
         self._handles, self.sent_log, self._next_send = [], [], 0
+        self.probe = None       # tests: a dict that _send / finish_backward fill with the overlap evidence of one eager step
         self.aux_streams, self._main_stream = [], None
         self.companions = []  # flat buffers that must follow a re-layout (optimizer moments)
         self._deferred, self._keepalive, self._defer_ring = [], None, None
@@ -439,6 +440,11 @@ class GradArena:
                                                    ctypes.c_void_p(self.comm_stream.cuda_stream)), "tsasr_allreduce_bucket")
             self._handles.append((None, None, payload, back))
             self.sent_log.append((b["lo"], b["hi"]))
+            if self.probe is not None and "first_done" not in self.probe and not torch.cuda.is_current_stream_capturing():
+                # overlap probe (tests): when was the FIRST bucket's collective issued, and an event behind it on the communication stream
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(self.comm_stream)
+                self.probe.update(first_done=ev, first_in_backward=bool(self.in_backward))
             return
         if dist.get_backend(self.group) == "nccl":
             self._handles.append((dist.all_reduce(payload, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, payload, back))
@@ -447,6 +453,10 @@ class GradArena:
         self.sent_log.append((b["lo"], b["hi"]))
 
     def finish_backward(self):
+        if self.probe is not None and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event(enable_timing=True)       # the end of backward on the main stream (every forked stream has been joined)
+            ev.record()
+            self.probe.update(backward_done=ev, sent_during_backward=len(self.sent_log))
         if self.device.type == "cuda":
             from . import ops
             self.flush_wgrads(release=True)   # every queued weight gradient, one grouped launch (accumulates into the arena)
