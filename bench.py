@@ -112,7 +112,27 @@ def cpu_baseline(brain, torch, budget_steps=6, B=4):   # ~10 s of host work
         if i > 0:
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(B * T_MEL / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    # What this "port" figure is worth relative to the REFERENCE: tools/cpu_crosscheck.py times the imported reference modules and this
+    # oracle back to back in the build container (identical inputs, weights, exclusions; profiles/r*_cpu_crosscheck.json, committed).
+    # reference_ratio = oracle frames/s / reference frames/s there: multiply nothing - it says the port is within that factor of the reference.
+    ref_ratio, ref_src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_cpu_crosscheck.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if "reference_ratio" in d:
+                ref_ratio, ref_src = d["reference_ratio"], os.path.basename(path)
+                break
+        except (OSError, ValueError):
+            continue
+    return {"value": round(B * T_MEL / med, 1), "unit": "frames/s", "cores": cores, "kind": "port", "threads": cores, "cpu_model": cpu_model,
+            "reference_ratio": ref_ratio, "reference_ratio_source": ref_src,
             "host": {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota, "cpu_share_of_a_one_gpu_job": share},
             "sample": f"fwd+loss+bwd of the same model/shape at B={B} (T=1000 mel, U=120, 5 s enrollment), fp32, median of {len(times)} steps after 1 warm-up; optimizer step excluded"}
 

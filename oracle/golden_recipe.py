@@ -27,6 +27,18 @@ CFG1 = dict(
     mix_lens=(1.0, 0.9, 0.8, 0.7), enroll_lens=(1.0, 0.75, 1.0, 0.5), tok_lens=(1.0, 0.9, 0.75, 0.5),
 )
 
+# Full-WIDTH model (BASELINE.json configs[1] layer shapes: d_model 256, Dh = 64, d_ffn 2048, joint 640, predictor 512) at two layers and two
+# short utterances: the shapes the benchmarked kernels are built for (Dh = 64 attention, J = 640 joint, H = 512 LSTM), checked whole-model
+# against the reference itself (oracle/gen_golden_d256.py -> tests/golden/c2_fullwidth.npz), not only against the oracle.
+CFG2 = dict(
+    sample_rate=16000, n_fft=512, n_mels=80, win_length=32,
+    d_model=256, nhead=4, encoder_num_layers=2, speaker_num_layers=2, d_ffn=2048,
+    kernel_size=31, joint_dim=640, decoder_neurons=512, vocab_size=29, blank_index=0,
+    frontend_channels=(128, 128), encoder_input_size=2560,
+    B=2, L_mix=31840, L_enroll=15840, U=20,
+    mix_lens=(1.0, 0.8), enroll_lens=(1.0, 0.75), tok_lens=(1.0, 0.75),
+)
+
 _LN_PAT = re.compile(
     r"(\.norm\.(weight|bias)$)|(layer_norm\.(weight|bias)$)|(after_conv\.0\.(weight|bias)$)"
     r"|(ffn_module[12]\.0\.(weight|bias)$)|(norm[12]\.norm\.(weight|bias)$)"

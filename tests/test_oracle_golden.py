@@ -5,13 +5,24 @@ import pytest
 import torch
 
 from oracle import tsasr_ref as R
-from oracle.golden_recipe import CFG1, det_tensor, det_weight, golden_inputs
+from oracle.golden_recipe import CFG1, CFG2, det_tensor, det_weight, golden_inputs
 
 ATOL = 2e-5  # fp32 forward tolerance on O(1) activations (1e-5 .. a few ulp of sums)
 
 
 def T(x):
     return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def c2_lattice_mask(shape):
+    """oracle/gen_golden_d256.py lattice_mask: 1 inside each utterance's RNN-T lattice, 0 outside."""
+    from oracle.golden_recipe import CFG2 as c
+    B, Tp, U1, _ = shape
+    m = torch.zeros(B, Tp, U1, 1)
+    for b in range(B):
+        tb, ub = int(round(float(c["mix_lens"][b]) * Tp)), int(round(float(c["tok_lens"][b]) * (U1 - 1)))
+        m[b, :tb, : ub + 1] = 1.0
+    return m
 
 
 def close(a, b, atol=ATOL, rtol=1e-4):
@@ -261,6 +272,40 @@ def test_full_chain_backward(golden):
             close(sd[name].grad, g[k], atol=2e-5, rtol=5e-3)
         checked += 1
     assert checked > 150
+
+def test_full_width_chain_vs_reference_golden(golden):
+    """The oracle at the benchmark's layer widths (oracle/golden_recipe.CFG2: d_model 256, Dh 64, d_ffn 2048, joint 640, predictor 512; 2 + 2
+    layers, B = 2) against the reference's own outputs and gradients (oracle/gen_golden_d256.py -> tests/golden/c2_fullwidth.npz)."""
+    g = golden["c2_fullwidth"]
+    sd = full_state_dict(CFG2, "cat")
+    batch = torch_batch(golden_inputs(CFG2))
+    with torch.no_grad():
+        c = {}
+        R.compute_forward(batch, sd, CFG2, "cat", collect=c)
+        hyps = R.greedy_decode(c["enc_proj"], sd, CFG2)
+    for k in ("norm", "spk_norm", "spk_emb", "enc", "enc_proj", "dec_proj", "logits"):
+        close(c[k], g[k], atol=2e-4, rtol=1e-3)
+    for b in range(CFG2["B"]):
+        assert hyps[b] == g["greedy_hyps"][b, : g["greedy_lens"][b]].tolist()
+    for v in sd.values():
+        v.requires_grad_(True)
+    logits = R.compute_forward(batch, sd, CFG2, "cat")
+    probe = T(det_tensor("probe.logits.c2", logits.shape, 1.0)) * c2_lattice_mask(logits.shape)
+    (logits * probe).sum().mul(1.0 / logits.numel()).backward()
+    checked = 0
+    for k in g.files:
+        if ":" not in k:
+            continue
+        kind, name = k.split(":", 1)
+        if name not in sd:
+            continue
+        if kind == "norm":
+            np.testing.assert_allclose(sd[name].grad.double().norm().item(), float(g[k]), rtol=2e-3, atol=1e-7)
+        else:
+            close(sd[name].grad, g[k], atol=2e-5, rtol=5e-3)
+        checked += 1
+    assert checked > 150
+
 
 @pytest.mark.parametrize("beam", [4, 15])
 def test_beam_search_vs_reference(golden, beam):
