@@ -150,6 +150,9 @@ def mix_sources(sigs, delays, start, duration, target_speaker_idx, sample_rate=1
     return mixed[a:a + math.ceil(duration * sample_rate)]
 
 
+MIX_MAX_SRC = 8          # csrc/dataio.hip
+
+
 def mix_sources_device(sigs, delays, start, duration, target_speaker_idx, sample_rate=16000, gain_nontarget=0):
     """mix_sources on the GPU (csrc/dataio.hip, tsasr_mix_sources): ``sigs`` are 1-D fp32 device tensors; returns the cropped mixture as a
     device tensor. The host only converts seconds to samples with the reference's own ceil (train_librispeechmix_scratch.py:370,379-385).
@@ -159,6 +162,8 @@ def mix_sources_device(sigs, delays, start, duration, target_speaker_idx, sample
     from . import _capi as C
     C.require_gpu(*sigs)
     n = len(sigs)
+    if n > MIX_MAX_SRC:      # the kernel takes up to 8 sources (LibriSpeechMix has 1 - 3): a longer list is mixed by the host formulas on the device tensors
+        return mix_sources(list(sigs), delays, start, duration, target_speaker_idx, sample_rate, gain_nontarget)
     lens = [int(s.numel()) for s in sigs]
     src = sigs[0].float().contiguous() if n == 1 else torch.cat([s.float().reshape(-1) for s in sigs])
     off = (ctypes.c_longlong * (n + 1))(*([0] + [sum(lens[:j + 1]) for j in range(n)]))
@@ -202,7 +207,10 @@ def manifest_batches(json_path, hparams, data_folder=None, device="cpu"):
     and tokenising text are the caller's job (no torchaudio / dataset on the GPU box): every entry names, next to the reference's keys,
     a `tensors` file (torch.save of {"sigs": [1-D waveforms of the sources], "enroll_sig": 1-D, "tokens": 1-D int}). The mixture is
     built here as audio_pipeline does (mix_sources: gains, delays, sum, crop; trim_enroll), examples are sorted by duration
-    (`sorting: ascending`) and grouped by DynamicBatchSampler when hparams has `max_batch_length`, else in fixed `batch_size` groups."""
+    (`sorting: ascending`) and grouped by DynamicBatchSampler when hparams has `max_batch_length`, else in fixed `batch_size` groups.
+    device="cuda" builds the mixtures with csrc/dataio.hip; with `gain_nontarget` != 0 those differ from device="cpu" in the last bits (the two
+    mean powers are fp64 sums rounded once on the device, fp32 cascade sums on the host: a few ulp of the samples) - train and evaluate one
+    manifest with one setting when runs must be comparable bit for bit."""
     entries = load_manifest(json_path, {"data_folder": data_folder} if data_folder else None)
     sr = int(hparams.get("sample_rate", 16000))
     on_device = torch.device(device).type == "cuda"      # the mixture is then built by the HIP kernel from the sources' device copies

@@ -1007,7 +1007,7 @@ class _LstmF32Fn(torch.autograd.Function):
         H = w_hh.shape[1]
         f = lambda t: None if t is None else _f32(t).contiguous()  # noqa: E731
         wi, wh, bi, bh, h0c, c0c = f(w_ih), f(w_hh), f(b_ih), f(b_hh), f(h0), f(c0)
-        train = any(ctx.needs_input_grad)
+        train = torch.is_grad_enabled() and any(ctx.needs_input_grad)      # (the searchers call this under no_grad: no gate / cell-state planes then)
         hs = torch.empty(B, U, H, dtype=torch.float32, device=x.device)
         hn, cn = torch.empty(B, H, dtype=torch.float32, device=x.device), torch.empty(B, H, dtype=torch.float32, device=x.device)
         cs = torch.empty(B, U, H, dtype=torch.float32, device=x.device) if train else None
