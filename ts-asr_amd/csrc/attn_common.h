@@ -90,3 +90,48 @@ __device__ __forceinline__ unsigned attn_keep16(unsigned row_state, int jblk, in
     attn_pair_masks(row_state, jblk, hh, thr16, m);
     return attn_keep_bits(m);
 }
+
+// ---- helpers of the everything-in-LDS kernels (csrc/attention_short.hip, csrc/attention_fused.hip) ---------------------------------------
+
+constexpr float AT2_THR_LOG2 = 6.f;     // the running maximum is raised when a new row maximum exceeds it by this many powers of two
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {     // own DMA pieces landed (all but the N youngest), then every wave's
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// x + (float) half of the packed fp16 pair, as fma(half, one, x) with `one` opaque to the optimiser: hipcc then selects v_fma_mix_f32 (the
+// conversion rides in the operand). NOT inline asm: these read MFMA results, and hipcc pads the MFMA -> VALU wait states only for
+// instructions it can see (guide 5.7 item 2) - the asm form of this file's first version read the accumulators early (NaN).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float add_h_lo(float x, unsigned pair, float one) { return __builtin_fmaf((float)__builtin_bit_cast(f16x2, pair)[0], one, x); }
+__device__ __forceinline__ float add_h_hi(float x, unsigned pair, float one) { return __builtin_fmaf((float)__builtin_bit_cast(f16x2, pair)[1], one, x); }
+__device__ __forceinline__ unsigned pk_f16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2)); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// one 8-row x 128-byte LDS-DMA piece of a [rows][64] bf16 tile through a buffer descriptor (base = the tile's row 0 / column 0 in global
+// memory, 32-bit offsets): lane (prow = lane >> 3, pos = lane & 7) fetches 16 bytes of source row src_row + prow into LDS slot (prow, pos).
+// voff_lane = prow * stride + (swizzled chunk << 4) is the lane's constant part (the caller keeps one per tile kind); a piece whose eight
+// rows all exist costs one vector add on top of scalar arithmetic, a piece that straddles the first / last row clamps per lane.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma_buf16(i32x4 srd, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_piece(i32x4 srd, int stride_b, unsigned chunk_lane, int src_row, int lo, int hi, unsigned col_b, unsigned lds_dst, int lane) {
+    // source row of this lane = clamp(src_row + prow, lo, hi) = src_row + med3(prow, lo - src_row, hi - src_row): three full-rate vector operations
+    const int prow = lane >> 3;
+    const int rel = min(max(prow, lo - src_row), hi - src_row);
+    const unsigned voff = __umul24((unsigned)rel & 0xffffffu, (unsigned)stride_b) + chunk_lane + (unsigned)(src_row * stride_b);
+    dma_buf16(srd, voff, col_b, lds_dst);
+}
+template <int OFF>
+__device__ __forceinline__ void g_store_pair(unsigned addr, unsigned pair, bool dup) {      // fp16 pair -> rows OFF/64 and OFF/64 + 1 of a [32][32] fp16 tile
+    asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(addr), "v"(pair), "n"(OFF), "n"(OFF + 64) : "memory");
+    if (dup) asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(addr), "v"(pair), "n"(OFF + 4096), "n"(OFF + 4096 + 64) : "memory");
+}
+
