@@ -168,12 +168,20 @@ int tsasr_convmod_bwd(const void *dz, const void *y2, const float *b2, const flo
  * waves gather the patch rows from x [B,T,F,Ci] (bf16, channels-last) with the padding rule folded into the source address. Wm [128, 9*Ci] =
  * the 3x3 filter as [Co, (kt, kf, ci)], W2 [128, Ci] (bf16); b1 / b2 fp32 [128]; y1, y2 [B,T',F',128] bf16. Co == 128, Ci in {64, 128}.
  * Filter gradients: dWm [128, 9*Ci], dW2 [128, Ci] fp32 (overwritten; split-K slabs in the workspace, summed in fixed order) from dy1, dy2
- * [P,128] and x. (The data gradient is dy1 . Wm through tsasr_gemm_bf16 + tsasr_frontend_col2im.) */
+ * [P,128] and x. Data gradient: dx [B,T,F,Ci] bf16 (every element written) as ONE gathered GEMM launch over classes of input pixels (which
+ * taps and output positions reach a pixel depends on its parity and on the reflected border rows) - no [P, 9*Ci] gradient matrix, no inverse
+ * gather pass (tsasr_frontend_col2im remains the fp32 / other-shape path). The plan (classes + launch order of their 128-pixel tiles)
+ * depends on (B, T, F, causal) only: tsasr_conv3x3s2_dgrad_plan fills a HOST buffer of tsasr_conv3x3s2_dgrad_plan_bytes (0 = unsupported
+ * shape), the caller uploads it once and passes the device copy. */
 int tsasr_conv3x3s2_fwd(const void *x, const void *Wm, const float *b1, const void *W2, const float *b2, void *y1, void *y2, int B, int T, int F,
                         int Ci, int Co, int causal, void *stream);
 size_t tsasr_conv3x3s2_wgrad_workspace_bytes(int B, int T, int F, int Ci);
 int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
                           void *workspace, size_t workspace_bytes, void *stream);
+size_t tsasr_conv3x3s2_dgrad_plan_bytes(int B, int T, int F, int causal);
+int tsasr_conv3x3s2_dgrad_plan(int B, int T, int F, int causal, void *plan_host, size_t plan_bytes);
+int tsasr_conv3x3s2_dgrad(const void *dy1, const void *dy2, const void *Wm, const void *W2, void *dx, int B, int T, int F, int Ci, int Co, int causal,
+                          const void *plan_dev, size_t plan_bytes, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Convolutional front-end (SB/lobes/models/convolution.py:103-266, Conv2d.forward SB/nnet/CNN.py:629-711): stride-2 3x3
  * conv ('same' = reflect padding, or causal = (2,0) zero pad on time, (1,1) on frequency) + 1x1 stride-2 residual conv.

@@ -178,13 +178,15 @@ def test_convblock_module_uses_fused_path():
     assert rel_l2(a, b) < 6e-3     # the unfused chain rounds y, r and both LayerNorm outputs to bf16 on the way
 
 
-@pytest.mark.parametrize("B,T,F,Ci,causal", [(2, 37, 21, 128, False), (2, 37, 21, 128, True), (1, 500, 40, 128, False), (3, 10, 8, 64, True), (1, 2, 2, 128, False)])
+@pytest.mark.parametrize("B,T,F,Ci,causal", [(2, 37, 21, 128, False), (2, 37, 21, 128, True), (1, 500, 40, 128, False), (3, 10, 8, 64, True), (1, 2, 2, 128, False),
+                                             (2, 3, 3, 64, False), (4, 124, 40, 64, False), (2, 45, 40, 64, True)])
 def test_conv_implicit_gemm_equals_im2col_path(B, T, F, Ci, causal):
     """Front-end block 2's convolutions as implicit GEMMs (csrc/gemm.hip conv_s2_fwd / conv_s2_wgrad: the ring kernels' loader waves gather
     the 3x3 patch rows, padding rule folded into the address - SB/nnet/CNN.py:629-711 reflect / causal) against the im2col + GEMM path
     they replace, which the golden-vector tests above pin to the reference: same bf16 operands, fp32 accumulation in another order.
-    Outputs, data gradient, both filter gradients and both bias gradients; odd and even sizes, reflection at both ends, causal zero
-    padding, a single output position, Ci = 64."""
+    Outputs, data gradient (conv_s2_dgrad: one gathered GEMM per class of input pixels, against dy . Wm + col2im), both filter gradients and
+    both bias gradients; odd and even sizes, reflection at both ends (an index reached by four taps at T = F = 3), causal zero padding, a
+    single output position, Ci = 64."""
     ops = importlib.import_module("ts-asr_amd.ops")
     Co = 128
     g = torch.Generator().manual_seed(T * 3 + F + Ci)
@@ -208,3 +210,48 @@ def test_conv_implicit_gemm_equals_im2col_path(B, T, F, Ci, causal):
     for a, b_, name in zip(res[True], res[False], ("y1", "y2", "dx", "dw1", "db1", "dw2", "db2")):
         rel = float((a - b_).norm() / (b_.norm() + 1e-30))
         assert rel < (4e-3 if name in ("y1", "y2", "dx") else 2e-4), (name, rel)      # bf16 outputs round once each way; fp32 filter gradients
+
+
+@pytest.mark.parametrize("B,T,F,Ci,causal", [(2, 9, 6, 64, False), (1, 7, 5, 128, True), (3, 4, 4, 64, False)])
+def test_conv_data_gradient_vs_definition(B, T, F, Ci, causal):
+    """conv_s2_dgrad against the transpose of the convolution written out from its definition in float64 (SB/nnet/CNN.py:629-711: reflect /
+    causal padding as csrc/frontend.hip src_index; the 1x1 stride-2 branch reads x[2t', 2f']): same bf16 operands, one rounding of the result."""
+    ops = importlib.import_module("ts-asr_amd.ops")
+    Co = 128
+    g = torch.Generator().manual_seed(B * 100 + T * 7 + F)
+    x = torch.randn(B, T, F, Ci, generator=g).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5))
+    w2 = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5)
+    b1, b2 = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    To, Fo = (T - 1) // 2 + 1, (F - 1) // 2 + 1
+    d1 = torch.randn(B, To, Fo, Co, generator=g).to(torch.bfloat16)
+    d2 = torch.randn(B, To, Fo, Co, generator=g).to(torch.bfloat16)
+    xl = x.clone().requires_grad_()
+    y1, y2 = ops._FrontendConvFn.apply(xl, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), causal)
+    torch.autograd.backward([y1, y2], [d1.to(DEV), d2.to(DEV)])
+
+    def src(o, k, n, mode):
+        if mode == 1:
+            i = 2 * o + k - 2
+            return -1 if i < 0 else i
+        i = 2 * o + k - 1
+        if mode == 0:
+            i = -i if i < 0 else i
+            return 2 * (n - 1) - i if i >= n else i
+        return -1 if (i < 0 or i >= n) else i
+
+    tm, fm = (1, 2) if causal else (0, 0)
+    w1b = w1.to(torch.bfloat16).double().numpy()      # [Co, Ci, kF, kT]
+    w2b = w2.to(torch.bfloat16).double().numpy().reshape(Co, Ci)
+    d1n, d2n = d1.double().numpy(), d2.double().numpy()
+    ref = np.zeros((B, T, F, Ci))
+    for to in range(To):
+        for fo in range(Fo):
+            for kt in range(3):
+                for kf in range(3):
+                    ti, fi = src(to, kt, T, tm), src(fo, kf, F, fm)
+                    if ti >= 0 and fi >= 0:
+                        ref[:, ti, fi, :] += d1n[:, to, fo, :] @ w1b[:, :, kf, kt]
+            ref[:, 2 * to, 2 * fo, :] += d2n[:, to, fo, :] @ w2b
+    got = xl.grad.double().cpu().numpy()
+    assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() and np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-3      # one bf16 rounding

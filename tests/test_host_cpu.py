@@ -416,3 +416,64 @@ def test_manifest_batches_mix_and_bucket(tmp_path):
     ref[1600:3600] += t1["sigs"][1]                                                         # second source (2000 samples) delayed by 0.1 s
     assert torch.allclose(b0.mixed_sig.data[0, :4000], ref)
     assert b0.tokens_bos.data[0, 0] == 0 and torch.equal(b0.tokens_bos.data[0, 1:7], t1["tokens"])
+
+
+def _src_index(o, k, n, mode):      # the padding rule of the front-end convolutions (SB/nnet/CNN.py:629-711: reflect / causal), as csrc/frontend.hip
+    if mode == 1:
+        i = 2 * o + k - 2
+        return -1 if i < 0 else i
+    i = 2 * o + k - 1
+    if mode == 0:
+        if i < 0:
+            i = -i
+        if i >= n:
+            i = 2 * (n - 1) - i
+        return i
+    return -1 if (i < 0 or i >= n) else i
+
+
+@pytest.mark.parametrize("B,T,F,causal", [(2, 37, 21, False), (2, 37, 21, True), (1, 500, 40, False), (3, 10, 8, True), (1, 2, 2, False), (2, 3, 3, False),
+                                          (1, 4, 5, True), (2, 2, 7, True), (1, 6, 2, False)])
+def test_conv_dgrad_plan_covers_every_pixel_with_its_taps(pkg, B, T, F, causal):
+    """The host plan of the front-end block-2 data gradient (csrc/gemm.hip conv_dgrad_plan: classes of input pixels x tap slots, launch order of
+    the 128-pixel tiles) against the definition: every input pixel lies in exactly one class row, its slots name exactly the (tap, output
+    position) pairs whose padded source index is that pixel (the convolution's transpose, SB/nnet/CNN.py:629-711), the 1x1 branch rides where
+    the centre tap does, and every tile is launched exactly once. Pure host code: no kernel runs."""
+    capi = importlib.import_module("ts-asr_amd._capi")
+    L = capi.lib()
+    n = L.tsasr_conv3x3s2_dgrad_plan_bytes(B, T, F, int(causal))
+    assert n > 0 and n % 4 == 0
+    plan = np.zeros(n // 4, dtype=np.int32)
+    assert L.tsasr_conv3x3s2_dgrad_plan(B, T, F, int(causal), plan.ctypes.data, n) == 0
+    ncls, slots, coff, toff = (int(v) for v in plan[:4])
+    To, Fo = (T - 1) // 2 + 1, (F - 1) // 2 + 1
+    tm, fm = (1, 2) if causal else (0, 0)
+    ckt, ckf = (2, 1) if causal else (1, 1)
+    want_t = {i: sorted((k, o) for o in range(To) for k in range(3) if _src_index(o, k, T, tm) == i) for i in range(T)}
+    want_f = {i: sorted((k, o) for o in range(Fo) for k in range(3) if _src_index(o, k, F, fm) == i) for i in range(F)}
+    seen = np.zeros((B, T, F), dtype=np.int32)
+    tiles_of = []
+    for ci in range(ncls):
+        c = plan[coff + 32 * ci: coff + 32 * ci + 32]
+        rows, nt, nf, t0, tstep, ost, f0, fstep, osf, nst, nsf, res_st, res_sf = (int(v) for v in c[:13])
+        kt, ct, kf, cf = c[16:20], c[20:24], c[24:28], c[28:32]
+        assert rows == B * nt * nf and 1 <= nst <= 4 and 1 <= nsf <= 4
+        tiles_of.append((rows + 127) // 128)
+        for it in range(nt):
+            ti = t0 + tstep * it
+            got_t = sorted((int(kt[s]), it * ost + int(ct[s])) for s in range(nst) if 0 <= it * ost + int(ct[s]) < To)
+            assert got_t == want_t[ti], (ti, got_t, want_t[ti])
+        for jf in range(nf):
+            fi = f0 + fstep * jf
+            got_f = sorted((int(kf[s]), jf * osf + int(cf[s])) for s in range(nsf) if 0 <= jf * osf + int(cf[s]) < Fo)
+            assert got_f == want_f[fi], (fi, got_f, want_f[fi])
+        has_centre = [(s, q) for s in range(nst) for q in range(nsf) if kt[s] == ckt and kf[q] == ckf]
+        assert ([(res_st, res_sf)] if res_st >= 0 else []) == has_centre
+        if res_st >= 0:      # the centre tap reads x[2 t', 2 f']: the 1x1 branch's only source
+            assert tstep in (0, 2) and (t0 % 2 == 0) and (f0 % 2 == 0) and 2 * int(ct[res_st]) == t0 and 2 * int(cf[res_sf]) == f0
+        seen[:, t0: t0 + max(tstep, 1) * nt: max(tstep, 1), f0: f0 + max(fstep, 1) * nf: max(fstep, 1)] += 1
+    assert (seen == 1).all()
+    order = plan[toff: toff + 2 * slots].reshape(slots, 2)
+    assert slots % 8 == 0 and slots >= sum(tiles_of)
+    launched = sorted((int(a), int(b)) for a, b in order if a >= 0)
+    assert launched == [(ci, t) for ci in range(ncls) for t in range(tiles_of[ci])]

@@ -68,6 +68,9 @@ _PROTOS = {
     "tsasr_conv3x3s2_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "tsasr_conv3x3s2_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_conv3x3s2_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_conv3x3s2_dgrad_plan_bytes": (c_size_t, [c_int] * 4),
+    "tsasr_conv3x3s2_dgrad_plan": (c_int, [c_int] * 4 + [c_void_p, c_size_t]),
+    "tsasr_conv3x3s2_dgrad": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_frontend_im2col": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "tsasr_frontend_col2im": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "tsasr_frontend_block_supported": (c_int, [c_int, c_int]),

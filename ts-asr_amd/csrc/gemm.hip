@@ -17,8 +17,11 @@
 // v_mfma_f32_32x32x16_bf16, fp32 accumulators, two LDS buffers with the next tile's global loads in flight during the MFMAs
 // (register staging, one barrier per k-tile), LDS rows padded by 16 B (conflict-free 16-byte fragment reads).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -1116,6 +1119,218 @@ __global__ __launch_bounds__(RING_THREADS, 1) void conv_s2_wgrad_kernel(const bf
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// data gradient of front-end block 2 (round 5): dx[b, ti, fi, :] = sum over the taps (kt, kf) and output positions (to, fo) with
+// src(to, kt) = ti, src(fo, kf) = fi of dy1[b, to, fo, :] . W1[:, (kt, kf), :]  (+ dy2[b, ti/2, fi/2, :] . W2 at even ti, fi) - a gathered GEMM
+// per CLASS of input pixels instead of dA = dy1 . Wm (a [P, 9 Ci] matrix in HBM) + the inverse gather fe_col2im. Which (tap, output
+// position) pairs reach an input index depends only on its parity, except next to a reflected border: along each axis the host plan
+// (conv_dgrad_axis) sorts the indices into stride-2 runs whose contributions are (k, o = run index + c) for a fixed list of (k, c) - taps
+// whose o falls outside [0, No) read the zero line - and SINGLE indices with their explicit list (the reflected rows: index 1, and n - 2
+// when n is odd). A 2-D class = (time run) x (frequency run); its rows (b, it, if) are tiled by 128, each tile contracts over
+// (slots of the class) x 128 output channels, the 1x1 branch rides as one more slot wherever the centre tap is in the list. The plan also
+// fixes the launch order of the tiles: sorted by the time position of their first row and dealt to the XCDs in contiguous runs, so that the
+// classes that gather the same dy rows run side by side on the same L2.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvDgradClass {      // 32 ints, read through scalar loads (workgroup-uniform)
+    int rows, nt, nf, t0, tstep, ost, f0, fstep, osf, nst, nsf, res_st, res_sf, pad0, pad1, pad2;
+    int kt[4], ct[4], kf[4], cf[4];
+};
+#define CONV_DGRAD_HDR 8     // plan header ints: [0] classes, [1] tiles (launch slots, a multiple of 8), [2] class table offset, [3] tile table offset
+
+__global__ __launch_bounds__(RING_THREADS, 1) void conv_s2_dgrad_kernel(const bf16_t *__restrict__ dy1, const bf16_t *__restrict__ dy2,
+                                                                        const bf16_t *__restrict__ Wm /*[128][9Ci]*/, const bf16_t *__restrict__ W2 /*[128][Ci]*/,
+                                                                        bf16_t *__restrict__ dx, ConvGeom g, const int *__restrict__ plan) {
+    using TA = RingTile<128, false>;
+    using TB = RingTile<64, true>;
+    constexpr int SLOT = TA::BYTES + TB::BYTES, NS = GB_K / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave8 & 3, wm = wave >> 1, wn = wave & 1;
+    const int cls = plan[plan[3] + 2 * blockIdx.x], tile = plan[plan[3] + 2 * blockIdx.x + 1];
+    if (cls < 0) return;      // a padding slot of the launch order (workgroup-uniform, before any barrier)
+    const ConvDgradClass &c = *reinterpret_cast<const ConvDgradClass *>(plan + plan[2] + 32 * cls);
+    const int n0 = blockIdx.y * 64, r0 = tile * 128;
+    const int nreg = c.nst * c.nsf, nk = 2 * (nreg + (c.res_st >= 0 ? 1 : 0));
+    if (wave8 >= 4) {
+        constexpr int LPT = TA::INSTR + TB::INSTR;
+        const bf16_t *gb[TB::INSTR], *g2[TB::INSTR];
+        TB::src_ptrs(Wm, 9 * g.Ci, n0, g.Ci, 0, wave, lane, gb);
+        TB::src_ptrs(W2, g.Ci, n0, g.Ci, 0, wave, lane, g2);
+        int rb[TA::INSTR], rit[TA::INSTR], rif[TA::INSTR], chunk[TA::INSTR];      // this lane's four pixels: fixed, only the slot changes
+#pragma unroll
+        for (int i = 0; i < TA::INSTR; ++i) {
+            const int byte = (i * 4 + wave) * 1024 + lane * 16;
+            const int lrow = byte / TA::ROW_BYTES, pos = (byte % TA::ROW_BYTES) / 16;
+            const unsigned row = (unsigned)min(r0 + lrow, c.rows - 1), q = row / (unsigned)c.nf;
+            rif[i] = (int)(row - q * (unsigned)c.nf);
+            rb[i] = (int)(q / (unsigned)c.nt);
+            rit[i] = (int)(q - (unsigned)rb[i] * (unsigned)c.nt);
+            chunk[i] = TA::swz(lrow, pos) * 8;
+        }
+        auto issue = [&](int kt) {
+            char *slot = smem + (kt % RING_STAGES) * SLOT;
+            const int sl = kt >> 1, half = kt & 1;
+            const bool res = sl >= nreg;
+            const int st = res ? c.res_st : sl / c.nsf, sf = res ? c.res_sf : sl - st * c.nsf;
+            const int ct = c.ct[st], cf = c.cf[sf];
+            const bf16_t *src = (res ? dy2 : dy1) + half * GB_K;
+#pragma unroll
+            for (int i = 0; i < TA::INSTR; ++i) {
+                const int to = rit[i] * c.ost + ct, fo = rif[i] * c.osf + cf;
+                const bool ok = (unsigned)to < (unsigned)g.To && (unsigned)fo < (unsigned)g.Fo;
+                const bf16_t *p = ok ? src + ((long long)(rb[i] * g.To + to) * g.Fo + fo) * 128 + chunk[i] : g_conv_zero_line + chunk[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                 (__attribute__((address_space(3))) void *)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
+            if (res) TB::issue_at(g2, (long long)half * GB_K * g.Ci, slot + TA::BYTES, wave);
+            else TB::issue_at(gb, (long long)half * GB_K * 9 * g.Ci + (c.kt[st] * 3 + c.kf[sf]) * g.Ci, slot + TA::BYTES, wave);
+        };
+        for (int t = 0; t < RING_STAGES - 1; ++t)
+            if (t < nk) issue(t);
+        for (int kt = 0; kt < nk; ++kt) {
+            ring_wait_landed(min(RING_STAGES - 2, nk - 1 - kt), LPT);
+            __builtin_amdgcn_s_barrier();
+            if (kt + RING_STAGES - 1 < nk) issue(kt + RING_STAGES - 1);
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    f32x16 acc[2];
+    acc[0] = (f32x16){0};
+    acc[1] = (f32x16){0};
+    int a_off[2][NS][TA::NFO], b_off[NS][TB::NFO];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) TA::frag_offsets(wm * 64 + 32 * i, s, lane, a_off[i][s]);
+        TB::frag_offsets(wn * 32, s, lane, b_off[s]);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char *as = smem + (kt % RING_STAGES) * SLOT, *bs = as + TA::BYTES;
+        bf16x8 af[2][NS], bfr[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i][s] = TA::frag_at(as, a_off[i][s]);
+            bfr[s] = TB::frag_at(bs, b_off[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bfr[s], acc[i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // the loader waves end behind it; the ring becomes the output staging tile
+    constexpr int LDT = 64 + 8;
+    bf16_t *tl = reinterpret_cast<bf16_t *>(smem);      // [128][LDT] bf16
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) tl[(wm * 64 + 32 * i + (gq & 3) + 8 * (gq >> 2) + 4 * hh) * LDT + wn * 32 + r] = (bf16_t)acc[i][gq];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 128 * 8; e += 256) {
+        const int rr = e >> 3, cc = (e & 7) * 8;
+        const int row = r0 + rr;
+        if (row >= c.rows) continue;
+        const unsigned q = (unsigned)row / (unsigned)c.nf, fi_i = (unsigned)row - q * (unsigned)c.nf, b = q / (unsigned)c.nt, ti_i = q - b * (unsigned)c.nt;
+        const long long pix = ((long long)b * g.T + c.t0 + c.tstep * (int)ti_i) * g.F + c.f0 + c.fstep * (int)fi_i;
+        *reinterpret_cast<uint4 *>(dx + pix * g.Ci + n0 + cc) = *reinterpret_cast<const uint4 *>(tl + rr * LDT + cc);
+    }
+}
+
+// ---- host plan of conv_s2_dgrad_kernel ----
+struct ConvAxisClass { int i0, step, n, ostep, ns, k[4], c[4]; };
+static int conv_src_index_host(int o, int k, int n, int mode) {      // = conv_src_index
+    if (mode == 1) { const int i = 2 * o + k - 2; return i < 0 ? -1 : i; }
+    int i = 2 * o + k - 1;
+    if (mode == 0) { if (i < 0) i = -i; if (i >= n) i = 2 * (n - 1) - i; return i; }
+    return (i < 0 || i >= n) ? -1 : i;
+}
+// the classes of one axis (input length n, output length No, padding mode): false if an index collects more than four contributions
+static bool conv_dgrad_axis(int n, int No, int mode, std::vector<ConvAxisClass> &out) {
+    std::vector<std::vector<std::pair<int, int>>> L(n);
+    for (int o = 0; o < No; ++o)
+        for (int k = 0; k < 3; ++k) {
+            const int i = conv_src_index_host(o, k, n, mode);
+            if (i >= 0) L[i].push_back({k, o});
+        }
+    const int off = mode == 1 ? 2 : 1;
+    std::vector<char> regular(n);
+    for (int i = 0; i < n; ++i) {
+        std::vector<std::pair<int, int>> e;
+        for (int k = 0; k < 3; ++k)
+            if (((i - k + off) & 1) == 0) {
+                const int o = (i - k + off) / 2;
+                if (i - k + off >= 0 && o < No) e.push_back({k, o});
+            }
+        std::sort(e.begin(), e.end());
+        std::sort(L[i].begin(), L[i].end());
+        regular[i] = e == L[i];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (regular[i]) {
+            if (i >= 2 && regular[i - 2]) continue;      // inside a run that started earlier
+            ConvAxisClass a{};
+            a.i0 = i; a.step = 2; a.ostep = 1; a.n = 0;
+            for (int j = i; j < n && regular[j]; j += 2) ++a.n;
+            for (int k = 0; k < 3; ++k)
+                if (((i - k + off) & 1) == 0) { a.k[a.ns] = k; a.c[a.ns] = (i - k + off) / 2; ++a.ns; }      // o of run index 0 (>= 0; the far end of the run may pass No - 1: zero line)
+            out.push_back(a);
+        } else {
+            if (L[i].size() > 4) return false;
+            ConvAxisClass a{};
+            a.i0 = i; a.step = 0; a.ostep = 0; a.n = 1;
+            for (auto &kc : L[i]) { a.k[a.ns] = kc.first; a.c[a.ns] = kc.second; ++a.ns; }
+            if (a.ns == 0) { a.ns = 1; a.k[0] = 0; a.c[0] = -1; }      // an index nothing reads (cannot happen with stride 2, kernel 3): one slot of zeros
+            out.push_back(a);
+        }
+    }
+    return true;
+}
+struct ConvDgradPlan { std::vector<ConvDgradClass> cls; std::vector<int> tile_cls, tile_idx; int slots; };
+static bool conv_dgrad_plan(int B, int T, int F, int causal, bool with_order, ConvDgradPlan &pl) {
+    const int To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    std::vector<ConvAxisClass> ta, fa;
+    if (!conv_dgrad_axis(T, To, causal ? 1 : 0, ta) || !conv_dgrad_axis(F, Fo, causal ? 2 : 0, fa)) return false;
+    const int ckt = causal ? 2 : 1, ckf = 1;      // the tap that reads x[2 t', 2 f']
+    long long tiles = 0;
+    for (auto &a : ta)
+        for (auto &f : fa) {
+            ConvDgradClass c{};
+            c.nt = a.n; c.nf = f.n; c.rows = B * a.n * f.n;
+            c.t0 = a.i0; c.tstep = a.step; c.ost = a.ostep; c.f0 = f.i0; c.fstep = f.step; c.osf = f.ostep;
+            c.nst = a.ns; c.nsf = f.ns; c.res_st = c.res_sf = -1;
+            for (int s = 0; s < 4; ++s) { c.kt[s] = a.k[s]; c.ct[s] = a.c[s]; c.kf[s] = f.k[s]; c.cf[s] = f.c[s]; }
+            for (int s = 0; s < a.ns; ++s)
+                for (int q = 0; q < f.ns; ++q)
+                    if (a.k[s] == ckt && f.k[q] == ckf) { c.res_st = s; c.res_sf = q; }
+            pl.cls.push_back(c);
+            tiles += (c.rows + 127) / 128;
+        }
+    if (tiles > (1 << 22)) return false;
+    pl.slots = (int)((tiles + 7) / 8 * 8);
+    if (!with_order) return true;
+    // launch order: tiles sorted by (batch item, input time) of their first row, dealt to the 8 XCDs in contiguous runs (workgroup w runs on XCD w % 8)
+    std::vector<std::pair<long long, std::pair<int, int>>> keyed;
+    for (size_t ci = 0; ci < pl.cls.size(); ++ci) {
+        const ConvDgradClass &c = pl.cls[ci];
+        for (int t = 0; t < (c.rows + 127) / 128; ++t) {
+            const long long r0 = (long long)t * 128, q = r0 / c.nf, b = q / c.nt, it = q % c.nt;
+            keyed.push_back({b * T + c.t0 + c.tstep * it, {(int)ci, t}});
+        }
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    pl.tile_cls.assign(pl.slots, -1);
+    pl.tile_idx.assign(pl.slots, 0);
+    const int per = pl.slots / 8;
+    for (int w = 0; w < pl.slots; ++w) {
+        const size_t s = (size_t)(w % 8) * per + w / 8;
+        if (s < keyed.size()) { pl.tile_cls[w] = keyed[s].second.first; pl.tile_idx[w] = keyed[s].second.second; }
+    }
+    return true;
+}
+
 template <int BM, int BN, bool AT, bool BT>
 struct RingSmem {
     static constexpr size_t PIPE = (size_t)RING_STAGES * (RingTile<BM, AT>::BYTES + RingTile<BN, BT>::BYTES);
@@ -1440,6 +1655,46 @@ int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float
     gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * 9 * Ci / 4, 256), 256, 0, st>>>(slab1, dWm, 128, 9 * Ci, 9 * Ci, z1, (long long)128 * 9 * Ci, 0);
     gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * Ci / 4, 256), 256, 0, st>>>(slab2, dW2, 128, Ci, Ci, z2, (long long)128 * Ci, 0);
     TSASR_CHECK_LAUNCH("tsasr_conv3x3s2_wgrad");
+    return 0;
+}
+
+/* Data gradient of the same block as ONE gathered GEMM launch (conv_s2_dgrad_kernel): dx [B,T,F,Ci] bf16 (every element written) from dy1,
+ * dy2 [P,128] bf16 and the filters as the forward takes them. The plan (classes of input pixels + launch order of their tiles) depends on
+ * the shape only: tsasr_conv3x3s2_dgrad_plan fills a HOST buffer of tsasr_conv3x3s2_dgrad_plan_bytes, the caller keeps a device copy. */
+size_t tsasr_conv3x3s2_dgrad_plan_bytes(int B, int T, int F, int causal) {
+    ConvDgradPlan pl;
+    if (B <= 0 || T < 2 || F < 2 || !conv_dgrad_plan(B, T, F, causal, false, pl)) return 0;
+    return (size_t)(CONV_DGRAD_HDR + 32 * pl.cls.size() + 2 * (size_t)pl.slots) * sizeof(int);
+}
+int tsasr_conv3x3s2_dgrad_plan(int B, int T, int F, int causal, void *plan_host, size_t plan_bytes) {
+    TSASR_CHECK_ARG(plan_host && B > 0 && T >= 2 && F >= 2, "tsasr_conv3x3s2_dgrad_plan: bad argument");
+    ConvDgradPlan pl;
+    TSASR_CHECK_ARG(conv_dgrad_plan(B, T, F, causal, true, pl), "tsasr_conv3x3s2_dgrad_plan: unsupported shape (T=%d F=%d)", T, F);
+    const size_t need = (size_t)(CONV_DGRAD_HDR + 32 * pl.cls.size() + 2 * (size_t)pl.slots) * sizeof(int);
+    TSASR_CHECK_ARG(plan_bytes >= need, "tsasr_conv3x3s2_dgrad_plan: buffer too small");
+    int *p = (int *)plan_host;
+    memset(p, 0, need);
+    p[0] = (int)pl.cls.size(); p[1] = pl.slots; p[2] = CONV_DGRAD_HDR; p[3] = CONV_DGRAD_HDR + 32 * (int)pl.cls.size();
+    p[4] = B; p[5] = T; p[6] = F; p[7] = causal ? 1 : 0;
+    static_assert(sizeof(ConvDgradClass) == 32 * sizeof(int), "class record = 32 ints");
+    memcpy(p + p[2], pl.cls.data(), pl.cls.size() * sizeof(ConvDgradClass));
+    for (int w = 0; w < pl.slots; ++w) { p[p[3] + 2 * w] = pl.tile_cls[w]; p[p[3] + 2 * w + 1] = pl.tile_idx[w]; }
+    return 0;
+}
+int tsasr_conv3x3s2_dgrad(const void *dy1, const void *dy2, const void *Wm, const void *W2, void *dx, int B, int T, int F, int Ci, int Co, int causal,
+                          const void *plan_dev, size_t plan_bytes, void *stream) {
+    TSASR_CHECK_ARG(dy1 && dy2 && Wm && W2 && dx && plan_dev, "tsasr_conv3x3s2_dgrad: null pointer");
+    TSASR_CHECK_ARG(B > 0 && T >= 2 && F >= 2 && Co == 128 && Ci % 64 == 0 && Ci >= 64 && Ci <= 128, "tsasr_conv3x3s2_dgrad: unsupported shape (Ci=%d Co=%d)", Ci, Co);
+    ConvGeom g{B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, Ci, causal ? 1 : 0, causal ? 2 : 0};
+    TSASR_CHECK_ARG((long long)B * T * F < (1ll << 31), "tsasr_conv3x3s2_dgrad: more than 2^31 positions");
+    ConvDgradPlan pl;
+    TSASR_CHECK_ARG(conv_dgrad_plan(B, T, F, causal, false, pl), "tsasr_conv3x3s2_dgrad: unsupported shape (T=%d F=%d)", T, F);
+    TSASR_CHECK_ARG(plan_bytes >= (size_t)(CONV_DGRAD_HDR + 32 * pl.cls.size() + 2 * (size_t)pl.slots) * sizeof(int), "tsasr_conv3x3s2_dgrad: plan of another shape");
+    constexpr int lds = RING_STAGES * (RingTile<128, false>::BYTES + RingTile<64, true>::BYTES);
+    (void)hipFuncSetAttribute((const void *)conv_s2_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    conv_s2_dgrad_kernel<<<dim3((unsigned)pl.slots, (unsigned)(Ci / 64)), RING_THREADS, lds, (hipStream_t)stream>>>(
+        (const bf16_t *)dy1, (const bf16_t *)dy2, (const bf16_t *)Wm, (const bf16_t *)W2, (bf16_t *)dx, g, (const int *)plan_dev);
+    TSASR_CHECK_LAUNCH("tsasr_conv3x3s2_dgrad");
     return 0;
 }
 

@@ -1000,14 +1000,16 @@ class _LstmF32Fn(torch.autograd.Function):
     The recurrence is one HIP launch each way; dx / dW_ih / dW_hh / db are fp32 GEMMs over all (b, t) (csrc/gemm_f32.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0, grad_mode=True):
         C.require_gpu(x, w_ih, w_hh)
         xc = x.contiguous()
         B, U, I = xc.shape
         H = w_hh.shape[1]
         f = lambda t: None if t is None else _f32(t).contiguous()  # noqa: E731
         wi, wh, bi, bh, h0c, c0c = f(w_ih), f(w_hh), f(b_ih), f(b_hh), f(h0), f(c0)
-        train = torch.is_grad_enabled() and any(ctx.needs_input_grad)      # (the searchers call this under no_grad: no gate / cell-state planes then)
+        # grad_mode = torch.is_grad_enabled() AT THE CALL (inside forward() autograd has it switched off, and needs_input_grad only mirrors
+        # requires_grad): the searchers call this under no_grad - no gate / cell-state planes then
+        train = bool(grad_mode) and any(ctx.needs_input_grad)
         hs = torch.empty(B, U, H, dtype=torch.float32, device=x.device)
         hn, cn = torch.empty(B, H, dtype=torch.float32, device=x.device), torch.empty(B, H, dtype=torch.float32, device=x.device)
         cs = torch.empty(B, U, H, dtype=torch.float32, device=x.device) if train else None
@@ -1042,7 +1044,7 @@ class _LstmF32Fn(torch.autograd.Function):
         dw_ih = gemm_f32(dg2, xc.view(B * U, I), G, I, B * U, G, I, 1, 1) if ctx.needs_input_grad[1] else None
         dw_hh = gemm_f32(dg2, h_prev.view(B * U, H), G, H, B * U, G, H, 1, 1) if ctx.needs_input_grad[2] else None
         db = dg2.sum(0) if (b_ih is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])) else None
-        return (dx, dw_ih, dw_hh, db if ctx.needs_input_grad[3] else None, db if (b_hh is not None and ctx.needs_input_grad[4]) else None, dh0, dc0)
+        return (dx, dw_ih, dw_hh, db if ctx.needs_input_grad[3] else None, db if (b_hh is not None and ctx.needs_input_grad[4]) else None, dh0, dc0, None)
 
 
 def lstm_f32_ok(rnn):
@@ -1060,7 +1062,7 @@ def lstm(x, rnn, hx=None):
     if LSTM_F32_HIP and lstm_f32_ok(rnn) and x.is_cuda:
         h0, c0 = (None, None) if hx is None else (hx[0][0], hx[1][0])       # torch's (num_layers, B, H)
         b_ih, b_hh = (rnn.bias_ih_l0, rnn.bias_hh_l0) if rnn.bias else (None, None)
-        out, hn, cn = _LstmF32Fn.apply(x.float(), rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, h0, c0)
+        out, hn, cn = _LstmF32Fn.apply(x.float(), rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, h0, c0, torch.is_grad_enabled())
         return out.to(x.dtype), (hn.unsqueeze(0), cn.unsqueeze(0))
     lib_fallback("lstm", f"num_layers {rnn.num_layers}, bidirectional {rnn.bidirectional}, hidden {rnn.hidden_size}")
     out, hn = rnn(x.float(), hx) if hx is not None else rnn(x.float())
@@ -1698,6 +1700,27 @@ class _FrontendC1Fn(torch.autograd.Function):
 CONV_IMPLICIT = os.environ.get("TSASR_CONV_IMPLICIT", "1") != "0"      # front-end block 2 through the implicit-GEMM kernels (tests / A-B runs switch it off: the im2col path)
 
 
+CONV_DGRAD_IMPLICIT = os.environ.get("TSASR_CONV_DGRAD", "1") != "0"      # ... and its data gradient as one gathered GEMM (0: dy . Wm + col2im, the A/B path)
+_CONV_DGRAD_PLANS = {}
+
+
+def _conv_dgrad_plan(B, T, Fq, causal, device):
+    """Device copy of tsasr_conv3x3s2_dgrad's plan for this shape (host-side function of (B, T, F, causal); built and uploaded on first use - the
+    eager warm-up steps - so that a captured step only sees the device pointer). None: a shape the plan does not cover (T or F below 4)."""
+    key = (B, T, Fq, bool(causal), str(device))
+    if key not in _CONV_DGRAD_PLANS:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("front-end data-gradient plan requested for a new shape during graph capture: run one eager step of this shape first")
+        n = C.lib().tsasr_conv3x3s2_dgrad_plan_bytes(B, T, Fq, int(causal))
+        if n == 0:      # (an index with more than four contributions: does not occur for T, F >= 2; the HIP GEMM + col2im path takes it)
+            _CONV_DGRAD_PLANS[key] = None
+        else:
+            host = torch.empty(n // 4, dtype=torch.int32)
+            C.check(C.lib().tsasr_conv3x3s2_dgrad_plan(B, T, Fq, int(causal), host.data_ptr(), n), "tsasr_conv3x3s2_dgrad_plan")
+            _CONV_DGRAD_PLANS[key] = host.to(device)
+    return _CONV_DGRAD_PLANS[key]
+
+
 def _pgrad_view(dwm, Co, Ci, dtype):
     """dWm [Co, (kt, kf, ci)] fp32 -> the reference's [Co, ci, kF, kT] filter gradient."""
     return dwm.view(Co, 3, 3, Ci).permute(0, 3, 2, 1).to(dtype)
@@ -1709,8 +1732,8 @@ def _pgrad_view2(dw2f, shape, dtype):
 
 class _FrontendConvFn(torch.autograd.Function):
     """A ConvBlock's two convolutions for C_in > 1 (SB/lobes/models/convolution.py:178-266): bf16, C_in in {64, 128}, C_out = 128 = implicit GEMMs
-    (csrc/gemm.hip conv_s2_*: the ring kernels' loader waves gather the 3x3 patch rows; forward and filter gradients; the data gradient is
-    dy . Wm + the inverse gather col2im). Other shapes / fp32: the tap gather (im2col, padding rule folded in) + the HIP GEMMs + col2im."""
+    (csrc/gemm.hip conv_s2_*: the ring kernels' loader waves gather the 3x3 patch rows; forward, filter gradients and - gathering dy rows
+    per class of input pixels - the data gradient). Other shapes / fp32: the tap gather (im2col, padding rule folded in) + the HIP GEMMs + col2im."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, causal):
@@ -1771,13 +1794,19 @@ class _FrontendConvFn(torch.autograd.Function):
             with prof.region("conv3x3s2_wgrad", 2.0 * P * Co * 10 * Ci):
                 C.check(C.lib().tsasr_conv3x3s2_wgrad(C.ptr(g1), C.ptr(g2), C.ptr(xc), C.ptr(dwm), C.ptr(dw2f), B, T, Fq, Ci, Co, int(causal),
                                                       C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_conv3x3s2_wgrad")
-            dA = gemm_bf16(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)                                         # g1 . wm
-            dR = gemm_bf16(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
             db1, db2 = _pgrad(ctx.biases[0], colsum(g1)), _pgrad(ctx.biases[1], colsum(g2))
             dx = torch.empty(B, T, Fq, Ci, dtype=xc.dtype, device=xc.device)
-            with prof.region("frontend_col2im"):
-                C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
-                        "tsasr_frontend_col2im")
+            plan = _conv_dgrad_plan(B, T, Fq, causal, xc.device) if CONV_DGRAD_IMPLICIT else None
+            if plan is not None:    # one gathered GEMM per class of input pixels: no [P, 9*Ci] gradient matrix, no inverse gather
+                with prof.region("conv3x3s2_dgrad", 2.0 * P * Co * 10 * Ci):
+                    C.check(C.lib().tsasr_conv3x3s2_dgrad(C.ptr(g1), C.ptr(g2), C.ptr(wm), C.ptr(w2m), C.ptr(dx), B, T, Fq, Ci, Co, int(causal),
+                                                          C.ptr(plan), plan.numel() * 4, C.stream_ptr()), "tsasr_conv3x3s2_dgrad")
+            else:
+                dA = gemm_bf16(g1, wm, P, 9 * Ci, Co, Co, 9 * Ci, 0, 1)                                         # g1 . wm
+                dR = gemm_bf16(g2, w2m, P, Ci, Co, Co, Ci, 0, 1)
+                with prof.region("frontend_col2im"):
+                    C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
+                            "tsasr_frontend_col2im")
             return dx, _pgrad_view(dwm, Co, Ci, dw1t), db1, _pgrad_view2(dw2f, w2shape, dw2t), db2, None
         if hip:
             dwm = gemm_bf16(g1, A, Co, 9 * Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32)              # g1^T . A
