@@ -375,6 +375,349 @@ __global__ __launch_bounds__(FB_THREADS) void fe_block_bwd_kernel(const FeBlockA
     }
 }
 
+// =====================================================================================================================
+// Block 1 (C_in = 1) in bf16 with the two convolutions on the matrix cores (round 5). The kernels above spend most of their vector
+// instructions on the 9 + 1 taps (per wave and row: 108 fused multiply-adds + 66 v_readlane forward; 256 + 130 backward, where the filter
+// gradients are the same products again) and on drop_hash's quarter-rate multiplies: 731 / 1010 instructions per wave and row, at one
+// wave-instruction per CU and cycle = the kernels' whole duration (profiles/r05_notes.md). Here
+//   * the taps of a row are staged once in LDS, as P[position][slot] and T[slot][position] (slot k = kf*3 + kt as the filter is stored,
+//     slot 9 = 1 at real positions: the bias), by 432 threads that own one (slot, position) each for the whole kernel;
+//   * y and r are three v_mfma_f32_16x16x32_bf16 each per wave and row: K = 32 holds the 10 slots twice, against the bf16 high and low
+//     parts of the fp32 filters (w = hi + lo to 2^-17), so the result is the fp32 convolution of the bf16 features to ~1e-5;
+//   * wave w owns channels 16w .. 16w+15 at all positions. Forward: D^T = W^T . P^T, a lane holds 4 consecutive channels of one position
+//     (8-byte stores, float4 parameters). Backward: D = P . W, a lane holds one channel at 4 consecutive positions - exactly the B
+//     operand of the filter-gradient MFMA D[slot][c] += sum_p T[slot][p] . dy[p][c] (positions on K), whose accumulators stay in
+//     registers for the whole kernel: no cross-wave fold, no tap broadcasts;
+//   * LayerNorm statistics in one pass (sum and sum of squares of the fp32 accumulators; padded positions are exact zeros), one workgroup
+//     reduction and one barrier per row, which also publishes the next row's taps (double-buffered);
+//   * dropout words from the per-row stream of csrc/attn_common.h's form (one strong hash per row on the scalar unit, one full-rate 24-bit
+//     multiply per pair of channels): word(pair) = mix24(drop_hash(row, key) + pair_index * 0x9E3779B9).
+// =====================================================================================================================
+constexpr int F1_PP = 48;                        // padded positions: up to 3 blocks of 16
+constexpr int F1_PBYTES = F1_PP * 16 * 2;        // P[48][16] bf16
+constexpr int F1_TBYTES = 16 * F1_PP * 2;        // T[16][48] bf16
+constexpr int F1_LDS = 2 * (F1_PBYTES + F1_TBYTES) + 2 * FB_WAVES * 4 * 4;
+
+__device__ __forceinline__ unsigned fe1_word(unsigned row_key, unsigned cidx) {
+    unsigned y = row_key + cidx;
+    y ^= y >> 15;
+    y = __umul24(y, 0x1b3c6du);
+    y ^= y >> 16;
+    return y;
+}
+// filters of this lane as MFMA operand: lane (channel 16*wave + (lane & 15), k-group g = lane >> 4) holds slots 8(g&1) .. +7; g < 2 the bf16
+// high parts, g >= 2 the low parts
+__device__ __forceinline__ void fe1_filters(const FeBlockArgs &A, int wave, int lane, int centre, bf16x8 &wy, bf16x8 &wr) {
+    const int c = 16 * wave + (lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int slot = 8 * (g & 1) + e;
+        const float v = slot < 9 ? A.w1[c * 9 + slot] : (slot == 9 ? A.b1[c] : 0.f);
+        const float vr = slot == centre ? A.w2[c] : (slot == 9 ? A.b2[c] : 0.f);
+        const bf16_t vh = (bf16_t)v, vrh = (bf16_t)vr;
+        wy[e] = g < 2 ? vh : (bf16_t)(v - (float)vh);
+        wr[e] = g < 2 ? vrh : (bf16_t)(vr - (float)vrh);
+    }
+}
+// the staging threads' life: thread tid < 9 * 48 owns (slot k, position p); value of row (b, to) = the padded source sample (raw bf16 bits)
+struct Fe1Stage {
+    int k, p, fi, kt;
+    bool on;
+    __device__ __forceinline__ void init(const FeBlockArgs &A) {
+        const int t = threadIdx.x;
+        on = t < 9 * F1_PP;
+        k = on ? t / F1_PP : 0;
+        p = t - k * F1_PP;
+        const int kf = k / 3;
+        kt = k - kf * 3;
+        fi = (on && p < A.Fo) ? fb_src_index(p, kf, A.F, A.fmode) : -1;
+    }
+    __device__ __forceinline__ unsigned short load(const FeBlockArgs &A, int b, int to) const {
+        const int ti = fb_src_index(to, kt, A.Tn, A.tmode);
+        const unsigned short raw = *(reinterpret_cast<const unsigned short *>(A.x) + ((size_t)b * A.Tn + max(ti, 0)) * A.F + max(fi, 0));   // always issued
+        return (ti >= 0 && fi >= 0) ? raw : (unsigned short)0;
+    }
+    __device__ __forceinline__ void store(char *pbuf, char *tbuf, unsigned short v) const {
+        if (on) {
+            *reinterpret_cast<unsigned short *>(pbuf + (p * 16 + k) * 2) = v;
+            *reinterpret_cast<unsigned short *>(tbuf + (k * F1_PP + p) * 2) = v;
+        }
+    }
+};
+__device__ __forceinline__ void fe1_lds_init(char *lds, int Fo) {      // zeros everywhere, 1.0 in slot 9 of the real positions (both buffers)
+    for (int i = threadIdx.x; i < 2 * (F1_PBYTES + F1_TBYTES) / 4; i += FB_THREADS) reinterpret_cast<unsigned *>(lds)[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x < 2 * F1_PP) {
+        const int buf = threadIdx.x / F1_PP, p = threadIdx.x - buf * F1_PP;
+        if (p < Fo) {
+            *reinterpret_cast<unsigned short *>(lds + buf * F1_PBYTES + (p * 16 + 9) * 2) = 0x3F80;
+            *reinterpret_cast<unsigned short *>(lds + 2 * F1_PBYTES + buf * F1_TBYTES + (9 * F1_PP + p) * 2) = 0x3F80;
+        }
+    }
+}
+
+template <int NPB>
+__global__ __launch_bounds__(FB_THREADS, 4) void fe_block1_fwd_mfma_kernel(const FeBlockArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char f1_lds[];
+    char *Pb = f1_lds, *Tb = f1_lds + 2 * F1_PBYTES;
+    float *red = reinterpret_cast<float *>(f1_lds + 2 * (F1_PBYTES + F1_TBYTES));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    const int Fo = A.Fo, N = Fo * FB_C;
+    const float inv_n = 1.f / (float)N;
+    bf16x8 wy, wr;
+    fe1_filters(A, wave, lane, A.tmode == 1 ? 5 : 4, wy, wr);
+    int off[NPB];
+    bool ok[NPB];
+    f32x4 g1[NPB], be1[NPB], g2[NPB], be2[NPB];
+    const unsigned cidx0 = (unsigned)((pl * FB_C + 16 * wave + 4 * g) >> 1) * 0x9E3779B9u;      // pair index of (position pl, first channel) times the stream's stride
+#pragma unroll
+    for (int t = 0; t < NPB; ++t) {
+        const int p = 16 * t + pl;
+        ok[t] = p < Fo;
+        off[t] = min(p, Fo - 1) * FB_C + 16 * wave + 4 * g;
+        g1[t] = *reinterpret_cast<const f32x4 *>(A.g1 + off[t]);
+        be1[t] = *reinterpret_cast<const f32x4 *>(A.be1 + off[t]);
+        g2[t] = *reinterpret_cast<const f32x4 *>(A.g2 + off[t]);
+        be2[t] = *reinterpret_cast<const f32x4 *>(A.be2 + off[t]);
+    }
+    const unsigned long long sd = A.seed_dev ? *A.seed_dev : 0ull;
+    const unsigned thr1 = drop_thr16(A.p1), thr2 = drop_thr16(A.p2), thr1s = thr1 << 16, thr2s = thr2 << 16;
+    const DropKey k1 = drop_key(A.seed1 + sd), k2 = drop_key(A.seed2 + sd);
+    const float ks1 = drop_scale16(thr1), ks2 = drop_scale16(thr2);
+    Fe1Stage stg;
+    stg.init(A);
+    fe1_lds_init(f1_lds, Fo);
+    int b = (int)(blockIdx.x / (unsigned)A.To), to = (int)(blockIdx.x % (unsigned)A.To);
+    const int stride_b = (int)(gridDim.x / (unsigned)A.To), stride_t = (int)(gridDim.x % (unsigned)A.To);
+    __syncthreads();
+    if ((long long)blockIdx.x < A.R) stg.store(Pb, Tb, stg.load(A, b, to));
+    __syncthreads();
+    int par = 0;
+    for (long long row = blockIdx.x; row < A.R; row += gridDim.x, par ^= 1) {
+        to += stride_t; b += stride_b;
+        if (to >= A.To) { to -= A.To; ++b; }
+        const bool more = row + gridDim.x < A.R;
+        unsigned short nxt = 0;
+        if (more) nxt = stg.load(A, b, to);                  // the next row's tap of this thread: in flight under the MFMAs and the statistics
+        const char *P = Pb + par * F1_PBYTES;
+        f32x4 y[NPB], r[NPB];
+#pragma unroll
+        for (int t = 0; t < NPB; ++t) {
+            const bf16x8 taps = *reinterpret_cast<const bf16x8 *>(P + (16 * t + pl) * 32 + (g & 1) * 16);
+            y[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wy, taps, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            r[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, taps, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        float s[4] = {0.f, 0.f, 0.f, 0.f};      // padded positions: all slots zero -> y = r = 0 exactly, nothing to mask
+#pragma unroll
+        for (int t = 0; t < NPB; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0] += y[t][j]; s[1] += r[t][j];
+                s[2] = __builtin_fmaf(y[t][j], y[t][j], s[2]); s[3] = __builtin_fmaf(r[t][j], r[t][j], s[3]);
+            }
+        if (more) stg.store(Pb + (par ^ 1) * F1_PBYTES, Tb + (par ^ 1) * F1_TBYTES, nxt);      // read last in the previous row, before its barrier
+        fb_wg_sum<4>(s, red + par * FB_WAVES * 4, wave, lane);
+        const float mu_y = s[0] * inv_n, mu_r = s[1] * inv_n;
+        const float rs_y = rsqrtf(fmaxf(s[2] * inv_n - mu_y * mu_y, 0.f) + A.eps), rs_r = rsqrtf(fmaxf(s[3] * inv_n - mu_r * mu_r, 0.f) + A.eps);
+        if (threadIdx.x == 0) *reinterpret_cast<float4 *>(A.stats + row * 4) = make_float4(mu_y, rs_y, mu_r, rs_r);
+        const float cy = -mu_y * rs_y, cr = -mu_r * rs_r;
+        const unsigned rk1 = drop_hash((unsigned long long)row, k1) + cidx0, rk2 = drop_hash((unsigned long long)row, k2) + cidx0;
+        bf16_t *outr = (bf16_t *)A.out + row * N;
+#pragma unroll
+        for (int t = 0; t < NPB; ++t) {
+            float o[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                // (p = 0: thr = 0, every comparison holds and ks = 1 - no branch on the rate)
+                const unsigned cth = (unsigned)(16 * t * (FB_C / 2) + h2) * 0x9E3779B9u;
+                const unsigned wa = fe1_word(rk1, cth), wb = fe1_word(rk2, cth);
+                const float m1[2] = {(wa << 16) >= thr1s ? ks1 : 0.f, wa >= thr1s ? ks1 : 0.f};
+                const float m2[2] = {(wb << 16) >= thr2s ? ks2 : 0.f, wb >= thr2s ? ks2 : 0.f};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * h2 + e;
+                    const float hy = __builtin_fmaf(y[t][j], rs_y, cy);
+                    const float z = __builtin_fmaf(hy, g1[t][j], be1[t][j]);
+                    const float act = fmaxf(z, z * A.slope);
+                    const float hr = __builtin_fmaf(r[t][j], rs_r, cr);
+                    const float rn = __builtin_fmaf(hr, g2[t][j], be2[t][j]);
+                    o[j] = __builtin_fmaf(act, m1[e], rn) * m2[e];
+                }
+            }
+            if (ok[t]) {
+                bf16x4 ob;
+                ob[0] = (bf16_t)o[0]; ob[1] = (bf16_t)o[1]; ob[2] = (bf16_t)o[2]; ob[3] = (bf16_t)o[3];
+                *reinterpret_cast<bf16x4 *>(outr + off[t]) = ob;
+            }
+        }
+    }
+}
+
+template <int NPB>
+__global__ __launch_bounds__(FB_THREADS) void fe_block1_bwd_mfma_kernel(const FeBlockArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char f1_lds[];
+    char *Pb = f1_lds, *Tb = f1_lds + 2 * F1_PBYTES;
+    float *red = reinterpret_cast<float *>(f1_lds + 2 * (F1_PBYTES + F1_TBYTES));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    const int Fo = A.Fo, N = Fo * FB_C, c = 16 * wave + pl, centre = A.tmode == 1 ? 5 : 4;
+    const float inv_n = 1.f / (float)N;
+    bf16x8 wy, wr;
+    fe1_filters(A, wave, lane, centre, wy, wr);
+    // this lane: channel c at positions 16t + 4g + j
+    int off[NPB];                        // element offset of (position 16t + 4g, c), clamped to the last real position
+    float okf[4];                        // 1 / 0: position 16(NPB-1) + 4g + j is real
+    float g1[NPB][4], be1[NPB][4], g2[NPB][4];
+    float ag1[NPB][4], abe1[NPB][4], ag2[NPB][4], abe2[NPB][4];
+    const unsigned cidx0 = (unsigned)((4 * g * FB_C + c) >> 1) * 0x9E3779B9u;      // pair index of (position 4g, c) times the stream's stride
+#pragma unroll
+    for (int t = 0; t < NPB; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = min(16 * t + 4 * g + j, Fo - 1), e = p * FB_C + c;
+            if (j == 0) off[t] = e;
+            g1[t][j] = A.g1[e]; be1[t][j] = A.be1[e]; g2[t][j] = A.g2[e];
+            ag1[t][j] = abe1[t][j] = ag2[t][j] = abe2[t][j] = 0.f;
+            if (t == NPB - 1) okf[j] = (16 * t + 4 * g + j) < Fo ? 1.f : 0.f;
+        }
+    }
+    const int sh = (lane & 1) ? 0 : 16;          // even channel: low half of the pair's word
+    f32x4 dwy = {0.f, 0.f, 0.f, 0.f}, dwr = {0.f, 0.f, 0.f, 0.f};      // D[slot 4g + j][c]
+    const unsigned long long sd = A.seed_dev ? *A.seed_dev : 0ull;
+    const unsigned thr1 = drop_thr16(A.p1), thr2 = drop_thr16(A.p2), thr1s = thr1 << 16, thr2s = thr2 << 16;
+    const DropKey k1 = drop_key(A.seed1 + sd), k2 = drop_key(A.seed2 + sd);
+    const float ks1 = drop_scale16(thr1), ks2 = drop_scale16(thr2);
+    Fe1Stage stg;
+    stg.init(A);
+    fe1_lds_init(f1_lds, Fo);
+    int b = (int)(blockIdx.x / (unsigned)A.To), to = (int)(blockIdx.x % (unsigned)A.To);
+    const int stride_b = (int)(gridDim.x / (unsigned)A.To), stride_t = (int)(gridDim.x % (unsigned)A.To);
+    __syncthreads();
+    if ((long long)blockIdx.x < A.R) stg.store(Pb, Tb, stg.load(A, b, to));
+    __syncthreads();
+    int par = 0;
+    for (long long row = blockIdx.x; row < A.R; row += gridDim.x, par ^= 1) {
+        to += stride_t; b += stride_b;
+        if (to >= A.To) { to -= A.To; ++b; }
+        const bool more = row + gridDim.x < A.R;
+        unsigned short nxt = 0;
+        if (more) nxt = stg.load(A, b, to);
+        const unsigned short *dor = reinterpret_cast<const unsigned short *>(A.dout) + row * N;
+        const float4 st = *reinterpret_cast<const float4 *>(A.stats + row * 4);
+        const float rs_y = st.y, rs_r = st.w, cy = -st.x * st.y, cr = -st.z * st.w;
+        float d[NPB][4];
+#pragma unroll
+        for (int t = 0; t < NPB; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = min(16 * t + 4 * g + j, Fo - 1);
+                d[t][j] = __uint_as_float((unsigned)dor[p * FB_C + c] << 16);
+            }
+        const char *P = Pb + par * F1_PBYTES, *T = Tb + par * F1_TBYTES;
+        f32x4 y[NPB], r[NPB];
+#pragma unroll
+        for (int t = 0; t < NPB; ++t) {
+            const bf16x8 taps = *reinterpret_cast<const bf16x8 *>(P + (16 * t + pl) * 32 + (g & 1) * 16);
+            y[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(taps, wy, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            r[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(taps, wr, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        // taps^T as the filter-gradient A operand: lane (slot pl, group g), k = 8g + e <-> position 4g + e (e < 4) of block 0 / 16 + 4g + e - 4 of block 1
+        bf16x8 ta, tb;
+        {
+            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(T + (pl * F1_PP + 4 * g) * 2);
+            bf16x4 hi = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (NPB > 1) hi = *reinterpret_cast<const bf16x4 *>(T + (pl * F1_PP + 16 + 4 * g) * 2);
+            ta = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16x4 l2 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (NPB > 2) l2 = *reinterpret_cast<const bf16x4 *>(T + (pl * F1_PP + 32 + 4 * g) * 2);
+            tb = (bf16x8){l2[0], l2[1], l2[2], l2[3], (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
+        const unsigned rb1 = drop_hash((unsigned long long)row, k1) + cidx0, rb2 = drop_hash((unsigned long long)row, k2) + cidx0;
+        float hy[NPB][4], hr[NPB][4], gy[NPB][4], gr[NPB][4];
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NPB; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                constexpr unsigned step = 64u * 0x9E3779B9u;      // the pair index grows by FB_C / 2 per position
+                const unsigned cij = (unsigned)(16 * t + j) * step;
+                const float m1 = (fe1_word(rb1, cij) << sh) >= thr1s ? ks1 : 0.f;
+                const float m2 = (fe1_word(rb2, cij) << sh) >= thr2s ? ks2 : 0.f;
+                float ds = d[t][j] * m2;
+                if (t == NPB - 1) ds *= okf[j];
+                const float h = __builtin_fmaf(y[t][j], rs_y, cy);
+                const float z = __builtin_fmaf(h, g1[t][j], be1[t][j]);
+                const float da = ds * m1;
+                const float dz = z > 0.f ? da : da * A.slope;
+                hy[t][j] = h;
+                ag1[t][j] = __builtin_fmaf(dz, h, ag1[t][j]);
+                abe1[t][j] += dz;
+                const float gyv = dz * g1[t][j];
+                gy[t][j] = gyv;
+                s[0] += gyv; s[1] = __builtin_fmaf(gyv, h, s[1]);
+                const float hrv = __builtin_fmaf(r[t][j], rs_r, cr);
+                hr[t][j] = hrv;
+                ag2[t][j] = __builtin_fmaf(ds, hrv, ag2[t][j]);
+                abe2[t][j] += ds;
+                const float grv = ds * g2[t][j];
+                gr[t][j] = grv;
+                s[2] += grv; s[3] = __builtin_fmaf(grv, hrv, s[3]);
+            }
+        if (more) stg.store(Pb + (par ^ 1) * F1_PBYTES, Tb + (par ^ 1) * F1_TBYTES, nxt);
+        fb_wg_sum<4>(s, red + par * FB_WAVES * 4, wave, lane);
+        const float m1y = s[0] * inv_n, m2y = s[1] * inv_n, m1r = s[2] * inv_n, m2r = s[3] * inv_n;
+        float dyv[NPB][4], drv[NPB][4];
+#pragma unroll
+        for (int t = 0; t < NPB; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dyv[t][j] = rs_y * (gy[t][j] - m1y - hy[t][j] * m2y);
+                drv[t][j] = rs_r * (gr[t][j] - m1r - hr[t][j] * m2r);
+                if (t == NPB - 1) { dyv[t][j] *= okf[j]; drv[t][j] *= okf[j]; }      // (a padded position: gy = 0 but -m1y is not)
+            }
+        const bf16_t z0 = (bf16_t)0.f;
+        bf16x8 by, br;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            by[j] = (bf16_t)dyv[0][j]; br[j] = (bf16_t)drv[0][j];
+            by[4 + j] = NPB > 1 ? (bf16_t)dyv[NPB > 1 ? 1 : 0][j] : z0;
+            br[4 + j] = NPB > 1 ? (bf16_t)drv[NPB > 1 ? 1 : 0][j] : z0;
+        }
+        dwy = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, by, dwy, 0, 0, 0);
+        dwr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, br, dwr, 0, 0, 0);
+        if (NPB > 2) {
+            bf16x8 by2, br2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                by2[j] = (bf16_t)dyv[NPB > 2 ? 2 : 0][j]; br2[j] = (bf16_t)drv[NPB > 2 ? 2 : 0][j];
+                by2[4 + j] = z0; br2[4 + j] = z0;
+            }
+            dwy = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tb, by2, dwy, 0, 0, 0);
+            dwr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tb, br2, dwr, 0, 0, 0);
+        }
+    }
+    // partial parameter gradients of this workgroup: [dw1 C*9 | db1 C | dw2 C | db2 C] then [dg1 | dbe1 | dg2 | dbe2]
+    const int conv_w = FB_C * 12;
+    float *mine = A.slab + (size_t)blockIdx.x * (conv_w + 4 * N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = 4 * g + j;
+        if (slot < 9) mine[c * 9 + slot] = dwy[j];
+        if (slot == 9) { mine[FB_C * 9 + c] = dwy[j]; mine[FB_C * 11 + c] = dwr[j]; }
+        if (slot == centre) mine[FB_C * 10 + c] = dwr[j];
+    }
+#pragma unroll
+    for (int t = 0; t < NPB; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (16 * t + 4 * g + j >= Fo) continue;
+            const int e = off[t] + j * FB_C;
+            mine[conv_w + e] = ag1[t][j];
+            mine[conv_w + N + e] = abe1[t][j];
+            mine[conv_w + 2 * N + e] = ag2[t][j];
+            mine[conv_w + 3 * N + e] = abe2[t][j];
+        }
+}
+
 int fb_out_len(int n) { return (n - 1) / 2 + 1; }
 int fb_np(int Fo) { return (Fo + FB_WAVES - 1) / FB_WAVES; }
 unsigned fb_grid(long long R, int per_cu) {
@@ -396,6 +739,29 @@ unsigned fb_resident_grid(K kern, long long R, size_t lds) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FB_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     return fb_grid(R, per_cu > 2 ? 2 : per_cu);
 }
+
+// block 1 in bf16 on the matrix-core kernels (TSASR_FE_MFMA=0: the vector kernels above, for A/B runs)
+bool fe1_enabled() {
+    static const bool on = [] { const char *e = getenv("TSASR_FE_MFMA"); return !e || e[0] != '0'; }();
+    return on;
+}
+bool fe1_takes(bool conv, int io_dtype, int Fo) { return conv && io_dtype == TSASR_BF16 && Fo <= F1_PP && fe1_enabled(); }
+void fe1_launch_fwd(int Fo, hipStream_t st, const FeBlockArgs &a) {
+#define F1_FWD(NPBV)                                                                   \
+    {                                                                                  \
+        auto kern = fe_block1_fwd_mfma_kernel<NPBV>;                                   \
+        static const unsigned grid_full = fb_resident_grid(kern, 1ll << 40, F1_LDS);   \
+        kern<<<(unsigned)(a.R < grid_full ? a.R : grid_full), FB_THREADS, F1_LDS, st>>>(a); \
+    }
+    if (Fo <= 16) F1_FWD(1) else if (Fo <= 32) F1_FWD(2) else F1_FWD(3)
+#undef F1_FWD
+}
+void fe1_launch_bwd(int Fo, unsigned grid, hipStream_t st, const FeBlockArgs &a) {
+    if (Fo <= 16) fe_block1_bwd_mfma_kernel<1><<<grid, FB_THREADS, F1_LDS, st>>>(a);
+    else if (Fo <= 32) fe_block1_bwd_mfma_kernel<2><<<grid, FB_THREADS, F1_LDS, st>>>(a);
+    else fe_block1_bwd_mfma_kernel<3><<<grid, FB_THREADS, F1_LDS, st>>>(a);
+}
+
 template <typename T, bool CONV>
 void fb_launch_fwd(int np, bool full, hipStream_t st, const FeBlockArgs &a) {
 #define FB_FWD(NPV, FULLV)                                                            \
@@ -466,7 +832,8 @@ int tsasr_frontend_block_fwd(const void *x, const void *y1, const void *y2, cons
     hipStream_t st = (hipStream_t)stream;
     const int np = fb_np(Fo);
     const bool full = Fo == np * FB_WAVES;
-    if (io_dtype == TSASR_BF16) { if (conv) fb_launch_fwd<bf16_t, true>(np, full, st, a); else fb_launch_fwd<bf16_t, false>(np, full, st, a); }
+    if (fe1_takes(conv, io_dtype, Fo)) fe1_launch_fwd(Fo, st, a);
+    else if (io_dtype == TSASR_BF16) { if (conv) fb_launch_fwd<bf16_t, true>(np, full, st, a); else fb_launch_fwd<bf16_t, false>(np, full, st, a); }
     else if (io_dtype == TSASR_F32) { if (conv) fb_launch_fwd<float, true>(np, full, st, a); else fb_launch_fwd<float, false>(np, full, st, a); }
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     TSASR_CHECK_LAUNCH("tsasr_frontend_block_fwd");
@@ -506,7 +873,8 @@ int tsasr_frontend_block_bwd(const void *x, const void *y1, const void *y2, cons
     hipStream_t st = (hipStream_t)stream;
     const int np = fb_np(Fo);
     const bool full = Fo == np * FB_WAVES;
-    if (io_dtype == TSASR_BF16) { if (conv) fb_launch_bwd<bf16_t, true>(np, full, grid, st, a); else fb_launch_bwd<bf16_t, false>(np, full, grid, st, a); }
+    if (fe1_takes(conv, io_dtype, Fo)) fe1_launch_bwd(Fo, grid, st, a);
+    else if (io_dtype == TSASR_BF16) { if (conv) fb_launch_bwd<bf16_t, true>(np, full, grid, st, a); else fb_launch_bwd<bf16_t, false>(np, full, grid, st, a); }
     else if (io_dtype == TSASR_F32) { if (conv) fb_launch_bwd<float, true>(np, full, grid, st, a); else fb_launch_bwd<float, false>(np, full, grid, st, a); }
     else TSASR_CHECK_ARG(false, "bad io_dtype %d", io_dtype);
     const int width = (int)tsasr_frontend_block_dparams(Fo, C, conv);
