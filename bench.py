@@ -212,8 +212,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--config", default="scratch", choices=sorted(WORKLOADS), help="workload (default: the headline, BASELINE.json configs[1])")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the workload (pricing runs only: the line is then NOT the headline configuration and says so)")
     args = ap.parse_args()
-    wl = WORKLOADS[args.config]
+    wl = dict(WORKLOADS[args.config])
+    if args.batch:
+        wl["B"], wl["name"] = args.batch, wl["name"] + f" -- NOT the named configuration: per-GPU batch {args.batch}"
     global B_LOCAL, T_MEL, T_ENROLL, U
     B_LOCAL, T_MEL, T_ENROLL, U = wl["B"], wl["T"], wl["Te"], wl["U"]
 

@@ -132,8 +132,10 @@ def test_training_gradients_vs_oracle(dtype):
                 worst = (f"{mn}.{k}", rel)
             # the positional path (pos_bias_u / pos_bias_v / linear_pos) sums strongly cancelling terms over every (b, i, j): its gradients'
             # norms are small against the per-term bf16 rounding of dS, so their relative error is the largest of all parameters
-            # (measured: 6.9e-2 / 6.4e-2 in bf16; every other parameter < 4e-2. fp32 mode: no extra allowance - 2.1e-5 is the worst of all)
-            lim = 2.5 * budget if (dtype == "bf16" and ("pos_bias" in k or "linear_pos" in k)) else budget
+            # (round 5, measured: linear_pos.weight 7.0e-2 the worst, every other parameter < 6e-2: the query-major backward still hands dS to the
+            # key-major / d(pk) passes in bf16 - the one-kernel backward that would keep it in fp32 was slower (csrc/lab/attention_fused.hip) - so
+            # 8e-2 here instead of round 4's 1.5e-1. fp32 mode: no extra allowance - 2.4e-5 is the worst of all)
+            lim = 8e-2 if (dtype == "bf16" and ("pos_bias" in k or "linear_pos" in k)) else budget
             if rel >= lim:
                 bad.append((mn, k, rel))
             n += 1
@@ -276,7 +278,7 @@ def test_pretrained_variant_training_step_vs_oracle(dtype):
                 ref = sd[f"{mn}.{k}"].grad
                 rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
                 worst = max(worst, rel)
-                lim = 2e-4 if dtype == "fp32" else (1.5e-1 if ("pos_bias" in k or "linear_pos" in k) else 6e-2)   # fp32 mode: measured worst 9.9e-6
+                lim = 2e-4 if dtype == "fp32" else 6e-2   # every parameter, the positional ones included (bf16: measured worst 5.6e-2; fp32: 1.3e-5)
                 assert rel < lim, (mn, k, rel)
     print(dtype, "pretrained variant: worst relative L2 gradient error", worst)
     w0 = brain.modules.speaker_proj.w.weight.detach().clone()
@@ -329,12 +331,15 @@ def test_none_variant_training_steps_and_graph_replay():
     loss_o = RR.transducer_loss_ref_torch(logits_o, T(inp["tokens"]), T(inp["mixed_lens"]), T(inp["tokens_lens"]), 0, "mean")
     loss_o.backward()
     assert float(loss) == pytest.approx(float(loss_o), rel=3e-2)
+    worst_none = 0.0
     for mn, mod in brain.modules.items():
         for k, p in mod.named_parameters():
             if p.requires_grad:
                 ref = sd[f"{mn}.{k}"].grad
                 rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
-                assert rel < (1.5e-1 if ("pos_bias" in k or "linear_pos" in k) else 6e-2), (mn, k, rel)
+                worst_none = max(worst_none, rel)
+                assert rel < 6e-2, (mn, k, rel)      # every parameter, the positional ones included (measured worst 5.5e-2)
+    print("bf16 none variant: worst relative L2 gradient error", worst_none)
     losses = {}
     for mode in ("eager", "graph"):
         b2, _ = none_brain("bf16")
