@@ -1368,12 +1368,20 @@ extern "C" size_t tsasr_relpos_attn_lds_bytes(void);
 extern "C" int tsasr_attn_short_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, void *out,
                                     float *lse, int B, int T, int H, float scale, int causal, float pdrop, unsigned long long seed,
                                     const unsigned long long *seed_dev, void *keepbits, hipStream_t st);
+extern "C" int tsasr_attn_chunk_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, int B, int T, int H,
+                                    float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, int nparts,
+                                    float *part_o, float *part_ml, hipStream_t st);
 extern "C" int tsasr_attn_short_bwd_q(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *out,
                                       const void *dout, const float *lse, void *dqkv, void *pd, void *ds, float *slab, int Tp, int B, int T, int H,
                                       float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev,
                                       const void *keepbits, hipStream_t st);
 extern "C" int tsasr_attn_short_bwd_kv(const void *qkv, const float *bias_u, const float *bias_v, const int32_t *key_lens, const void *dout, const void *pd,
                                        const void *ds, void *dqkv, void *qv_out, int B, int T, int Tp, int H, int causal, hipStream_t st);
+constexpr int AT_CHUNK_KEYS = 256;
+static bool attn_chunk_enabled() {      // TSASR_ATTN_CHUNK=0: the streaming forward for long sequences (A/B runs)
+    static const bool on = [] { const char *e = getenv("TSASR_ATTN_CHUNK"); return !e || e[0] != '0'; }();
+    return on;
+}
 static int attn_short_version() {   // TSASR_ATTN_SHORT = 1: round 3's short-sequence forward (A/B); default 2
     static const int v = [] { const char *e = getenv("TSASR_ATTN_SHORT"); return e ? atoi(e) : 2; }();
     return v;
@@ -1522,7 +1530,7 @@ size_t tsasr_relpos_attn_lds_bytes(void) {
 
 size_t tsasr_relpos_attn_fwd_workspace_bytes(int B, int T, int H) {   // sized for the finest split any mask may choose
     int pk = 0;
-    const int np = std::max(attn_key_parts(B, T, H, 0, &pk), attn_key_parts(B, T, H, 1, &pk)) > 1 ? attn_max_parts(T) : 1;
+    const int np = std::max(attn_key_parts(B, T, H, 0, &pk), attn_key_parts(B, T, H, 1, &pk)) > 1 ? std::max(attn_max_parts(T), cdiv(T, AT_CHUNK_KEYS)) : 1;
     return np > 1 ? align_up((size_t)B * H * T * np * (AT_DP + 2) * sizeof(float), 256) : 0;
 }
 
@@ -1573,6 +1581,17 @@ int tsasr_relpos_attn_fwd_ws(const void *qkv, const void *pk, const float *bias_
     int part_keys = 0;
     int nparts = workspace ? attn_key_parts(B, T, H, causal, &part_keys) : 1;
     if (nparts > 1 && workspace_bytes < tsasr_relpos_attn_fwd_workspace_bytes(B, T, H)) nparts = 1;
+    if (nparts > 1 && io_dtype == TSASR_BF16 && Dh == 64 && cdiv(T, AT_CHUNK_KEYS) <= 64 && attn_chunk_enabled()) {
+        // long sequence in a small batch: the everything-in-LDS kernel of the short sequences, one workgroup per chunk of 256 keys
+        // (csrc/attention_short.hip), merged like the streaming kernel's key parts
+        const int np = cdiv(T, AT_CHUNK_KEYS);
+        float *po = (float *)workspace, *pml = po + (size_t)B * H * T * np * AT_DP;
+        tsasr_attn_chunk_fwd(qkv, pk, bias_u, bias_v, key_lens, B, T, H, scale, causal, pdrop, seed, seed_dev, np, po, pml, st);
+        relpos_attn_merge_kernel<bf16_t><<<(unsigned)(((long long)B * H * T * 16 + 255) / 256), 256, 0, st>>>(po, pml, key_lens, (bf16_t *)out, lse, B, T, H, Dh, causal, np,
+                                                                                                               AT_CHUNK_KEYS);
+        TSASR_CHECK_LAUNCH("tsasr_relpos_attn_fwd");
+        return 0;
+    }
     float *part_o = (float *)workspace, *part_ml = nparts > 1 ? part_o + (size_t)B * H * T * nparts * AT_DP : nullptr;
     if (nparts > 1) grid.x *= nparts;
     const unsigned mgrid = (unsigned)(((long long)B * H * T * 16 + 255) / 256);

@@ -18,6 +18,7 @@
 //         to the bf16 PAIR after the conversion (one AND per two elements); 1 / (1 - p) is folded into the final 1 / l;
 //       - P.V of a step runs at the head of the NEXT step, behind that step's AC / G MFMAs (its V block arrives with that group).
 //   * the dropout keep-bits the backward reads (tsasr_relpos_attn_keepbits) leave as ONE 8-byte store per lane.
+#include <algorithm>
 #include <type_traits>
 
 #include "attn_common.h"
@@ -28,15 +29,28 @@
 // 256, two parts of 128), 2 x 4 for QH = 64 (keys padded to 128, four parts of 32); a lane owns ONE query (accumulators: rows = keys /
 // band rows / head dims, column = query), the key parts of a query block are merged through LDS at the end.
 // =====================================================================================================================
-template <int QH>
-__global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
-                                                                        const float *__restrict__ bias_u, const float *__restrict__ bias_v,
-                                                                        const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
-                                                                        float *__restrict__ lse, int Tn, int H, float scale, int causal,
-                                                                        float pdrop, unsigned long long seed,
-                                                                        const unsigned long long *__restrict__ seed_dev,
-                                                                        unsigned short *__restrict__ keepbits /*[B*H*T][2][8] or NULL*/) {
+// CHUNK (QH = 128, T > 256: long sequences in small batches, BASELINE configs[4]'s T' = 4000): the same workgroup against ONE chunk of 256 keys
+// (keys j0 = 256 * part ..), one workgroup per (b, h, 128 queries, chunk that the tile's causal / length limit reaches); it leaves its
+// un-normalised (O, m, l) in part_o / part_ml exactly as relpos_attn_fwd_kernel's key parts do, and relpos_attn_merge_kernel combines the
+// chunks of a query. ~1100 live workgroups of equal size at T' = 4000 instead of 384 of very unequal size.
+// the live (query tile, chunk) pairs of one (b, h), chunk-major: chunk p is met by the query tiles first_qt[p] .. nqt - 1 (host-computed from
+// the look-ahead rule with every key present; shorter utterances make some of them return at once); passed to the kernel by value
+struct AttnChunkPlan {
+    int per_pair, nparts, base[65], first_qt[64];
+};
+
+template <int QH, bool CHUNK>
+__device__ __forceinline__ void relpos_attn_fwd_short2_item(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
+                                                            const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                            const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
+                                                            float *__restrict__ lse, int Tn, int H, float scale, int causal,
+                                                            float pdrop, unsigned long long seed,
+                                                            const unsigned long long *__restrict__ seed_dev,
+                                                            unsigned short *__restrict__ keepbits /*[B*H*T][2][8] or NULL*/,
+                                                            unsigned bid, unsigned nbid, const AttnChunkPlan *__restrict__ plan, float *__restrict__ part_o,
+                                                            float *__restrict__ part_ml) {
     constexpr int Dh = 64, NQB = QH / 32, NKP = 8 / NQB, TPAD = 2 * QH, KP = TPAD / NKP, NSUB = KP / 32, NB = QH + TPAD;
+    static_assert(!CHUNK || QH == 128, "chunks are 256 keys against 128 queries");
     constexpr int K_OFF = 0, V_OFF = TPAD * 128, P_OFF = 2 * TPAD * 128, G_OFF = P_OFF + NB * 128;
     constexpr int Q_OFF = G_OFF, UV_OFF = G_OFF + QH * 128;      // the query rows and the two bias rows live in the G scratch until they are read
     static_assert(QH * 128 + 512 <= 8 * 6144, "query staging fits the G scratch");
@@ -48,17 +62,23 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
     if (seed_dev) seed += *seed_dev;
     // blockIdx.x -> (query tile, (b, h)): the query tiles of one (b, h) get block ids 8 apart, i.e. the same XCD under round-robin
     // dispatch - they fetch the same K / V rows (speed only: any placement is correct)
-    const int nqt = (Tn + QH - 1) / QH, npair = gridDim.x / nqt;
-    int qt, pair;
-    if ((npair & 7) == 0) {
-        const int k = blockIdx.x >> 3;
+    const int nqt = (Tn + QH - 1) / QH, npair = nbid / nqt;
+    const int nparts = CHUNK ? plan->nparts : 1;
+    int qt, pair, part = 0;
+    if (CHUNK) {            // neighbouring items: the same chunk of keys against consecutive query tiles
+        pair = bid / plan->per_pair;
+        const int rem = bid - pair * plan->per_pair;
+        while (plan->base[part + 1] <= rem) ++part;
+        qt = plan->first_qt[part] + (rem - plan->base[part]);
+    } else if ((npair & 7) == 0) {
+        const int k = bid >> 3;
         qt = k % nqt;
-        pair = (k / nqt) * 8 + (blockIdx.x & 7);
+        pair = (k / nqt) * 8 + (bid & 7);
     } else {
-        qt = blockIdx.x % nqt;
-        pair = blockIdx.x / nqt;
+        qt = bid % nqt;
+        pair = bid / nqt;
     }
-    const int b = pair / H, h = pair % H, i0 = qt * QH;
+    const int b = pair / H, h = pair % H, i0 = qt * QH, j0 = CHUNK ? part * TPAD : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
     const int qb = wave % NQB, kp = wave / NQB;
     const int D = H * Dh;
@@ -66,8 +86,13 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
     const bf16_t *q_base = qkv + ((long long)b * Tn) * row_stride + (long long)h * 3 * Dh;
     const bf16_t *p_base = pk + (long long)h * Dh;
     const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    if (CHUNK) {            // a chunk beyond what the tile's last query attends: no such part for the merge (workgroup-uniform, before any barrier)
+        const int i_last = min(i0 + QH - 1, Tn - 1 + QH);
+        const int j_end = causal ? min(len, causal_limit(i_last, causal) + 1) : len;
+        if (j0 >= j_end) return;
+    }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const int r_lo = (Tn - 1) - (i0 + QH - 1);      // band row R of the workgroup <-> table row r_lo + R (clamped: out-of-table rows only meet masked keys)
+    const int r_lo = (Tn - 1) - (i0 + QH - 1) + j0; // band row R of the workgroup <-> table row r_lo + R (clamped: out-of-table rows only meet masked keys)
 
 #ifdef AT_PROFILE
     long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = clock64();
@@ -95,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
                     dma_piece(srd_q, qs_b, voff_q, i0 + pc * 8, 0, Tn - 1, 0u, __builtin_amdgcn_readfirstlane(lds0 + Q_OFF + pc * 1024), lane);
                 else if (8 * n < QH / 8 + NKP * 4) {
                     const int e = pc - QH / 8, row = (e >> 2) * KP + (e & 3) * 8;
-                    dma_piece(srd_q, qs_b, voff_q, row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
+                    dma_piece(srd_q, qs_b, voff_q, j0 + row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
                 } else {
                     const int row = (pc - QH / 8 - NKP * 4) * 8;
                     dma_piece(srd_p, ps_b, voff_p, r_lo + row, 0, 2 * Tn - 2, 0u, __builtin_amdgcn_readfirstlane(lds0 + P_OFF + row * 128), lane);
@@ -109,10 +134,10 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
                 const int pc = wave + 8 * n;
                 if (8 * n < NKP * 4) {
                     const int row = (pc >> 2) * KP + 32 * (g - 1) + (pc & 3) * 8;
-                    dma_piece(srd_q, qs_b, voff_v, row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
+                    dma_piece(srd_q, qs_b, voff_v, j0 + row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
                 } else if (8 * n < 2 * NKP * 4) {
                     const int e = pc - NKP * 4, row = (e >> 2) * KP + 32 * g + (e & 3) * 8;
-                    dma_piece(srd_q, qs_b, voff_q, row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
+                    dma_piece(srd_q, qs_b, voff_q, j0 + row, 0, Tn - 1, Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + K_OFF + row * 128), lane);
                 } else {
                     const int row = NBA + (pc - 2 * NKP * 4) * 8;
                     dma_piece(srd_p, ps_b, voff_p, r_lo + row, 0, 2 * Tn - 2, 0u, __builtin_amdgcn_readfirstlane(lds0 + P_OFF + row * 128), lane);
@@ -123,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
             for (int n = 0; n < GL_W; ++n) {
                 const int pc = wave + 8 * n;
                 const int row = (pc >> 2) * KP + 32 * (NSUB - 1) + (pc & 3) * 8;
-                dma_piece(srd_q, qs_b, voff_v, row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
+                dma_piece(srd_q, qs_b, voff_v, j0 + row, 0, Tn - 1, 2 * Dh * 2, __builtin_amdgcn_readfirstlane(lds0 + V_OFF + row * 128), lane);
             }
         }
     };
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
     const unsigned row_state = attn_row_state((unsigned long long)(b * H + h) * Tn + iq, drop_key(seed));
     const int lim_q = causal ? causal_limit(iq, causal) : 0x3fffffff;
     const int lim_blk = causal ? causal_limit(min(i0 + 32 * qb + 31, Tn - 1), causal) : 0x3fffffff;   // last key any query of this wave attends
-    const int j_lim = min(len - 1, lim_q);      // last key this lane's query attends ...
+    const int j_lim = min(len - 1, lim_q) - j0; // last key this lane's query attends (index inside the chunk) ...
     int j_all = j_lim;                          // ... and the last one EVERY query of the wave attends
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) j_all = min(j_all, __shfl_xor(j_all, o));
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
 #undef AT2_GSTORE
     };
     const int j_first = kp * KP;
-    int j_last = min(min((kp + 1) * KP, len), lim_blk + 1);    // keys [j_first, j_last) are live for this wave
+    int j_last = min(min((kp + 1) * KP, len - j0), lim_blk + 1 - j0);    // keys [j_first, j_last) of the chunk are live for this wave
     if (i0 + 32 * qb >= Tn) j_last = j_first;                   // a query block beyond the sequence
     const int nsub = j_last > j_first ? (j_last - j_first + 31) / 32 : 0;      // wave-uniform
     const int Rb0 = j_first - 32 * qb + QH - 32;                // band block of step 0 (rows Rb0 .. Rb0 + 31), the new block of step s: Rb0 + 32 (s + 1)
@@ -308,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
         for (int k = 0; k < 8; ++k) pw[k] = pk_bf16(p[2 * k], p[2 * k + 1]);
         if (drop) {
             unsigned km[8];
-            attn_pair_masks(row_state, jb >> 5, hh, thr, km);
+            attn_pair_masks(row_state, (j0 + jb) >> 5, hh, thr, km);
 #pragma unroll
             for (int k = 0; k < 8; ++k) pw[k] &= km[k];
             kbits[sub >> 1] |= attn_keep_bits(km) << (16 * (sub & 1));
@@ -327,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
     if (NSUB - 1 < nsub) pv(NSUB - 1);
     ATS_STAMP(4);   // last P.V
     // keep-bits for the backward: [row][hh][8 blocks of 32 keys] u16; this wave's NSUB blocks are consecutive
-    if (drop && keepbits && iq < Tn && nsub > 0) {
+    if (!CHUNK && drop && keepbits && iq < Tn && nsub > 0) {
         unsigned short *kb = keepbits + (((size_t)(b * H + h) * Tn + iq) * 2 + hh) * 8 + kp * NSUB;
         if constexpr (NSUB == 4) *reinterpret_cast<uint2 *>(kb) = make_uint2(kbits[0], kbits[1]);
         else if constexpr (NSUB == 2) *reinterpret_cast<unsigned *>(kb) = kbits[0];
@@ -364,6 +389,28 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
             for (int g = 0; g < 16; ++g)
                 o_acc[db][g] = o_acc[db][g] * a_me + oth[(32 * db + (g & 3) + 8 * (g >> 2) + 4 * hh) * 32 + r] * a_o;
     }
+    if (CHUNK) {            // un-normalised partial result of this chunk (relpos_attn_fwd_kernel's part format: m in units of the scaled score)
+#ifdef AT_PROFILE
+        ATS_STAMP(7);
+        if (bid == (unsigned)(nqt - 2) && tid == 0) {     // a full-size item of chunk 0 (profile build: its stamps replace real values)
+            for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(part_ml)[i] = sacc[i];
+            return;
+        }
+#endif
+        if (iq < Tn) {
+            const size_t row = (((size_t)b * H + h) * Tn + iq) * nparts + part;
+            float *po = part_o + row * 64;
+            const float ks = drop ? keep_scale : 1.f;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(po + 32 * db + 8 * q + 4 * hh) =
+                        make_float4(o_acc[db][4 * q] * ks, o_acc[db][4 * q + 1] * ks, o_acc[db][4 * q + 2] * ks, o_acc[db][4 * q + 3] * ks);
+            if (hh == 0) *reinterpret_cast<float2 *>(part_ml + row * 2) = make_float2(l_run > 0.f ? m_run * scale : -INFINITY, l_run);
+        }
+        return;
+    }
     if (iq < Tn) {
         const float inv = l_run > 0.f ? (drop ? keep_scale : 1.f) / l_run : 0.f;
         bf16_t *orow = out + ((long long)b * Tn + iq) * D + (long long)h * Dh;
@@ -378,9 +425,35 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf
     }
 #ifdef AT_PROFILE
     ATS_STAMP(7);   // merge + epilogue
-    if (blockIdx.x == 0 && tid == 0 && lse)
+    if (bid == 0 && tid == 0 && lse)
         for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(lse)[i] = sacc[i];   // (profile build: clobbers the first lse values)
 #endif
+}
+
+template <int QH>
+__global__ __launch_bounds__(512, 2) void relpos_attn_fwd_short2_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
+                                                                        const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                        const int32_t *__restrict__ key_lens, bf16_t *__restrict__ out,
+                                                                        float *__restrict__ lse, int Tn, int H, float scale, int causal,
+                                                                        float pdrop, unsigned long long seed,
+                                                                        const unsigned long long *__restrict__ seed_dev,
+                                                                        unsigned short *__restrict__ keepbits) {
+    relpos_attn_fwd_short2_item<QH, false>(qkv, pk, bias_u, bias_v, key_lens, out, lse, Tn, H, scale, causal, pdrop, seed, seed_dev, keepbits, blockIdx.x,
+                                           gridDim.x, nullptr, nullptr, nullptr);
+}
+// long sequences: PERSISTENT workgroups (one per CU: the 160 KB of LDS admit no second one) walk the live (query tile, chunk) items - a fresh
+// workgroup per item cost ~4 us of launch and teardown around ~10 us of work, and the items beyond the causal limit as much for nothing
+__global__ __launch_bounds__(512, 2) void relpos_attn_fwd_chunk_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ pk,
+                                                                       const float *__restrict__ bias_u, const float *__restrict__ bias_v,
+                                                                       const int32_t *__restrict__ key_lens, int Tn, int H, float scale, int causal,
+                                                                       float pdrop, unsigned long long seed, const unsigned long long *__restrict__ seed_dev,
+                                                                       const AttnChunkPlan plan, unsigned nitems, float *__restrict__ part_o,
+                                                                       float *__restrict__ part_ml) {
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+        relpos_attn_fwd_short2_item<128, true>(qkv, pk, bias_u, bias_v, key_lens, nullptr, nullptr, Tn, H, scale, causal, pdrop, seed, seed_dev, nullptr, item,
+                                               nitems, &plan, part_o, part_ml);
+        __syncthreads();        // every wave is through the item (the merge buffers live where the next item's tiles land)
+    }
 }
 
 // =====================================================================================================================
@@ -918,6 +991,36 @@ int tsasr_attn_short_fwd(const void *qkv, const void *pk, const float *bias_u, c
                                                                                     (bf16_t *)out, lse, T, H, scale, causal, pdrop, seed, seed_dev,
                                                                                     (unsigned short *)keepbits);
     }
+    return 0;
+}
+
+/* The same kernel per chunk of 256 keys for long sequences (bf16, Dh = 64, T > 256): partial results for relpos_attn_merge_kernel,
+ * nparts = cdiv(T, 256) parts per query (part_o [B*H*T*nparts][64], part_ml [B*H*T*nparts][2], fp32). */
+int tsasr_attn_chunk_fwd(const void *qkv, const void *pk, const float *bias_u, const float *bias_v, const int32_t *key_lens, int B, int T, int H,
+                         float scale, int causal, float pdrop, unsigned long long seed, const unsigned long long *seed_dev, int nparts,
+                         float *part_o, float *part_ml, hipStream_t st) {
+    constexpr int LDSS = (2 * 256 + 128 + 256) * 128 + 8 * 6144;
+    if (nparts > 64) return 1;      // (T > 16384: the caller keeps the streaming kernel)
+    AttnChunkPlan plan{};
+    const int nqt = cdiv(T, 128);
+    plan.nparts = nparts;
+    for (int p = 0; p < nparts; ++p) {
+        int first = nqt;
+        for (int qt = 0; qt < nqt; ++qt) {
+            const int i_last = std::min(qt * 128 + 127, T - 1 + 128);
+            const int lim = causal <= 1 ? i_last : (i_last / causal + 1) * causal - 1;      // = causal_limit (csrc/attn_common.h)
+            const int j_end = causal ? std::min(T, lim + 1) : T;
+            if (256 * p < j_end) { first = qt; break; }
+        }
+        plan.first_qt[p] = first;
+        plan.base[p + 1] = plan.base[p] + (nqt - first);
+    }
+    plan.per_pair = plan.base[nparts];
+    const unsigned nitems = (unsigned)plan.per_pair * (unsigned)(B * H);
+    static const int cus = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    (void)hipFuncSetAttribute((const void *)relpos_attn_fwd_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
+    relpos_attn_fwd_chunk_kernel<<<dim3(std::min<unsigned>(nitems, (unsigned)cus)), 512, LDSS, st>>>((const bf16_t *)qkv, (const bf16_t *)pk, bias_u, bias_v, key_lens, T, H,
+                                                                                                  scale, causal, pdrop, seed, seed_dev, plan, nitems, part_o, part_ml);
     return 0;
 }
 
