@@ -61,28 +61,50 @@ __global__ __launch_bounds__(256) void inject_fwd_kernel(const T *__restrict__ s
     st8(out + e, x);
 }
 
+// workgroup = (64 channels, utterance): 1024 threads = (64 / VE channel groups of one 16-byte piece) x NSL time slices; the slices' partial
+// sums meet in LDS and are added in slice order (deterministic). (Round 4's form - 4 slices of 2-byte loads - took 263 us at B = 1, T' = 4000,
+// where 4 workgroups walked 1000 frames each, and 18 us at the headline shape.)
 template <typename T, bool PROD>
-__global__ __launch_bounds__(256) void inject_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ src, const T *__restrict__ spk,
-                                                         T *__restrict__ dsrc, T *__restrict__ dspk, int Tn, int D) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
-    const float sp = (PROD && d < D) ? ld1(spk + (long long)b * D + d) : 1.f;
-    float acc = 0.f;
-    if (d < D)
-        for (int t = sl; t < Tn; t += 4) {
-            const long long e = ((long long)b * Tn + t) * D + d;
-            const float g = ld1(dout + e);
+__global__ __launch_bounds__(1024) void inject_bwd_kernel(const T *__restrict__ dout, const T *__restrict__ src, const T *__restrict__ spk,
+                                                          T *__restrict__ dsrc, T *__restrict__ dspk, int Tn, int D) {
+    constexpr int VE = 16 / sizeof(T), NDL = 64 / VE, NSL = 1024 / NDL;
+    __shared__ float red[NSL][64 + 1];
+    const int b = blockIdx.y, dl = threadIdx.x % NDL, sl = threadIdx.x / NDL, d0 = blockIdx.x * 64 + dl * VE;
+    const bool ok = d0 < D;         // D % 8 == 0 (checked by the launcher): a piece is inside or outside as a whole
+    float sp[VE], acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { sp[e] = (PROD && ok) ? ld1(spk + (long long)b * D + d0 + e) : 1.f; acc[e] = 0.f; }
+    if (ok)
+        for (int t = sl; t < Tn; t += NSL) {
+            const long long e0 = ((long long)b * Tn + t) * D + d0;
+            float g[VE], x[VE];
+            if constexpr (VE == 8) ld8(dout + e0, g);
+            else { const float4 v = *reinterpret_cast<const float4 *>(dout + e0); g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w; }
             if (PROD) {
-                acc += g * ld1(src + e);
-                st1(dsrc + e, g * sp);
+                if constexpr (VE == 8) ld8(src + e0, x);
+                else { const float4 v = *reinterpret_cast<const float4 *>(src + e0); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+                float o[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { acc[e] += g[e] * x[e]; o[e] = g[e] * sp[e]; }
+                if constexpr (VE == 8) st8(dsrc + e0, o);
+                else *reinterpret_cast<float4 *>(dsrc + e0) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
-                acc += g;
-                if (dsrc) st1(dsrc + e, g);     // (sum: the gradient of src IS dout - the host passes NULL and hands dout on)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] += g[e];
+                if (dsrc) {     // (sum: the gradient of src IS dout - the host passes NULL and hands dout on)
+                    if constexpr (VE == 8) st8(dsrc + e0, g);
+                    else *reinterpret_cast<float4 *>(dsrc + e0) = make_float4(g[0], g[1], g[2], g[3]);
+                }
             }
         }
-    red[sl][threadIdx.x & 63] = acc;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[sl][dl * VE + e] = acc[e];
     __syncthreads();
-    if (sl == 0 && d < D) st1(dspk + (long long)b * D + d, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < D) {
+        float s = 0.f;
+        for (int k = 0; k < NSL; ++k) s += red[k][threadIdx.x];
+        st1(dspk + (long long)b * D + blockIdx.x * 64 + threadIdx.x, s);
+    }
 }
 
 extern "C" {
@@ -107,15 +129,15 @@ int tsasr_inject_fwd(const void *src, const void *spk, void *out, int B, int T, 
 /* dsrc [B,T,D], dspk [B,1,D] from dout [B,T,D] (src, spk read only in mode 1; mode 0: dsrc may be NULL - it equals dout) */
 int tsasr_inject_bwd(const void *dout, const void *src, const void *spk, void *dsrc, void *dspk, int B, int T, int D, int mode, int io_dtype,
                      void *stream) {
-    TSASR_CHECK_ARG(dout && dspk && (dsrc || mode == 0) && B > 0 && T > 0 && D > 0 && (mode == 0 || (mode == 1 && src && spk)), "tsasr_inject_bwd: bad arguments");
+    TSASR_CHECK_ARG(dout && dspk && (dsrc || mode == 0) && B > 0 && T > 0 && D > 0 && D % 8 == 0 && (mode == 0 || (mode == 1 && src && spk)), "tsasr_inject_bwd: bad arguments");
     dim3 grid(cdiv(D, 64), B);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == TSASR_F32) {
-        if (mode) inject_bwd_kernel<float, true><<<grid, 256, 0, st>>>((const float *)dout, (const float *)src, (const float *)spk, (float *)dsrc, (float *)dspk, T, D);
-        else inject_bwd_kernel<float, false><<<grid, 256, 0, st>>>((const float *)dout, nullptr, nullptr, (float *)dsrc, (float *)dspk, T, D);
+        if (mode) inject_bwd_kernel<float, true><<<grid, 1024, 0, st>>>((const float *)dout, (const float *)src, (const float *)spk, (float *)dsrc, (float *)dspk, T, D);
+        else inject_bwd_kernel<float, false><<<grid, 1024, 0, st>>>((const float *)dout, nullptr, nullptr, (float *)dsrc, (float *)dspk, T, D);
     } else {
-        if (mode) inject_bwd_kernel<bf16_t, true><<<grid, 256, 0, st>>>((const bf16_t *)dout, (const bf16_t *)src, (const bf16_t *)spk, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
-        else inject_bwd_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t *)dout, nullptr, nullptr, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
+        if (mode) inject_bwd_kernel<bf16_t, true><<<grid, 1024, 0, st>>>((const bf16_t *)dout, (const bf16_t *)src, (const bf16_t *)spk, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
+        else inject_bwd_kernel<bf16_t, false><<<grid, 1024, 0, st>>>((const bf16_t *)dout, nullptr, nullptr, (bf16_t *)dsrc, (bf16_t *)dspk, T, D);
     }
     TSASR_CHECK_LAUNCH("tsasr_inject_bwd");
     return 0;
