@@ -75,6 +75,7 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
  * fwd keeps alpha/beta/lse in `workspace` (same pointer must be handed to bwd);
  * bwd writes dlogits[b,t,u,v] = gscale[b] * d costs[b] / d logits  (zeros outside the lattice / v >= V).
  * ------------------------------------------------------------------------------------------ */
+long long tsasr_rnnt_loss_error_word_offset(int B, int T, int U1);   /* split lattices (long targets, small batches): byte offset of the time-out word (1 = timed out), -1 = none */
 size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1);
 int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, const int32_t *tlen,
                         const int32_t *ulen, float *costs, int B, int T, int U1, int V, int ldl, int blank,

@@ -121,6 +121,14 @@ def test_rnnt_lattice_u1921_vs_oracle():
     g = lgd.grad.cpu().numpy()
     np.testing.assert_allclose(g, gref, atol=3e-5, rtol=max(1e-3, 5e-5 * (Tn + U1)))
     assert np.all(g[1, 31:] == 0) and np.all(g[1, :, 1501:] == 0)
+    # this shape splits each lattice over single-wave workgroups that wait for one another (csrc/rnnt.hip MC): the launch has a time-out
+    # word in its workspace, raised when a wait runs out (the costs are then NaN); Brain.flush_nonfinite reads it. Shapes whose lattice is
+    # one workgroup have none.
+    C = importlib.import_module("ts-asr_amd._capi")
+    assert C.lib().tsasr_rnnt_loss_error_word_offset(1, 4000, U1) >= 0 and C.lib().tsasr_rnnt_loss_error_word_offset(32, 250, 121) == -1
+    one = rn.rnnt_costs(lgd[:1].detach(), tg[:1].to(DEV), tl[:1].to(DEV), ul[:1].to(DEV), 0)      # B = 1: the split form
+    assert torch.isfinite(one).all() and abs(float(one[0]) - float(cref[0])) < 2e-5 * abs(float(cref[0]))
+    assert (len(rn._LATTICE_ERR) > 0) == (C.lib().tsasr_rnnt_loss_error_word_offset(1, Tn, U1) >= 0) and rn.lattice_timeouts() == 0
 
 
 def test_longform_joint_and_loss_full_size_properties():

@@ -38,6 +38,7 @@ _PROTOS = {
     "tsasr_joint_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_joint_bwd": (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_float, c_void_p, c_size_t, c_void_p]),
     "tsasr_rnnt_loss_workspace_bytes": (c_size_t, [c_int] * 3),
+    "tsasr_rnnt_loss_error_word_offset": (ctypes.c_longlong, [c_int] * 3),
     "tsasr_rnnt_lattice_plan": (None, [c_int] * 3),
     "tsasr_linear_add_layernorm_ok": (c_int, [c_ll, c_int, c_int, c_ll, c_ll]),
     "tsasr_linear_add_layernorm_fwd": (c_int, [c_void_p, c_ll, c_void_p, c_ll] + [c_void_p] * 8 + [c_ll, c_int, c_int, c_float, c_float,

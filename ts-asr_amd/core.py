@@ -442,6 +442,10 @@ class Brain:
             if _ops.lstm_timeouts():
                 raise RuntimeError("persistent LSTM kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
                                    "set TSASR_LSTM_PERSISTENT=0 to use the per-step kernels")
+            from . import rnnt as _rnnt
+            if _rnnt.lattice_timeouts():
+                raise RuntimeError("RNN-T lattice split over workgroups: a wait for the neighbouring column block timed out (blocks not "
+                                   "co-resident?); tsasr_rnnt_lattice_plan(-1, -1, 0) keeps every lattice in one workgroup")
         if self.nonfinite_count > self.nonfinite_patience:
             raise ValueError("Loss is not finite and patience is exhausted.")
         return self.nonfinite_count

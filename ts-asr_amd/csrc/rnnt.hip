@@ -661,6 +661,7 @@ __global__ void joint_bwd_reduce_kernel(const float *__restrict__ slab_w, const 
 // ============================================================================================
 struct RnntWs {
     float *lpb, *lpe_in, *lpe_out, *alpha, *beta, *lse, *logp, *xch;
+    unsigned *err;   // split lattice only: set to 1 by a workgroup whose wait for its neighbour's edge value ran out (the costs are then NaN)
     int U1P, K;      // padded columns per frame; columns per lane of the ONE-wave layout
     int KT, NW, NC;  // the lattice kernel's plan: columns per thread, waves per workgroup, column blocks (workgroups) per (utterance, direction)
     int R, sh;       // rows per utterance plane; column -> skew shift (31: no skew)
@@ -714,7 +715,7 @@ static size_t rnnt_plane_floats(int B, int T, int U1) {
 static size_t rnnt_xch_floats(int B, int T, int U1) {
     int kt, nw, nc, skew;
     rnnt_plan(B, U1, &kt, &nw, &nc, &skew);
-    return nc > 1 ? (size_t)2 * B * nc * (T + 1) : 0;
+    return nc > 1 ? (size_t)2 * B * nc * (T + 1) + 64 : 0;      // (+ 64: the split lattice's error word, see AB_SPIN_LIMIT)
 }
 
 static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
@@ -731,6 +732,7 @@ static RnntWs rnnt_carve(void *ws, int B, int T, int U1) {
     w.lpb = p; w.lpe_in = p + n; w.lpe_out = p + 2 * n; w.alpha = p + 3 * n; w.beta = p + 4 * n; w.lse = p + 5 * n;
     w.logp = p + 6 * n;
     w.xch = w.logp + align_up((size_t)B, 64);
+    w.err = w.NC > 1 ? reinterpret_cast<unsigned *>(w.xch + rnnt_xch_floats(B, T, U1) - 64) : nullptr;
     return w;
 }
 
@@ -944,6 +946,7 @@ __global__ __launch_bounds__(64 * NW) void rnnt_alphabeta_kernel(RnntWs w, const
             __builtin_amdgcn_s_sleep(16);
             xch_poll2(xch_in, 4u * xch_idx(s0 + d), 4u * xch_idx(s0 + d + XCH_LEAD), v, vf);
         } while ((v == 0xffffffffu || vf == 0xffffffffu) && ++spins < AB_SPIN_LIMIT);
+        if (spins >= AB_SPIN_LIMIT && (threadIdx.x & 63) == 0) *w.err = 1u;      // the producer never came (not co-resident?): the host reads this word (tsasr_rnnt_loss_error_word_offset)
         unsigned off[PF], out[PF];
 #pragma unroll
         for (int j = 0; j < PF; ++j) off[j] = 4u * xch_idx(j >= d ? s0 + j : s0 + PF + j);
@@ -1328,6 +1331,15 @@ int tsasr_joint_bwd(const float *dlogits, const void *enc, const void *dec, cons
  * one-workgroup lattice; mc = 0 never split a lattice over workgroups, 1 / 2 / 4 = split whenever it fits, that many columns per thread.
  * Changes tsasr_rnnt_loss_workspace_bytes; forward and backward of one loss must run under the same plan. Every plan gives the same bits. */
 void tsasr_rnnt_lattice_plan(int skew, int waves, int mc) { g_plan_skew = skew; g_plan_waves = waves; g_plan_mc = mc; }
+
+/* Byte offset, inside a loss workspace, of the split lattice's error word (uint32: 1 = a workgroup's wait for its neighbour ran out and the
+ * costs of that launch are NaN; any other value = fine), or -1 when this shape does not split its lattice over workgroups. */
+long long tsasr_rnnt_loss_error_word_offset(int B, int T, int U1) {
+    if (B <= 0 || T <= 0 || U1 <= 0) return -1;
+    char base[1];
+    const RnntWs w = rnnt_carve(base, B, T, U1);
+    return w.err ? (long long)(reinterpret_cast<char *>(w.err) - base) : -1;
+}
 
 size_t tsasr_rnnt_loss_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0) return 0;

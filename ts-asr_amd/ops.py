@@ -226,7 +226,7 @@ _WG_ENABLED = True
 # many CUs: -1 = half the device. A 256x256-tile workgroup holds 128 KB of LDS, so nothing shares a CU with it; with one per tile the
 # speaker branch's small kernels waited for whole CUs to drain (13.39-13.46 ms per step; 96 CUs 13.16, 112: 13.12, 128: 13.09, 144: 13.28,
 # 192: 13.20). 0 = one workgroup per tile.
-_WG_EARLY_WGS = -1
+_WG_EARLY_WGS = int(os.environ.get("TSASR_WG_EARLY_WGS", "-1"))
 _WG_EARLY_SLOTS = 0      # (2: the launch made beside another stream's kernels uses 64 KB of LDS - measured equal)
 
 

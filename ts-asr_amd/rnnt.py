@@ -92,6 +92,14 @@ def fused_joint_logits(enc_proj, dec_proj, head_weight, head_bias, slope=0.01, e
     return _JointLogitsFn.apply(enc_proj, dec_proj, head_weight, head_bias, slope, enc_abs_lens, tok_abs_lens)
 
 
+_LATTICE_ERR = []    # time-out words of the most recent split-lattice launches (csrc/rnnt.hip AB_SPIN_LIMIT)
+
+
+def lattice_timeouts():
+    """Number of kept split-lattice launches whose inter-workgroup wait ran out (a host read): their costs came out NaN."""
+    return sum(int(w.view(torch.int32)[0].item() == 1) for w in _LATTICE_ERR)
+
+
 class _RnntLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, tlen, ulen, blank):
@@ -108,6 +116,10 @@ class _RnntLossFn(torch.autograd.Function):
             C.check(C.lib().tsasr_rnnt_loss_fwd(C.ptr(lg), C.ptr(tg), tg.stride(0), C.ptr(tlen), C.ptr(ulen), C.ptr(costs),
                                                 B, T, U1, V, lg.stride(-2), int(blank), C.ptr(ws), ws.numel(), C.stream_ptr()),
                     "tsasr_rnnt_loss_fwd")
+        off = int(C.lib().tsasr_rnnt_loss_error_word_offset(B, T, U1))
+        if off >= 0:        # a lattice split over workgroups (long targets in small batches): keep its time-out word for Brain.flush_nonfinite
+            _LATTICE_ERR.append(ws[off:off + 4])
+            del _LATTICE_ERR[:-4]
         ctx.save_for_backward(lg, tg, tlen, ulen, ws)
         ctx.blank, ctx.in_dtype = int(blank), logits.dtype
         return costs
