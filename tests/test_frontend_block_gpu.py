@@ -72,7 +72,7 @@ def rel_l2(a, b):
 
 
 CASES = [  # (cin, B, T, F, padding)
-    (1, 3, 37, 80, "same"), (1, 2, 64, 80, "causal"), (1, 2, 21, 38, "same"),
+    (1, 3, 37, 80, "same"), (1, 2, 64, 80, "causal"), (1, 2, 21, 38, "same"), (1, 2, 16, 24, "causal"),
     (128, 2, 19, 40, "same"), (128, 2, 24, 40, "causal"),
 ]
 
