@@ -180,6 +180,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0x140>(v);   // row_mirror
     return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
+// FOUR wave-wide sums at once (every lane gets all four): the partial sums are folded into one register as soon as two lanes hold the same
+// value (after the first quad step lane parity picks which pair of values a lane carries on, after the second bit 1 of the lane), the rows
+// are joined by v_permlane16_swap / v_permlane32_swap (gfx950: swap(x, x) returns both rows' / halves' values, their sum is the same in both),
+// and four quad broadcasts hand the totals back: 19 vector operations instead of 4 x 11; fixed order.
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += dpp_mov<0xB1>(v[q]);                   // quad_perm [1,0,3,2]
+    float a = (lane & 1) ? v[1] : v[0], b = (lane & 1) ? v[3] : v[2];
+    a += dpp_mov<0x4E>(a);                                                     // quad_perm [2,3,0,1]
+    b += dpp_mov<0x4E>(b);
+    float c = (lane & 2) ? b : a;                                              // lane & 3 = index of the value this lane carries
+    c += dpp_mov<0x124>(c);                                                    // row_ror:4
+    c += dpp_mov<0x128>(c);                                                    // row_ror:8
+    // (inline asm: through __builtin_amdgcn_permlane16_swap / 32_swap hipcc (ROCm 7.2) folds r[0] + r[1] into 2 * r[0] - it takes the two
+    // results of the swap for equal. `s_nop 1`: the wait states hipcc itself puts between a VALU write and a lane swap of the same register)
+    {
+        float c2 = c;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(c2));
+        c += c2;
+        c2 = c;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(c2));
+        c += c2;
+    }
+    v[0] = dpp_mov<0x00>(c); v[1] = dpp_mov<0x55>(c); v[2] = dpp_mov<0xAA>(c); v[3] = dpp_mov<0xFF>(c);
+}
 // sum over the 32 lanes of this lane's half of the wave (two independent rows per wave: lanes 0-31 / 32-63)
 __device__ __forceinline__ float half_wave_sum(float v) {
     v += dpp_mov<0xB1>(v);

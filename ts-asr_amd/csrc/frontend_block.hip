@@ -79,8 +79,11 @@ __device__ __forceinline__ float fb_row_taps(const T *__restrict__ x, int b, int
 // sum over the workgroup of NV values per thread: wave_sum, one LDS slot per wave, fixed-order sum (every thread gets the totals)
 template <int NV>
 __device__ __forceinline__ void fb_wg_sum(float (&v)[NV], float *red /*[FB_WAVES][NV]*/, int wave, int lane) {
+    if constexpr (NV == 4) wave_sum4(v);
+    else {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = wave_sum(v[q]);
+        for (int q = 0; q < NV; ++q) v[q] = wave_sum(v[q]);
+    }
     if (lane == 0)
 #pragma unroll
         for (int q = 0; q < NV; ++q) red[wave * NV + q] = v[q];
