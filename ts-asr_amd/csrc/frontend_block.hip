@@ -399,7 +399,7 @@ __global__ __launch_bounds__(FB_THREADS) void fe_block_bwd_kernel(const FeBlockA
 constexpr int F1_PP = 48;                        // padded positions: up to 3 blocks of 16
 constexpr int F1_PBYTES = F1_PP * 16 * 2;        // P[48][16] bf16
 constexpr int F1_TBYTES = 16 * F1_PP * 2;        // T[16][48] bf16
-constexpr int F1_LDS = 2 * (F1_PBYTES + F1_TBYTES) + 2 * FB_WAVES * 4 * 4;
+constexpr int F1_LDS = 21504;      // tiles 2 * (1536 + 1536) + reductions 256; the forward first stages its filters ([2][16][132] floats) and their Gram sums there
 
 __device__ __forceinline__ unsigned fe1_word(unsigned row_key, unsigned cidx) {
     unsigned y = row_key + cidx;
@@ -463,7 +463,6 @@ template <int NPB>
 __global__ __launch_bounds__(FB_THREADS, 4) void fe_block1_fwd_mfma_kernel(const FeBlockArgs A) {
     extern __shared__ __attribute__((aligned(16))) char f1_lds[];
     char *Pb = f1_lds, *Tb = f1_lds + 2 * F1_PBYTES;
-    float *red = reinterpret_cast<float *>(f1_lds + 2 * (F1_PBYTES + F1_TBYTES));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
     const int Fo = A.Fo, N = Fo * FB_C;
     const float inv_n = 1.f / (float)N;
@@ -487,6 +486,55 @@ __global__ __launch_bounds__(FB_THREADS, 4) void fe_block1_fwd_mfma_kernel(const
     const unsigned thr1 = drop_thr16(A.p1), thr2 = drop_thr16(A.p2), thr1s = thr1 << 16, thr2s = thr2 << 16;
     const DropKey k1 = drop_key(A.seed1 + sd), k2 = drop_key(A.seed2 + sd);
     const float ks1 = drop_scale16(thr1), ks2 = drop_scale16(thr2);
+    // LayerNorm statistics WITHOUT touching the 2 x 12 accumulators: y[p][c] = sum_k taps[p][k] W[k][c] (slot 9 = 1: the bias), so over a row
+    //   sum y   = sum_k (sum_c W[k][c]) G[k][9] ,   sum y^2 = sum_{k,k'} (sum_c W[k][c] W[k'][c]) G[k][k'] ,   G = taps^T taps (16 x 16 per row),
+    // and G is two MFMAs of the T tile with itself (positions on K). Every wave forms G and the four sums (y and r) for itself - a lane holds
+    // G[4g + j][pl] and the matching weight sums, 16 multiply-adds and one wave_sum4 - so the statistics need no pass over the accumulators,
+    // no LDS round and no other wave (24 adds + 24 multiply-adds + two-level reduction before). Filter sums in fp32 from the fp32 filters.
+    float gy[4], gr[4], ay[4], ar[4];
+    {
+        // (the filters as [branch][slot][channel] rows in LDS - the tile area is not in use yet)
+        float *wf = reinterpret_cast<float *>(f1_lds);      // [2][16][FB_C + 4] floats
+        constexpr int WS = FB_C + 4;
+        static_assert(2 * 16 * WS * 4 <= F1_LDS, "filter staging fits the kernel's LDS");
+        const int ctr = A.tmode == 1 ? 5 : 4;
+        for (int i = threadIdx.x; i < 16 * FB_C; i += FB_THREADS) {
+            const int k = i / FB_C, c = i - k * FB_C;
+            wf[k * WS + c] = k < 9 ? A.w1[c * 9 + k] : (k == 9 ? A.b1[c] : 0.f);
+            wf[(16 + k) * WS + c] = k == ctr ? A.w2[c] : (k == 9 ? A.b2[c] : 0.f);
+        }
+        __syncthreads();
+        // one (slot, slot') pair and half of the channels per thread; the partial sums meet in LDS behind the filters
+        float *gw = wf + 2 * 16 * WS;       // [half][branch][16][16] dots, then [half][branch][16] row sums
+        static_assert((2 * 16 * WS + 2 * 2 * 256 + 2 * 2 * 16) * 4 <= F1_LDS, "filter staging fits the kernel's LDS");
+        {
+            const int k = (threadIdx.x >> 4) & 15, k2 = threadIdx.x & 15, half = threadIdx.x >> 8;
+            const float *ra = wf + k * WS + 64 * half, *rb = wf + k2 * WS + 64 * half;
+            float dy = 0.f, sy = 0.f, dr = 0.f, sr = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < 64; c += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(ra + c), z = *reinterpret_cast<const float4 *>(rb + c);
+                const float4 xr = *reinterpret_cast<const float4 *>(ra + 16 * WS + c), zr = *reinterpret_cast<const float4 *>(rb + 16 * WS + c);
+                dy += x.x * z.x + x.y * z.y + x.z * z.z + x.w * z.w;
+                sy += (x.x + x.y) + (x.z + x.w);
+                dr += xr.x * zr.x + xr.y * zr.y + xr.z * zr.z + xr.w * zr.w;
+                sr += (xr.x + xr.y) + (xr.z + xr.w);
+            }
+            gw[(half * 2 + 0) * 256 + k * 16 + k2] = dy;
+            gw[(half * 2 + 1) * 256 + k * 16 + k2] = dr;
+            if (k2 == 0) { gw[1024 + (half * 2 + 0) * 16 + k] = sy; gw[1024 + (half * 2 + 1) * 16 + k] = sr; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * g + j;
+            gy[j] = gw[k * 16 + pl] + gw[512 + k * 16 + pl];
+            gr[j] = gw[256 + k * 16 + pl] + gw[768 + k * 16 + pl];
+            ay[j] = pl == 9 ? gw[1024 + k] + gw[1024 + 32 + k] : 0.f;      // column 9 of G = the tap sums
+            ar[j] = pl == 9 ? gw[1024 + 16 + k] + gw[1024 + 48 + k] : 0.f;
+        }
+        __syncthreads();
+    }
     Fe1Stage stg;
     stg.init(A);
     fe1_lds_init(f1_lds, Fo);
@@ -496,13 +544,15 @@ __global__ __launch_bounds__(FB_THREADS, 4) void fe_block1_fwd_mfma_kernel(const
     if ((long long)blockIdx.x < A.R) stg.store(Pb, Tb, stg.load(A, b, to));
     __syncthreads();
     int par = 0;
+    // fragment addresses inside a T tile: positions 8g .. 8g+7 of slot pl, and positions 32 + 8g .. (g < 2; the other lanes read slot 15's zeros)
+    const int tf0 = (pl * F1_PP + 8 * g) * 2, tf1 = g < 2 ? (pl * F1_PP + 32 + 8 * g) * 2 : (15 * F1_PP) * 2;
     for (long long row = blockIdx.x; row < A.R; row += gridDim.x, par ^= 1) {
         to += stride_t; b += stride_b;
         if (to >= A.To) { to -= A.To; ++b; }
         const bool more = row + gridDim.x < A.R;
         unsigned short nxt = 0;
         if (more) nxt = stg.load(A, b, to);                  // the next row's tap of this thread: in flight under the MFMAs and the statistics
-        const char *P = Pb + par * F1_PBYTES;
+        const char *P = Pb + par * F1_PBYTES, *Tt = Tb + par * F1_TBYTES;
         f32x4 y[NPB], r[NPB];
 #pragma unroll
         for (int t = 0; t < NPB; ++t) {
@@ -510,16 +560,24 @@ __global__ __launch_bounds__(FB_THREADS, 4) void fe_block1_fwd_mfma_kernel(const
             y[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wy, taps, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             r[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, taps, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        float s[4] = {0.f, 0.f, 0.f, 0.f};      // padded positions: all slots zero -> y = r = 0 exactly, nothing to mask
-#pragma unroll
-        for (int t = 0; t < NPB; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[0] += y[t][j]; s[1] += r[t][j];
-                s[2] = __builtin_fmaf(y[t][j], y[t][j], s[2]); s[3] = __builtin_fmaf(r[t][j], r[t][j], s[3]);
+        f32x4 G;
+        {
+            const bf16x8 t0 = *reinterpret_cast<const bf16x8 *>(Tt + tf0);
+            G = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, t0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (NPB > 2) {
+                const bf16x8 t1 = *reinterpret_cast<const bf16x8 *>(Tt + tf1);
+                G = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, t1, G, 0, 0, 0);
             }
+        }
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0] = __builtin_fmaf(ay[j], G[j], s[0]); s[1] = __builtin_fmaf(ar[j], G[j], s[1]);
+            s[2] = __builtin_fmaf(gy[j], G[j], s[2]); s[3] = __builtin_fmaf(gr[j], G[j], s[3]);
+        }
+        wave_sum4(s);
         if (more) stg.store(Pb + (par ^ 1) * F1_PBYTES, Tb + (par ^ 1) * F1_TBYTES, nxt);      // read last in the previous row, before its barrier
-        fb_wg_sum<4>(s, red + par * FB_WAVES * 4, wave, lane);
+        __syncthreads();        // publishes the next row's taps (the statistics no longer need it)
         const float mu_y = s[0] * inv_n, mu_r = s[1] * inv_n;
         const float rs_y = rsqrtf(fmaxf(s[2] * inv_n - mu_y * mu_y, 0.f) + A.eps), rs_r = rsqrtf(fmaxf(s[3] * inv_n - mu_r * mu_r, 0.f) + A.eps);
         if (threadIdx.x == 0) *reinterpret_cast<float4 *>(A.stats + row * 4) = make_float4(mu_y, rs_y, mu_r, rs_r);
