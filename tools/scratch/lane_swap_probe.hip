@@ -1,6 +1,6 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include "../../../ts-asr_amd/csrc/common.h"
+#include "../../ts-asr_amd/csrc/common.h"
 __global__ void k(float *out) {
     const int lane = threadIdx.x;
     float c = (float)(1 << (lane & 15)) ;   // bit per lane in row

@@ -1,6 +1,6 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include "../../../ts-asr_amd/csrc/common.h"
+#include "../../ts-asr_amd/csrc/common.h"
 __global__ void k(const float *in, float *out) {
     float v[4];
     for (int q = 0; q < 4; ++q) v[q] = in[q * 64 + threadIdx.x];
