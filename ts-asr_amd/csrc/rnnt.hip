@@ -288,6 +288,28 @@ __device__ __forceinline__ void load_w_frags(BwdFrags &f, const float *__restric
                 f.wf[i][s][j] = (bf16_t)((f.kb[i] >= 0 && 16 * s + 8 * h + j < V) ? wv[i][s][j] : 0.f);
 }
 
+// the same fragments in fp16, straight from the fp32 head matrix (the forward's operand rounding: joint_fwd_regw_kernel)
+typedef _Float16 half8_w __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void load_w_frags16(half8_w (&wf)[KB][2], const BwdFrags &f, const float *__restrict__ W, int J, int V, int wslot, int nslots, int r,
+                                               int h) {
+    const int nkb = J / 32;
+    float wv[KB][2][8];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        const int kbc = min(wslot + i * nslots, nkb - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[i][s][j] = W[(size_t)min(16 * s + 8 * h + j, V - 1) * J + kbc * 32 + r];
+    }
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[i][s][j] = (_Float16)((f.kb[i] >= 0 && 16 * s + 8 * h + j < V) ? wv[i][s][j] : 0.f);
+}
+
 // A operand: dlogits[u_r][16s+8h+j] (fp32 -> bf16); rows beyond U1 read as zero
 __device__ __forceinline__ void load_a_frags(const float *__restrict__ dl_row, bool valid, int ldl, int h,
                                              bf16x8 (&a)[2], float (&af)[2][8]) {
@@ -350,10 +372,19 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
     const int t_chunk = (Tn + TS - 1) / TS, t_lo = ts * t_chunk, t_hi = min(Tn, t_lo + t_chunk);
     const int t_end = (u0 <= Ub) ? min(Tb, t_hi) : t_lo;  // tile entirely outside the lattice -> dlogits are zero
 
+    // F16 (bf16 training path, round 5): the vector work per lattice cell and joint dimension in PACKED fp16, as the forward does it -
+    //   x = e + d, h = max(x, slope x), lrelu'(x) = bit-select(sign mask of x, slope, 1), dh = cvt(D) * lrelu'  : 6 packed operations + one
+    //   conversion per PAIR of cells instead of ~7 fp32 operations per cell -
+    // with every MFMA on fp16 operands (dlogits and W in fp16: 11 significant bits instead of bf16's 8) and the two sums of dh off the vector
+    // unit: over the frames (ddec) as an MFMA against an identity operand with dh, in the registers it was formed in, as B operand; over the
+    // tile's rows (denc) as 7 packed adds. (fp32 tensors take the fp32 form below.)
+    constexpr bool F16 = !std::is_same<T, float>::value;
     BwdFrags f;
     load_w_frags(f, W, J, V, wslot, nslots, r, h);
     float dv[KB][16], dacc[KB][16];
-    f32x16 wacc[KB];
+    half2_t dvp[KB][8];
+    half8_t wf16[KB][2], ident16[2];
+    f32x16 wacc[KB], dsum[KB];
     int kbc[KB];
 #pragma unroll
     for (int i = 0; i < KB; ++i) kbc[i] = max(f.kb[i], 0);
@@ -366,12 +397,20 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             wacc[i] = (f32x16){0};
+            dsum[i] = (f32x16){0};
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 dv[i][g] = (f.kb[i] >= 0 && u0 + acc_row(g, h) < U1) ? (float)raw[i][g] : 0.f;
                 dacc[i][g] = 0.f;
             }
+#pragma unroll
+            for (int pq = 0; pq < 8; ++pq) dvp[i][pq] = (half2_t){(_Float16)dv[i][2 * pq], (_Float16)dv[i][2 * pq + 1]};
         }
+        if constexpr (F16) load_w_frags16(wf16, f, W, J, V, wslot, nslots, r, h);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ident16[s2][j] = (_Float16)((r == 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) ? 1.f : 0.f);
     }
     float bsum[2][8];
 #pragma unroll
@@ -382,12 +421,21 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
     bf16_t *my_lds = a_lds[wave];
     const bool row_ok = (u0 + r) < U1;
     // one frame: a = this lane's dlogits fragments (bf16), af = the same values in fp32 (bias-gradient sums), ev = enc[b, t, k] per k-block
+    const half2_t slope2 = {(_Float16)slope, (_Float16)slope};
+    const unsigned slope2u = __builtin_bit_cast(unsigned, slope2), one2u = 0x3C003C00u;
     auto frame = [&](int t, const bf16x8 (&a)[2], const float (&af)[2][8], const float (&ev)[KB]) {
+        half8_t a16[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum[s][j] += af[s][j];
-            *reinterpret_cast<bf16x8 *>(my_lds + r * 32 + 16 * s + 8 * h) = a[s];
+            if constexpr (F16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a16[s][j] = (_Float16)af[s][j];      // (af is already zero for rows beyond U1: cvt_a)
+                *reinterpret_cast<half8_t *>(my_lds + r * 32 + 16 * s + 8 * h) = a16[s];
+            } else {
+                *reinterpret_cast<bf16x8 *>(my_lds + r * 32 + 16 * s + 8 * h) = a[s];
+            }
         }
         __builtin_amdgcn_wave_barrier();  // same-wave LDS write -> read (DS ops retire in order)
         // A' operand of dW = dlogits^T . H : rows = v_r, inner index i <-> u = 16s + 8(j>>2) + 4h + (j&3)
@@ -404,6 +452,57 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
                 at[s][0] = lo[0]; at[s][1] = lo[1]; at[s][2] = lo[2]; at[s][3] = lo[3];
                 at[s][4] = hi[0]; at[s][5] = hi[1]; at[s][6] = hi[2]; at[s][7] = hi[3];
             }
+        }
+        if constexpr (F16) {
+            half8_t at16[2];
+            at16[0] = __builtin_bit_cast(half8_t, at[0]);
+            at16[1] = __builtin_bit_cast(half8_t, at[1]);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                if (f.kb[i] < 0) continue;   // wave-uniform
+                const _Float16 e16 = (_Float16)ev[i];
+                const half2_t e2 = {e16, e16};
+                f32x16 D = {0};
+                D = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[0], wf16[i][0], D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[1], wf16[i][1], D, 0, 0, 0);
+                typedef unsigned u32x4_j __attribute__((ext_vector_type(4)));
+                typedef short s16x2_j __attribute__((ext_vector_type(2)));
+                u32x4_j hbv[2], dbv[2];      // the B operands are written element by element where they will be read (no gathering moves)
+                half2_t dhp[8];
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq) {
+                    const half2_t x = dvp[i][pq] + e2, xs = x * slope2;
+                    // 0xffff in the halves with x <= 0 (torch: lrelu'(x) = x > 0 ? 1 : slope - and with bf16 operands e = -d happens once in ~10^4 cells):
+                    // as int16, fp16 bits are <= 0 exactly for -x and +0, so (bits - 1, saturating) is negative there and nowhere else
+                    const unsigned neg = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_j, x), (s16x2_j){1, 1}) >> (s16x2_j){15, 15});
+                    // lrelu(x) and lrelu'(x) as bit-selects on that mask; v_bfi_b32 by hand: left to itself hipcc makes two 16-bit compare + select pairs
+                    // and a v_perm (or not / and / and-or) out of the first one
+                    unsigned hsel, fct;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hsel) : "v"(neg), "v"(__builtin_bit_cast(unsigned, xs)), "v"(__builtin_bit_cast(unsigned, x)));
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(fct) : "v"(neg), "v"(slope2u), "v"(one2u));
+                    hbv[pq >> 2][pq & 3] = hsel;
+                    const half2_t dp = __builtin_convertvector((f32x2){D[2 * pq], D[2 * pq + 1]}, half2_t);
+                    dhp[pq] = dp * __builtin_bit_cast(half2_t, fct);
+                    dbv[pq >> 2][pq & 3] = __builtin_bit_cast(unsigned, dhp[pq]);
+                }
+                half8_t hb16[2], db16[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    hb16[s2] = __builtin_bit_cast(half8_t, hbv[s2]);
+                    db16[s2] = __builtin_bit_cast(half8_t, dbv[s2]);
+                }
+                dsum[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident16[0], db16[0], dsum[i], 0, 0, 0);
+                dsum[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident16[1], db16[1], dsum[i], 0, 0, 0);
+                if (denc_part) {      // this tile's share of denc[b, t, k]: the 16 rows of the lane as packed adds, the other half-wave's 16 by a lane swap
+                    const half2_t tsum = ((dhp[0] + dhp[1]) + (dhp[2] + dhp[3])) + ((dhp[4] + dhp[5]) + (dhp[6] + dhp[7]));
+                    float esum = (float)tsum[0] + (float)tsum[1];
+                    esum += other_half(esum);
+                    if (h == 0) denc_part[(((size_t)ut * nb + b) * Tn + t) * J + f.kb[i] * 32 + r] = esum;
+                }
+                wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(at16[0], hb16[0], wacc[i], 0, 0, 0);
+                wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(at16[1], hb16[1], wacc[i], 0, 0, 0);
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
@@ -496,9 +595,10 @@ __global__ __launch_bounds__(256) void joint_bwd_x_kernel(
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int u = u0 + acc_row(g, h);
+            const float dd = F16 ? dsum[i][g] : dacc[i][g];
             if (u < U1) {
-                if (TS > 1) ddec_part[(((size_t)ts * nb + b) * U1 + u) * J + k] = dacc[i][g];
-                else st1(ddec + ((size_t)b * U1 + u) * J + k, dacc[i][g]);
+                if (TS > 1) ddec_part[(((size_t)ts * nb + b) * U1 + u) * J + k] = dd;
+                else st1(ddec + ((size_t)b * U1 + u) * J + k, dd);
             }
             slab_w[((size_t)((ts * nb + b) * nut + ut) * 32 + acc_row(g, h)) * J + k] = wacc[i][g];
         }
