@@ -221,3 +221,38 @@ def test_attention_forward_key_split_equals_unsplit(B, Tn, H, Dh, causal, pdrop,
     chunked = dtype == torch.bfloat16 and Dh == 64
     assert float((o1 - o0).norm() / o0.norm()) < (5e-3 if chunked else 3e-3)
     assert float((l1 - l0).abs().max()) < (1e-3 if chunked else 1e-4)
+
+
+@pytest.mark.parametrize("B,Tn,H,causal,pdrop", [(1, 1500, 4, 1, 0.1), (2, 777, 2, 40, 0.0), (1, 4000, 4, 1, 0.0)])
+def test_attention_backward_ignores_workspace_garbage(B, Tn, H, causal, pdrop):
+    """Under a look-ahead mask the streaming backward clears only a BAND of its two [B,H,T,T] scratch matrices (what the key-major pass can read
+    beyond the query-major pass's writes, csrc/attention.hip attn_zero_band_kernel) instead of all of them. The same call on a workspace full
+    of NaN bits and on a workspace of zeros: every gradient finite and bit-identical."""
+    C = importlib.import_module("ts-asr_amd._capi")
+    Dh = 64
+    D = H * Dh
+    g = torch.Generator().manual_seed(Tn)
+    qkv = (torch.randn(B, Tn, 3 * D, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    pk = (torch.randn(2 * Tn - 1, D, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    u, v = (torch.randn(D, generator=g) * 0.1).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    lens = torch.tensor([Tn, max(1, Tn - 13)][:B], dtype=torch.int32, device=DEV)
+    dout = torch.randn(B, Tn, D, generator=g).to(torch.bfloat16).to(DEV)
+    out, lse = torch.empty(B, Tn, D, dtype=torch.bfloat16, device=DEV), torch.empty(B, H, Tn, device=DEV)
+    scale = 1.0 / D ** 0.5
+    nf = C.lib().tsasr_relpos_attn_fwd_workspace_bytes(B, Tn, H)
+    wsf = torch.empty(max(nf, 16), dtype=torch.uint8, device=DEV)
+    C.check(C.lib().tsasr_relpos_attn_fwd_ws(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(lse), B, Tn, H, Dh, scale, causal, pdrop, 99, None,
+                                             C.io_dtype(qkv), C.ptr(wsf) if nf else None, nf, C.stream_ptr()), "fwd")
+    nb = C.lib().tsasr_relpos_attn_bwd_workspace_bytes(B, Tn, H)
+    res = []
+    for fill in (0xFF, 0x00):
+        ws = torch.full((nb,), fill, dtype=torch.uint8, device=DEV)
+        dqkv, dpk = torch.empty_like(qkv), torch.empty_like(pk)
+        du, dv = torch.empty_like(u), torch.empty_like(v)
+        C.check(C.lib().tsasr_relpos_attn_bwd(C.ptr(qkv), C.ptr(pk), C.ptr(u), C.ptr(v), C.ptr(lens), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(dpk),
+                                              C.ptr(du), C.ptr(dv), B, Tn, H, Dh, scale, causal, pdrop, 99, None, C.io_dtype(qkv), C.ptr(ws), nb, C.stream_ptr()), "bwd")
+        torch.cuda.synchronize()
+        res.append([t.float().cpu() for t in (dqkv, dpk, du, dv)])
+    for a, b_, name in zip(res[0], res[1], ("dqkv", "dpk", "du", "dv")):
+        assert torch.isfinite(a).all(), name
+        assert torch.equal(a, b_), name

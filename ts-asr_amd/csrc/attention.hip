@@ -1382,6 +1382,10 @@ static bool attn_chunk_enabled() {      // TSASR_ATTN_CHUNK=0: the streaming for
     static const bool on = [] { const char *e = getenv("TSASR_ATTN_CHUNK"); return !e || e[0] != '0'; }();
     return on;
 }
+static bool attn_zero_band_enabled() {      // TSASR_ATTN_ZERO_BAND=0: clear the whole P_d / dS matrices under a look-ahead mask (A/B, round 4's form)
+    static const bool on = [] { const char *e = getenv("TSASR_ATTN_ZERO_BAND"); return !e || e[0] != '0'; }();
+    return on;
+}
 static int attn_short_version() {   // TSASR_ATTN_SHORT = 1: round 3's short-sequence forward (A/B); default 2
     static const int v = [] { const char *e = getenv("TSASR_ATTN_SHORT"); return e ? atoi(e) : 2; }();
     return v;
@@ -1459,6 +1463,24 @@ static std::vector<DpkJob> g_dpk_jobs;
 static int g_dpk_defer = 0;
 static void *g_attn_keepbits = nullptr;     // tsasr_relpos_attn_keepbits: the next forward writes / the next backward reads them
 
+// Streaming backward under a look-ahead mask: the query-major pass skips the 32-key blocks that lie beyond the limit of a whole 32-query wave,
+// and the key-major pass (relpos_attn_bwd_kv2_kernel) reads, for a tile of 64 keys, every query from the tile's first reachable 64-query chunk
+// on - without a mask. What it can meet unwritten is therefore a band to the right of the diagonal: row i, columns [32 floor(i / 32),
+// i + chunk + 192). Clearing that band of both matrices (<= ~0.3 KB per row and matrix) replaces clearing both whole matrices (2 x 129 MB per
+// layer at T' = 4000: 35 us). The d(pk) pass masks what it reads by the look-ahead rule itself.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_zero_band_kernel(T *__restrict__ pd, T *__restrict__ ds, long long rows, int Tn, int Tp, int chunk) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int i = (int)(row % Tn), lane = threadIdx.x & 63;
+    const int lo = (i / 32) * 32, hi = min(Tp, i + chunk + 192);      // (lo is a multiple of 32 elements: 16-byte aligned for both types; Tp % 8 == 0)
+    for (int c = lo + lane * VE; c < hi; c += 64 * VE) {
+        *reinterpret_cast<uint4 *>(pd + row * Tp + c) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(ds + row * Tp + c) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 __global__ void attn_zero_kernel(uint4 *p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -1478,10 +1500,16 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
     int part_keys = 0;
     const int nparts = attn_key_parts(B, Tn, H, causal, &part_keys);
     const int isplit = std::min(attn_dpk_isplit(B, Tn, H, causal, G), attn_dpk_max_isplit(Tn)), i_span = cdiv(cdiv(Tn, 64), isplit) * 64;
-    if (causal) {   // key blocks in the future of a whole query wave are skipped by bwd_q: their entries must read as zero
+    const bool short_path = sizeof(T) == 2 && Dh == 64 && Tn <= 256 && Tn >= 2 && nparts == 1 && attn_short_version() >= 2;
+    if (causal && (short_path || Tp % (16 / (int)sizeof(T)) != 0 || !attn_zero_band_enabled())) {
+        // key blocks in the future of a whole query wave are skipped by bwd_q: their entries must read as zero (the short key-major pass streams
+        // every query chunk past its keys: the whole matrices)
         const size_t used = align_up((size_t)B * H * Tn * Tp * sizeof(T), 16) / 16;   // `mat` is sized for fp32 io
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)pd, used);
         attn_zero_kernel<<<1024, 256, 0, st>>>((uint4 *)ds, used);
+    } else if (causal) {
+        const long long rows = (long long)B * H * Tn;
+        attn_zero_band_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(pd, ds, rows, Tn, Tp, std::max(causal, 1));
     }
     const size_t lds_q = tsasr_relpos_attn_lds_bytes();
     const unsigned short *kbq = (Tn <= 256 && sizeof(T) == 2) ? (const unsigned short *)g_attn_keepbits : nullptr;    // one-shot
