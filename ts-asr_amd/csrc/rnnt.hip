@@ -854,51 +854,68 @@ __global__ __launch_bounds__(256) void rnnt_lp_kernel(const float *__restrict__ 
                                                       int ldt, const int32_t *__restrict__ tlen,
                                                       const int32_t *__restrict__ ulen, RnntWs w, int B, int Tn, int U1,
                                                       int V, int ldl, int blank) {
-    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
     const int sub = threadIdx.x & 7;
-    if (row >= (long long)B * Tn * U1) return;  // whole 8-lane groups leave together
-    const int u = row % U1, t = (row / U1) % Tn, b = row / ((long long)U1 * Tn);
-    const float *rowp = logits + row * ldl;
+    const long long nrows = (long long)B * Tn * U1;
     if (V <= 32) {
-        // the benchmark's case (V = 29): ONE round trip - lengths, the cell's row (one float4 per lane) and its label are requested
-        // together, blank / label log-probabilities are picked out of the lanes' registers (a select + the same three DPP steps as the
-        // sums) instead of being re-read from the row after the label has arrived (lengths -> row -> label -> row[label]: four
-        // dependent round trips before)
-        const int tl = tlen[b], ul = ulen[b];
+        // the benchmark's case (V = 29): ONE round trip per cell - lengths, the cell's row (one float4 per lane) and its label are requested
+        // together, blank / label log-probabilities are picked out of the lanes' registers (a select + the same three DPP steps as the sums).
+        // Round 5: an 8-lane group walks LP_R cells (32 rows apart: a workgroup's loads stay contiguous 4 KB pieces) with all their requests
+        // in flight before the first one is used - one float4 per thread in flight left the kernel at 2.5 - 3 TB/s.
+        constexpr int LP_R = 4;
+        const long long row0 = (long long)blockIdx.x * (32 * LP_R) + (threadIdx.x >> 3);
         const int c = sub * 4;
-        const float4 x = *reinterpret_cast<const float4 *>(rowp + min(c, ldl - 4));
-        const int lab = targets[(size_t)b * ldt + min(u, max(ldt - 1, 0))];
-        const int Tb = min(max(tl, 1), Tn), Ub = min(max(ul, 0), U1 - 1);
-        if (t >= Tb || u > Ub) return;
-        const float xs[4] = {c + 0 < V ? x.x : NEG_INF, c + 1 < V ? x.y : NEG_INF, c + 2 < V ? x.z : NEG_INF, c + 3 < V ? x.w : NEG_INF};
-        float m = fmaxf(fmaxf(xs[0], xs[1]), fmaxf(xs[2], xs[3]));
-        m = fmaxf(m, dpp_mov<0xB1>(m));
-        m = fmaxf(m, dpp_mov<0x4E>(m));
-        m = fmaxf(m, dpp_mov<0x141>(m));
-        const int kl = min(max(lab, 0), V - 1);
-        float s = 0.f, vb = 0.f, vl = 0.f;
+        float4 x[LP_R];
+        int lab[LP_R], tl[LP_R], ul[LP_R], uu[LP_R], tt[LP_R], bb[LP_R];
+        bool in[LP_R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (c + j < V) s += __expf(xs[j] - m);
-            vb += (c + j == blank) ? xs[j] : 0.f;
-            vl += (c + j == kl) ? xs[j] : 0.f;
+        for (int k = 0; k < LP_R; ++k) {
+            const long long row = row0 + 32 * k;
+            in[k] = row < nrows;
+            const long long rc = in[k] ? row : nrows - 1;
+            uu[k] = (int)(rc % U1); tt[k] = (int)((rc / U1) % Tn); bb[k] = (int)(rc / ((long long)U1 * Tn));
+            x[k] = *reinterpret_cast<const float4 *>(logits + rc * ldl + min(c, ldl - 4));
+            tl[k] = tlen[bb[k]]; ul[k] = ulen[bb[k]];
+            lab[k] = targets[(size_t)bb[k] * ldt + min(uu[k], max(ldt - 1, 0))];
         }
-        s += dpp_mov<0xB1>(s);   vb += dpp_mov<0xB1>(vb);   vl += dpp_mov<0xB1>(vl);
-        s += dpp_mov<0x4E>(s);   vb += dpp_mov<0x4E>(vb);   vl += dpp_mov<0x4E>(vl);
-        s += dpp_mov<0x141>(s);  vb += dpp_mov<0x141>(vb);  vl += dpp_mov<0x141>(vl);
-        if (sub == 0) {
-            const float lse = m + __logf(s);
-            const size_t o = ws_at(w, b, t, u);
-            w.lse[o] = lse;
-            w.lpb[o] = vb - lse;
-            if (u < Ub) {
-                const float e = vl - lse;
-                w.lpe_out[o] = e;
-                w.lpe_in[ws_at(w, b, t, u + 1)] = e;
+#pragma unroll
+        for (int k = 0; k < LP_R; ++k) {
+            const int b = bb[k], t = tt[k], u = uu[k];
+            const int Tb = min(max(tl[k], 1), Tn), Ub = min(max(ul[k], 0), U1 - 1);
+            const bool live = in[k] && t < Tb && u <= Ub;      // (uniform over the 8-lane group; the DPP steps below run for every lane)
+            const float xs[4] = {c + 0 < V ? x[k].x : NEG_INF, c + 1 < V ? x[k].y : NEG_INF, c + 2 < V ? x[k].z : NEG_INF, c + 3 < V ? x[k].w : NEG_INF};
+            float m = fmaxf(fmaxf(xs[0], xs[1]), fmaxf(xs[2], xs[3]));
+            m = fmaxf(m, dpp_mov<0xB1>(m));
+            m = fmaxf(m, dpp_mov<0x4E>(m));
+            m = fmaxf(m, dpp_mov<0x141>(m));
+            const int kl = min(max(lab[k], 0), V - 1);
+            float sm = 0.f, vb = 0.f, vl = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c + j < V) sm += __expf(xs[j] - m);
+                vb += (c + j == blank) ? xs[j] : 0.f;
+                vl += (c + j == kl) ? xs[j] : 0.f;
+            }
+            sm += dpp_mov<0xB1>(sm);   vb += dpp_mov<0xB1>(vb);   vl += dpp_mov<0xB1>(vl);
+            sm += dpp_mov<0x4E>(sm);   vb += dpp_mov<0x4E>(vb);   vl += dpp_mov<0x4E>(vl);
+            sm += dpp_mov<0x141>(sm);  vb += dpp_mov<0x141>(vb);  vl += dpp_mov<0x141>(vl);
+            if (sub == 0 && live) {
+                const float lse = m + __logf(sm);
+                const size_t o = ws_at(w, b, t, u);
+                w.lse[o] = lse;
+                w.lpb[o] = vb - lse;
+                if (u < Ub) {
+                    const float e = vl - lse;
+                    w.lpe_out[o] = e;
+                    w.lpe_in[ws_at(w, b, t, u + 1)] = e;
+                }
             }
         }
         return;
     }
+    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (row >= nrows) return;  // whole 8-lane groups leave together
+    const int u = row % U1, t = (row / U1) % Tn, b = row / ((long long)U1 * Tn);
+    const float *rowp = logits + row * ldl;
     const int Tb = min(max(tlen[b], 1), Tn), Ub = min(max(ulen[b], 0), U1 - 1);
     if (t >= Tb || u > Ub) return;
     float m = NEG_INF;
@@ -1458,7 +1475,7 @@ int tsasr_rnnt_loss_fwd(const float *logits, const int32_t *targets, int ldt, co
     hipStream_t st = (hipStream_t)stream;
     RnntWs w = rnnt_carve(workspace, B, T, U1);
     const long long rows = (long long)B * T * U1;
-    rnnt_lp_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(logits, targets, ldt, tlen, ulen, w, B, T, U1, V, ldl, blank);
+    rnnt_lp_kernel<<<(unsigned)(V <= 32 ? (rows + 127) / 128 : (rows + 31) / 32), 256, 0, st>>>(logits, targets, ldt, tlen, ulen, w, B, T, U1, V, ldl, blank);
     if (int rc = launch_alphabeta(w, tlen, ulen, costs, B, T, U1, st)) return rc;
     TSASR_CHECK_LAUNCH("tsasr_rnnt_loss_fwd");
     return 0;
