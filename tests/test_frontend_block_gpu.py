@@ -179,7 +179,7 @@ def test_convblock_module_uses_fused_path():
 
 
 @pytest.mark.parametrize("B,T,F,Ci,causal", [(2, 37, 21, 128, False), (2, 37, 21, 128, True), (1, 500, 40, 128, False), (3, 10, 8, 64, True), (1, 2, 2, 128, False),
-                                             (2, 3, 3, 64, False), (4, 124, 40, 64, False), (2, 45, 40, 64, True)])
+                                             (2, 3, 3, 64, False), (4, 124, 40, 64, False), (2, 45, 40, 64, True), (16, 500, 40, 128, False)])
 def test_conv_implicit_gemm_equals_im2col_path(B, T, F, Ci, causal):
     """Front-end block 2's convolutions as implicit GEMMs (csrc/gemm.hip conv_s2_fwd / conv_s2_wgrad: the ring kernels' loader waves gather
     the 3x3 patch rows, padding rule folded into the address - SB/nnet/CNN.py:629-711 reflect / causal) against the im2col + GEMM path
