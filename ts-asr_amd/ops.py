@@ -17,11 +17,13 @@ from . import prof
 STATUS = {
     "joint_logits": "HIP", "rnnt_loss": "HIP", "layer_norm": "HIP", "bias_act_dropout": "HIP", "dropout_add": "HIP",
     "convmod_core": "HIP",
-    "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP",
+    "frontend_c1": "HIP", "frontend_im2col/col2im": "HIP (fp32 / other channel counts)",
+    "frontend block 1 (bf16)": "HIP (frontend_block.hip: convolutions and filter gradients on MFMA)",
+    "frontend block 2 (bf16, C_out = 128)": "HIP implicit GEMMs (conv_s2_fwd / conv_s2_wgrad / conv_s2_dgrad)",
     "matmul(bf16)": "HIP (gemm_bf16: fwd, dgrad, wgrad-into-arena)", "matmul(fp32 parity mode)": "HIP (gemm_f32: fp32 matrix cores; fwd, dgrad, wgrad)", "lstm(bf16 training)": "HIP persistent whole-sequence kernels (per-step kernels for other H)", "lstm(decoding / fp32 parity)": "HIP (lstm_f32: exact fp32, optional initial state)",
     "attention(fp32 parity, cross_attention injection)": "HIP (attention_f32: exact fp32)", "joint(fp32 parity)": "HIP (joint_f32)",
     "injection sum / prod": "HIP (inject)", "mix_sources": "HIP (dataio.hip)", "fbank": "HIP", "sentence_norm": "HIP",
-    "relpos_attention": "HIP (forward; backward = query-major, key-major, d(pk) and partial-sum kernels)",
+    "relpos_attention": "HIP (forward: everything-in-LDS kernel for T <= 256 and, per chunk of 256 keys, for long sequences in small batches, streaming kernel otherwise; backward = query-major, key-major, d(pk) and partial-sum kernels)",
     # What is NOT hand-written: shapes / modes none of the three recipes reaches. Each of these routes goes through lib_fallback(): counted in
     # LIB_FALLBACKS, announced once (warnings), refused with TsasrHipMissing when ops.STRICT_HIP (env TSASR_STRICT_HIP=1) is set.
     # tests/test_recipe_gpu.py asserts that a fit + evaluate of every recipe YAML leaves LIB_FALLBACKS empty.
