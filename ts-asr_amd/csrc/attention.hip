@@ -1094,9 +1094,12 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
                                                                   const T *__restrict__ dout, const T *__restrict__ pd,
                                                                   const T *__restrict__ ds, T *__restrict__ dqkv,
                                                                   T *__restrict__ qv_out /*[H][B*T][Dh] or NULL*/, int Tn, int Tp, int H,
-                                                                  int Dh, int causal) {
+                                                                  int Dh, int causal, int isplit, float *__restrict__ kv_part) {
+    // isplit > 1 (long sequences in small batches): blockIdx.x = key tile * isplit + part; part p takes the query chunks i_begin + 64 (p + isplit n)
+    // and leaves its fp32 share of (dK | dV) in kv_part [part][b][h][key][128] for relpos_attn_kv_merge_kernel. One workgroup per key tile walked
+    // every query from its keys on - 63 chunks for the first tile of a causal T' = 4000 utterance, 1 for the last, the launch as long as the longest.
     __shared__ __attribute__((aligned(16))) bf16_t xp[64 * KV2_LD], xs[64 * KV2_LD], ydo[64 * KV2_LD], yqu[64 * KV2_LD];
-    const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, jt = (int)blockIdx.x / isplit, part = (int)blockIdx.x - jt * isplit, j0 = jt * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int jhalf = wave & 1, dhalf = wave >> 1;
     const int D = H * Dh;
@@ -1133,8 +1136,9 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
         if (fast_d) request_t(i0n, std::true_type{});
         else request_t(i0n, std::false_type{});
     };
-    if (i_begin < Tn) request(i_begin);
-    for (int i0 = i_begin; i0 < Tn; i0 += 64) {
+    const int i_first = i_begin + 64 * part, i_step = 64 * isplit;
+    if (i_first < Tn) request(i_first);
+    for (int i0 = i_first; i0 < Tn; i0 += i_step) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1154,14 +1158,14 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
             st8(ydo + rr * KV2_LD + c, dov[it]);
             st8(yqu + rr * KV2_LD + c, a);
             // (Q + v) rows in the [H, B*T, Dh] layout of the d(pk) product: written once, by the workgroup of the first key block
-            if (qv_out && blockIdx.x == 0 && live && c < Dh) {
+            if (qv_out && jt == 0 && live && c < Dh) {
                 T *qo = qv_out + (((long long)h * gridDim.z + b) * Tn + i) * Dh + c;
                 if (fast_d) st8(qo, cv);
                 else
                     for (int e = 0; e < 8 && c + e < Dh; ++e) st1(qo + e, cv[e]);
             }
         }
-        if (i0 + 64 < Tn) request(i0 + 64);     // next chunk in flight during this chunk's MFMAs
+        if (i0 + i_step < Tn) request(i0 + i_step);     // next chunk in flight during this chunk's MFMAs
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {           // 16 queries per MFMA step
@@ -1180,6 +1184,18 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
             dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, b_s, dk, 0, 0, 0);
         }
     }
+    if (isplit > 1) {   // fp32 share of this part: [dK 64 | dV 64] per key (rows of 128 floats; dims beyond Dh hold zeros of the zero-padded operands)
+        if (jk < Tn) {
+            float *pp = kv_part + ((((long long)part * gridDim.z + b) * H + h) * Tn + jk) * 128;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * dhalf + 8 * q + 4 * hh;
+                *reinterpret_cast<float4 *>(pp + d) = make_float4(dk[4 * q], dk[4 * q + 1], dk[4 * q + 2], dk[4 * q + 3]);
+                *reinterpret_cast<float4 *>(pp + 64 + d) = make_float4(dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]);
+            }
+        }
+        return;
+    }
     if (jk < Tn) {   // accumulators: rows = head dims 32*dhalf + (g&3) + 8(g>>2) + 4hh, column = this lane's key; masked keys get zeros
         T *dkp = dqkv + ((long long)b * Tn + jk) * row_stride + (long long)h * 3 * Dh + Dh;
 #pragma unroll
@@ -1197,6 +1213,29 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv2_kernel(const T *__res
             }
         }
     }
+}
+
+// dK, dV of key (b, h, j) = sum over the parts of relpos_attn_bwd_kv2_kernel's fp32 shares, in part order; masked keys get zeros. 32 threads per key.
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_attn_kv_merge_kernel(const float *__restrict__ kv_part, const int32_t *__restrict__ key_lens, T *__restrict__ dqkv,
+                                                                   int B, int Tn, int H, int Dh, int isplit) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, key = gid >> 5;
+    const int d4 = (int)(gid & 31) * 4;      // 0 .. 124: dK dims 0 .. 63, then dV dims 0 .. 63
+    if (key >= (long long)B * H * Tn) return;
+    const int j = (int)(key % Tn), h = (int)((key / Tn) % H), b = (int)(key / ((long long)Tn * H));
+    const int len = key_lens ? min(max(key_lens[b], 1), Tn) : Tn;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < isplit; ++p) {
+        const float4 v = *reinterpret_cast<const float4 *>(kv_part + (((long long)p * B * H * Tn) + key) * 128 + d4);
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+    if (j >= len) a[0] = a[1] = a[2] = a[3] = 0.f;
+    const int which = d4 >> 6, d = d4 & 63;      // 0: dK, 1: dV
+    T *dst = dqkv + ((long long)b * Tn + j) * (3LL * H * Dh) + (long long)h * 3 * Dh + Dh + which * Dh + d;
+    if (d + 4 <= Dh && (Dh % 4) == 0) st4(dst, a[0], a[1], a[2], a[3]);
+    else
+        for (int e = 0; e < 4; ++e)
+            if (d + e < Dh) st1(dst + e, a[e]);
 }
 
 // d(pk)[r][h*Dh + d] = sum_b sum_i dS[b][h][i][j = r + i - (T-1)] * (q + v)[b][i][h][d]  - the gradient of the projected positional
@@ -1382,6 +1421,10 @@ static bool attn_chunk_enabled() {      // TSASR_ATTN_CHUNK=0: the streaming for
     static const bool on = [] { const char *e = getenv("TSASR_ATTN_CHUNK"); return !e || e[0] != '0'; }();
     return on;
 }
+static bool attn_kv_split_enabled() {      // TSASR_ATTN_KV_SPLIT=0: one workgroup per key tile in the streaming key-major pass (A/B)
+    static const bool on = [] { const char *e = getenv("TSASR_ATTN_KV_SPLIT"); return !e || e[0] != '0'; }();
+    return on;
+}
 static bool attn_zero_band_enabled() {      // TSASR_ATTN_ZERO_BAND=0: clear the whole P_d / dS matrices under a look-ahead mask (A/B, round 4's form)
     static const bool on = [] { const char *e = getenv("TSASR_ATTN_ZERO_BAND"); return !e || e[0] != '0'; }();
     return on;
@@ -1537,9 +1580,15 @@ static void launch_attn_bwd(const void *qkv, const void *pk, const float *bias_u
                                                                                                           nparts, part_keys);
     if (sizeof(T) == 2 && Dh == 64 && Tn <= 256 && Tn >= 2 && nparts == 1 && attn_short_version() >= 2)
         tsasr_attn_short_bwd_kv(qkv, bias_u, bias_v, key_lens, dout, pd, ds, dqkv, qv, B, Tn, Tp, H, causal, st);
-    else
-        relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64), H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
-                                                                              qv, Tn, Tp, H, Dh, causal);
+    else {
+        // few long utterances: four parts per key tile (interleaved query chunks: equal shares whatever the look-ahead mask), merged in part order;
+        // the shares live where the query-major pass's dQ shares were (already merged)
+        const int ks = (nparts > 1 && attn_kv_split_enabled() && attn_dq_part_bytes(B, Tn, H) >= (size_t)4 * B * H * Tn * 128 * sizeof(float)) ? 4 : 1;
+        relpos_attn_bwd_kv2_kernel<T><<<dim3(cdiv(Tn, 64) * ks, H, B), 256, 0, st>>>((const T *)qkv, bias_u, bias_v, key_lens, (const T *)dout, pd, ds, (T *)dqkv,
+                                                                                   qv, Tn, Tp, H, Dh, causal, ks, dq_part);
+        if (ks > 1)
+            relpos_attn_kv_merge_kernel<T><<<(unsigned)(((long long)B * H * Tn * 32 + 255) / 256), 256, 0, st>>>(dq_part, key_lens, (T *)dqkv, B, Tn, H, Dh, ks);
+    }
     if (g_dpk_defer) {   // queued: both passes run in tsasr_relpos_dpk_flush (workspace, key_lens and dpk stay alive until then)
         DpkJob j{ds, qv, key_lens, part, dpk, B, Tn, Tp, H, Dh, causal, bg, isplit, i_span, G * isplit, cdiv(R, 64),
                  sizeof(T) == 2 ? TSASR_BF16 : TSASR_F32, 0, cdiv(R, 64) * H * G * isplit, 0, std::min(1024, cdiv(R * H * 64, 256))};
