@@ -289,6 +289,39 @@ def test_convmod_core_full_width(ops, dtype, causal):
         assert rel < (2e-2 if lo else 2e-4), (name, rel)
 
 
+@pytest.mark.parametrize("B,Tn,K,causal,bias", [(3, 250, 31, False, True), (2, 125, 31, True, True), (1, 31, 31, False, False), (2, 77, 15, True, True),
+                                                (1, 1000, 31, True, False), (4, 33, 7, False, True), (2, 64, 3, False, True)])
+def test_convmod_one_launch_matches_pair(ops, monkeypatch, B, Tn, K, causal, bias):
+    """bf16 rows of D = 256: the one-launch-per-direction kernels (csrc/convmod.hip, convmod_*_fused_kernel) against the two / three-launch pair
+    they replace, same inputs: z, the saved statistics' consequences and dy2 BIT FOR BIT (c and dc are rounded where the pair stored them, the row
+    sums use the same lanes in the same order); the parameter gradients (summed per workgroup in another order, fp32) to 2e-5 relative."""
+    D = 256
+    g = torch.Generator().manual_seed(B * 1000 + Tn + K)
+    y2 = torch.randn(B, Tn, 2 * D, generator=g).bfloat16()
+    b2 = torch.randn(2 * D, generator=g) * 0.1 if bias else None
+    cw, cb = torch.randn(D, 1, K, generator=g) / K ** 0.5, torch.randn(D, generator=g) * 0.1
+    lw, lb = torch.randn(D, generator=g) * 0.1 + 1, torch.randn(D, generator=g) * 0.1
+    dz = torch.randn(B, Tn, D, generator=g).bfloat16().to(DEV)
+
+    def run(flag):
+        monkeypatch.setenv("TSASR_CONVMOD_FUSED", flag)
+        pg = [None if t is None else t.to(DEV).requires_grad_() for t in (y2, b2, cw, cb, lw, lb)]
+        z = ops.convmod_core(*pg, causal, 1e-5, 0.01)
+        z.backward(dz)
+        torch.cuda.synchronize()
+        return z.detach(), [None if t is None else t.grad for t in pg]
+
+    z1, g1 = run("1")
+    z0, g0 = run("0")
+    assert torch.equal(z1, z0)
+    assert torch.equal(g1[0], g0[0]), float((g1[0].float() - g0[0].float()).abs().max())
+    for a, r, name in zip(g1[1:], g0[1:], ("db2", "dcw", "dcb", "dlnw", "dlnb")):
+        if a is None:
+            continue
+        rel = float((a - r).norm() / r.norm())
+        assert rel < 2e-5, (name, rel)
+
+
 def test_ffn_and_layer_vs_reference(nn_, golden):
     g, x, lens, probe = block_inputs(golden)
     for tag, causal in (("layer", False), ("layer_causal", True)):

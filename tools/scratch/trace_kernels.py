@@ -1,6 +1,6 @@
 """Median duration per (kernel, grid) from a rocprofv3 kernel trace CSV; substring filters as arguments (scratch)."""
 import collections, csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[-1]
+f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[-1]
 pats = sys.argv[2:]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):

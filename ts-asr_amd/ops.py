@@ -229,6 +229,7 @@ _WG_ENABLED = True
 # speaker branch's small kernels waited for whole CUs to drain (13.39-13.46 ms per step; 96 CUs 13.16, 112: 13.12, 128: 13.09, 144: 13.28,
 # 192: 13.20). 0 = one workgroup per tile.
 _WG_EARLY_WGS = int(os.environ.get("TSASR_WG_EARLY_WGS", "-1"))
+_REDUCE_EARLY = os.environ.get("TSASR_REDUCE_EARLY", "1") != "0"
 _WG_EARLY_SLOTS = 0      # (2: the launch made beside another stream's kernels uses 64 KB of LDS - measured equal)
 
 
@@ -323,6 +324,13 @@ def wgrad_flush(hold=None):
     caller releases them once the consumer stream has joined it)."""
     done = _WG["params"]
     dpk_flush()      # queued d(pk) passes produce operands of the linear_pos weight gradients in this launch: they go first, same stream
+    if hold is not None and _REDUCE_EARLY and _DEFER["on"]:
+        # the early flush (beside another stream's backward): the partial-sum reductions queued so far go with it, IN FRONT of the long grouped
+        # launch - the reduction left for the end of backward (on the step's critical path) then covers the rest of the step only. The parked
+        # workspaces travel with the held operands (some were allocated on the other stream).
+        _reduce_flush("tsasr_reduce_flush")
+        hold.extend(_DEFER["keep"])
+        _DEFER["keep"] = []
     if done:
         ring = _WG["ring"]
         k, host, dev, _ = ring.acquire()
