@@ -879,7 +879,7 @@ def test_fp32_linear_runs_on_the_hip_gemm_and_equals_the_library(ops, monkeypatc
         assert float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max() + 1.0)
 
 
-@pytest.mark.parametrize("B,U,H", [(8, 21, 128), (8, 21, 256), (40, 9, 256), (32, 121, 512)])
+@pytest.mark.parametrize("B,U,H", [(8, 21, 128), (8, 21, 256), (40, 9, 256), (32, 121, 512), (1, 160, 512)])
 def test_lstm_hip_path_vs_oracle(ops, B, U, H):
     """bf16 predictor LSTM vs the oracle's explicit recurrence (oracle/tsasr_ref.lstm), fwd + bwd. H = 128 runs the per-step
     kernels, H in {256, 512} the persistent whole-sequence kernels (one and two 32-row batch groups, ragged last group; the
@@ -981,6 +981,58 @@ def test_lstm_persistent_kernels_survive_graph_replay_with_dirty_workspace():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(h, h_ref) and torch.equal(dgates, dg_ref)
+
+
+@pytest.mark.parametrize("U", [1, 2, 97, 640])
+def test_lstm_single_utterance_kernels_vs_exchange_groups(monkeypatch, U):
+    """B = 1 (the long-form configuration): the wave-autonomous recurrence (csrc/lstm.hip lstm_seq1_*: payload published into the
+    0xFFFF-pre-filled outputs, no counters, no barriers) against the exchange-group kernels on the same inputs. Forward: the same MFMA
+    chain in the same order - h, c and the activated gates BIT FOR BIT. Backward: the reduction over 4H runs as two halves instead of
+    four quarters (fp32), dgates to 2e-2 relative (bf16 values; a last-bit flip early in the recurrence is carried along). Then as a
+    replayed hipGraph over outputs left dirty (zeros: NOT the fill pattern) by the caller."""
+    from importlib import import_module
+    C = import_module("ts-asr_amd._capi")
+    B, H = 1, 512
+    g = torch.Generator().manual_seed(U)
+    gates0 = (torch.randn(B, U, H, 4, generator=g) * 0.5).to(DEV)
+    whh = (torch.randn(4 * H, H, generator=g) * 0.04).to(DEV).to(torch.bfloat16)
+    whhT = whh.t().contiguous()
+    dout = torch.randn(B, U, H, generator=g).to(DEV).to(torch.bfloat16)
+    lib = C.lib()
+    nb = lib.tsasr_lstm_seq_workspace_bytes(B, U, H)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    gates, c = torch.empty_like(gates0), torch.empty(B, U, H, device=DEV)
+    h, dgates = torch.empty(B, U, H, dtype=torch.bfloat16, device=DEV), torch.empty(B, U, 4 * H, dtype=torch.bfloat16, device=DEV)
+
+    def run():
+        gates.copy_(gates0)
+        C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh), B, U, H, C.BF16, C.ptr(ws), nb, C.stream_ptr()), "fwd")
+        C.check(lib.tsasr_lstm_seq_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), B, U, H, C.BF16, C.ptr(ws), nb,
+                                       C.stream_ptr()), "bwd")
+        torch.cuda.synchronize()
+        assert int(ws[:8].view(torch.int32)[1]) == 0      # the error word
+        return h.clone(), c.clone(), gates.clone(), dgates.clone()
+
+    monkeypatch.setenv("TSASR_LSTM_SEQ1", "0")
+    h0, c0, g0, d0 = run()
+    monkeypatch.setenv("TSASR_LSTM_SEQ1", "1")
+    h1, c1, g1, d1 = run()
+    assert torch.isfinite(h1.float()).all() and torch.isfinite(d1.float()).all()
+    assert torch.equal(h1, h0) and torch.equal(c1, c0) and torch.equal(g1, g0)
+    assert float((d1.float() - d0.float()).norm() / d0.float().norm()) < 2e-2
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gates.copy_(gates0)
+        C.check(lib.tsasr_lstm_seq_fwd(C.ptr(gates), C.ptr(c), C.ptr(h), C.ptr(whh), B, U, H, C.BF16, C.ptr(ws), nb, C.stream_ptr()), "fwd")
+        C.check(lib.tsasr_lstm_seq_bwd(C.ptr(gates), C.ptr(c), C.ptr(dout), C.ptr(dgates), C.ptr(whhT), B, U, H, C.BF16, C.ptr(ws), nb,
+                                       C.stream_ptr()), "bwd")
+    for _ in range(3):
+        ws.fill_(0xFF)
+        h.zero_()
+        dgates.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(h, h1) and torch.equal(dgates, d1)
 
 
 def test_fbank_and_sentence_norm_known_answers(nn_, ops):

@@ -215,7 +215,10 @@ __device__ __forceinline__ bool lq_wait(unsigned *ctr, unsigned target, unsigned
 template <int H, int BR>
 __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict__ gates, float *__restrict__ c, bf16_t *__restrict__ h,
                                                               const bf16_t *__restrict__ whh /*[4H,H]*/, bf16_t *xh /*[G][U][H/32][BR][32]*/,
-                                                              unsigned *sync, int B, int U) {
+                                                              unsigned *sync, int B, int U, int xcd) {
+    // xcd: the launch has 8 x the workgroups and group bg keeps those dealt to ONE XCD (workgroup n of a dispatch goes to XCD n mod 8): the
+    // exchange then stays inside one L2 instead of crossing the fabric. The other seven eighths leave at once.
+    if (xcd && (int)(blockIdx.x & 7) != (int)(blockIdx.y & 7)) return;
     constexpr int NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 32;
     static_assert(PP >= 1 && (BR & (BR - 1)) == 0 && BR <= 32, "BR in {8, 16, 32}");
     __shared__ __attribute__((aligned(16))) float pre[BR][LQ_UN * 4 + 4];     // [batch][unit*4 + gate]
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float *__restrict_
     __shared__ __attribute__((aligned(16))) bf16_t hl[(H / 32) * BR * 40];     // h_{t-1}: [unit block][batch row][32 + 8 pad]
     __shared__ int ok_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
+    const int wg = xcd ? blockIdx.x >> 3 : blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
     bf16_t *xh_g = xh + (size_t)bg * U * H * BR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xh_g, 0, U * H * BR * 2, 0x00020000);
@@ -341,7 +344,8 @@ template <int H, int BR>
 __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c,
                                                               const bf16_t *__restrict__ dout, bf16_t *__restrict__ dgates,
                                                               const bf16_t *__restrict__ whhT /*[H,4H]*/, bf16_t *xg /*[G][U][H/32][BR][128]*/,
-                                                              unsigned *sync, int B, int U) {
+                                                              unsigned *sync, int B, int U, int xcd) {
+    if (xcd && (int)(blockIdx.x & 7) != (int)(blockIdx.y & 7)) return;     // (see the forward kernel)
     constexpr int K4 = 4 * H, NWG = H / LQ_UN, PP = BR * 32 / 256, TILE = BR * 128;
     constexpr int XLD = 136;                                               // staged row: 128 bf16 + 8 pad (16-byte slots rotate per row)
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];         // 96 KB (also what keeps one workgroup per CU)
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) bf16_t dgt[BR][4 * LQ_UN];     // [batch][gate*32 + unit]: the published tile
     __shared__ int ok_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wg = blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
+    const int wg = xcd ? blockIdx.x >> 3 : blockIdx.x, bg = blockIdx.y, u0 = wg * LQ_UN, b0 = bg * BR;
     unsigned *ctr = sync + 2 * bg, *err = sync + 2 * bg + 1;
     bf16_t *xg_g = xg + (size_t)bg * U * K4 * BR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xg_g, 0, U * K4 * BR * 2, 0x00020000);
@@ -474,12 +478,367 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float *__res
     if (failed && tid == 0) dgates[((long long)min(b0, B - 1) * U) * K4 + u0] = (bf16_t)__builtin_nanf("");
 }
 
+// =====================================================================================================================
+// ONE utterance (B = 1: the long-form configuration, U ~ 2000 target tokens).
+//   With a single batch row the kernels above spend a step on their rendezvous, not on its 2 MFLOP: per step of the forward kernel
+//   (cycles at 2.4 GHz, B = 1, U = 1920) wait for the arrival counter 1920, exchange tile through LDS + MFMAs 1840, cell 545, publish +
+//   drain 680, outputs 290 = 2.2 us: a counter round trip, a payload round trip and a store acknowledgement in series, five
+//   workgroup barriers. What the exchange itself costs was measured on its skeleton (tools/scratch/xcc/ring_probe.hip: 16 workgroups
+//   publish 64 bytes each of a 1 KB row and poll the previous row until complete): 1920 cycles per step with agent-scope (write-through)
+//   stores, 920 with plain stores when the workgroups share an XCD - whose L2 then is the meeting point; across XCDs plain stores are
+//   never seen. Here (forward 4.2 -> 2.0 ms, backward 5.2 -> 2.7 ms at U = 1920):
+//   * 16 workgroups of 6 waves - 4 compute waves owning 8 hidden units each for the whole sequence (W_hh rows in registers as above), one
+//     POLLING wave, one LOADING wave - launched as 128 workgroups of which every eighth works: workgroup n of a dispatch runs on XCD
+//     n mod 8 (tools/scratch/xcc/xcc_probe.hip), so the sixteen share one L2. That placement is checked, not assumed: every workgroup
+//     posts its XCC_ID, and plain exchange stores are used only if all sixteen agree (lq1_same_xcd), agent-scope stores otherwise.
+//   * the payload carries its own arrival: h_t (forward) / dG_t (backward) are published straight into the OUTPUT tensors h [U, H] /
+//     dgates [U, 4H], which the launch pre-fills with the bf16 pattern 0xFFFF (a NaN no kernel here produces: conversions of finite
+//     values never give it, NaNs are quieted to 0x7FC0 | sign). The polling wave reads the row it needs with one agent-scope 16-byte
+//     load per lane (backward: four) until no 0xFFFF half is left in it - a piece caught half-written still shows one -, puts it into
+//     LDS, and ONE barrier per step hands it to the compute waves as MFMA B fragments. No counter, no drain, no second round trip.
+//   * the compute waves issue NO vector-memory loads: on gfx9 a wait for a load also waits for every store issued before it (loads and
+//     stores share vmcnt and complete out of order with respect to each other), and the waits the compiler placed at the loop's back edge
+//     cost a step 1100 - 1700 cycles. The loading wave fetches the step's operands four steps ahead (first-touch HBM reads) into an LDS
+//     ring, the polling wave has nothing but exchange rows in its queue.
+//   * every B column carries the same row (forward) / the even and odd columns the two halves of dG_{t+1} (backward: the 16 MFMA rows are
+//     8 units x the two halves of the reduction range, dh = D[unit][even] + D[8 + unit][odd], one cross-lane add), so the lanes of a
+//     16-lane group hold copies of the sums: each takes ONE unit, and the cell arithmetic is issued once per step instead of once per unit
+//     (a vector instruction costs 4 cycles whether 2 or 64 lanes matter).
+//   A row that never completes: the polling wave gives up after ~1 s, the workgroup raises the error word and leaves the 0xFFFF (NaN)
+//   pattern in what it did not write (the others then time out the same way): the step's finite check rejects the update, ops.lstm
+//   raises on the error word.
+// =====================================================================================================================
+#define LQ1_SPINS (1u << 21)
+#define LQ1_WGS 16
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_umax16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ bool has_unwritten(u32x4 v) {   // any of the eight halves still 0xFFFF
+    const unsigned m = pk_umax16(pk_umax16(v.x, v.y), pk_umax16(v.z, v.w));
+    return (m & 0xFFFFu) == 0xFFFFu || m >= 0xFFFF0000u;
+}
+__device__ __forceinline__ float lane_value(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+__global__ void fill_words_kernel(unsigned *p, size_t n, unsigned v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+#ifdef LQ_PROFILE
+#define LQ1_INIT() long long q_acc[4] = {0, 0, 0, 0}, q_prev = clock64()
+#define LQ1_STAMP(i) do { const long long n_ = clock64(); q_acc[i] += n_ - q_prev; q_prev = n_; } while (0)
+#define LQ1_DUMP() do { if (tid == 0 && blockIdx.x == 24) for (int i = 0; i < 4; ++i) reinterpret_cast<long long *>(sync + 32)[i] = q_acc[i]; } while (0)
+#else
+#define LQ1_INIT()
+#define LQ1_STAMP(i)
+#define LQ1_DUMP()
+#endif
+// Do all LQ1_WGS working workgroups sit on one XCD (one L2)? Then their exchange stores need no write-through: measured on the exchange skeleton
+// (tools/scratch/xcc/ring_probe.hip, 16 workgroups, 1 KB row) 920 cycles per step with plain stores against 1920 with agent-scope stores - and
+// plain stores are NOT seen from another XCD. Decided at run time from the hardware's XCC_ID, never assumed: every workgroup posts its id
+// (agent scope), reads all of them, and uses plain stores only if they are equal. ids: the EVEN words of the sync block's second half (the odd
+// words of the block are error words to the host, include/tsasr_hip.h), zeroed by the launch.
+__device__ __forceinline__ bool lq1_same_xcd(unsigned *ids, int w, int *flag_lds) {
+    if (threadIdx.x == 0) {
+        const unsigned mine = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu) + 1u;
+        __hip_atomic_store(ids + 2 * w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int i = 0; i < LQ1_WGS && same; ++i) {
+            unsigned v = 0, spins = 0;
+            while ((v = __hip_atomic_load(ids + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(1);
+            same = (v == mine);      // (a workgroup that never shows up: agent-scope stores; the row polls report it)
+        }
+        *flag_lds = same ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+
+// one 16-byte piece per lane of a published row, polled until complete; false after LQ1_SPINS rounds
+__device__ __forceinline__ bool lq1_poll_row(const __amdgpu_buffer_rsrc_t rs, int byte_off, u32x4 &row) {
+    unsigned spins = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");      // (the load is re-issued every round)
+        row = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+        if (__builtin_amdgcn_ballot_w64(has_unwritten(row)) == 0) return true;
+        if (++spins > LQ1_SPINS) return false;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(384, 1) void lstm_seq1_fwd_kernel(float *__restrict__ gates /*[U][H][4]*/, float *__restrict__ c /*[U][H]*/, bf16_t *h /*[U][H], 0xFFFF-filled*/,
+                                                               const bf16_t *__restrict__ whh /*[4H,H]*/, unsigned *sync, int U) {
+    static_assert(H == 512 && H == LQ1_WGS * 32, "one 16-byte piece of h_{t-1} per lane; 16 workgroups x 4 waves x 8 units");
+    constexpr int KS2 = H / 32;
+    if (blockIdx.x & 7) return;
+    __shared__ __attribute__((aligned(16))) bf16_t hbuf[2][H];
+    __shared__ __attribute__((aligned(16))) float gxr[4][32 * 4];      // x-part pre-activations of the workgroup's 32 units, rows t .. t + 2
+    __shared__ int fail_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kg = lane >> 4;
+    const int ub = (blockIdx.x >> 3) * 32;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(h, 0, U * H * 2, 0x00020000);
+    if (tid == 0) fail_flag = 0;
+    __shared__ int same_flag;
+    const bool one_l2 = lq1_same_xcd(sync + 32, blockIdx.x >> 3, &same_flag);
+    if (wave == 5) {
+        // the loading wave (see the header): row t is in slot t & 3 of the LDS ring in front of the barrier of the step that reads it
+        const int l32 = lane & 31;
+        auto row = [&](int t) { return *reinterpret_cast<const float4 *>(gates + ((long long)min(t, U - 1) * H + ub + l32) * 4); };
+        const float4 a0 = row(0);
+        float4 r[4] = {row(1), row(2), row(3), row(4)};      // four steps ahead (first-touch HBM reads: ~2 us, longer than a step)
+        if (lane < 32) *reinterpret_cast<float4 *>(&gxr[0][l32 * 4]) = a0;
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 1; t < U; t += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tt = t + k;
+                if (tt < U) {
+                    if (lane < 32) *reinterpret_cast<float4 *>(&gxr[tt & 3][l32 * 4]) = r[k];
+                    r[k] = row(tt + 4);
+                    __syncthreads();
+                    if (fail_flag) return;
+                }
+            }
+        }
+        return;
+    }
+    __syncthreads();
+    if (wave == 4) {      // the polling wave: nothing but the exchange rows in its memory queue
+#pragma unroll 1
+        for (int t = 1; t < U; ++t) {
+            u32x4 row;
+            if (lq1_poll_row(rs, ((t - 1) * H + 8 * lane) * 2, row)) *reinterpret_cast<u32x4 *>(hbuf[t & 1] + 8 * lane) = row;
+            else if (lane == 0) fail_flag = 1;
+            __syncthreads();      // (the buffers alternate: step t + 1's write cannot overtake a wave still reading step t's row)
+            if (fail_flag) break;
+        }
+        if (fail_flag && lane == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int u0 = ub + 8 * wave;      // this wave's eight units
+    // A operand: row m of row block rb = gate (m & 3) of unit u0 + 4 rb + (m >> 2); every B column carries the one batch row, so every lane of
+    // a 16-lane group ends up with the four gates of unit u0 + 4 rb + kg
+    bf16x8 af[2][KS2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const bf16_t *wrow = whh + ((long long)(m16 & 3) * H + u0 + 4 * rb + (m16 >> 2)) * H;
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) af[rb][s] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * s + 8 * kg);
+    }
+    // Every B column is the same row, so the lanes of a 16-lane group all hold the same accumulators: lane (m16 = rb, kg) finishes unit
+    // u0 + 4 rb + kg from row block rb - the cell arithmetic runs ONCE per wave-instruction instead of once per row block (a vector
+    // instruction is 4 cycles whether 2 or 64 lanes matter; 2 x ~50 of them were a quarter of the step)
+    const int rbl = m16 & 1, ulane = 8 * wave + 4 * rbl + kg;      // this lane's unit within the workgroup (lanes m16 >= 2: duplicates, never stored)
+    float cprev = 0.f;
+    LQ1_INIT();
+#pragma unroll 1
+    for (int t = 0; t < U; ++t) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        LQ1_STAMP(3);
+        if (t > 0) {
+            __syncthreads();
+            if (fail_flag) break;
+        }
+        LQ1_STAMP(0);
+        const float4 gx = *reinterpret_cast<const float4 *>(&gxr[t & 3][ulane * 4]);
+        if (t > 0) {
+            const bf16_t *hb = hbuf[t & 1];
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(hb + 32 * s + 8 * kg);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][s], b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][s], b, acc[1], 0, 0, 0);
+            }
+        }
+        const float p0 = rbl ? acc[1][0] : acc[0][0], p1 = rbl ? acc[1][1] : acc[0][1], p2 = rbl ? acc[1][2] : acc[0][2], p3 = rbl ? acc[1][3] : acc[0][3];
+        const float gi = sigm(gx.x + p0), gf = sigm(gx.y + p1), gg = tanh_fast(gx.z + p2), go = sigm(gx.w + p3);
+        const float cn = gf * cprev + gi * gg;
+        cprev = cn;
+        const float hv = go * tanh_fast(cn);
+        if (m16 < 2) {
+            // eight 2-byte stores of one instruction = the wave's 16-byte piece of h_t; a reader that catches it half-written still sees 0xFFFF
+            // halves and polls again
+            if (one_l2) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)hv), rs, (t * H + ub + ulane) * 2, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)hv), rs, (t * H + ub + ulane) * 2, 0, 16);
+            // the step's other outputs (kept for the backward): nobody waits for them
+            *reinterpret_cast<float4 *>(gates + ((long long)t * H + ub + ulane) * 4) = make_float4(gi, gf, gg, go);
+            c[(long long)t * H + ub + ulane] = cn;
+        }
+        LQ1_STAMP(2);
+    }
+    LQ1_DUMP();
+}
+
+template <int H>
+__global__ __launch_bounds__(384, 1) void lstm_seq1_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c, const bf16_t *__restrict__ dout,
+                                                               bf16_t *dgates /*[U][4H], 0xFFFF-filled*/, const bf16_t *__restrict__ whhT /*[H,4H]*/, unsigned *sync, int U) {
+    static_assert(H == 512 && H == LQ1_WGS * 32, "four 16-byte pieces of dG_{t+1} per lane; 16 workgroups x 4 waves x 8 units");
+    constexpr int K4 = 4 * H, KH = K4 / 2, KS = KH / 32;
+    if (blockIdx.x & 7) return;
+    __shared__ __attribute__((aligned(16))) bf16_t gbuf[2][K4];
+    // cell operands of the workgroup's 32 units, a four-slot ring filled by the loading wave (see the forward kernel): activated gates, c_t, c_{t-1}, dout
+    __shared__ __attribute__((aligned(16))) float opg[4][32 * 4], opc[4][32], opp[4][32];
+    __shared__ __attribute__((aligned(16))) bf16_t opd[4][32];
+    __shared__ int fail_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m16 = lane & 15, kg = lane >> 4;
+    const int ub = (blockIdx.x >> 3) * 32;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dgates, 0, U * K4 * 2, 0x00020000);
+    if (tid == 0) fail_flag = 0;
+    __shared__ int same_flag;
+    const bool one_l2 = lq1_same_xcd(sync + 32, blockIdx.x >> 3, &same_flag);
+    if (wave == 5) {      // the loading wave: step t's operands are in slot t & 3 in front of the barrier of step t, fetched two steps ahead
+        const int l32 = lane & 31;
+        auto fetch = [&](int t, float4 &g, float &cn, float &cp, bf16_t &dd) {
+            t = max(t, 0);
+            g = *reinterpret_cast<const float4 *>(gates + ((long long)t * H + ub + l32) * 4);
+            cn = c[(long long)t * H + ub + l32];
+            cp = c[(long long)max(t - 1, 0) * H + ub + l32];
+            dd = dout[(long long)t * H + ub + l32];
+        };
+        auto put = [&](int t, const float4 &g, float cn, float cp, bf16_t dd) {
+            if (lane < 32) {
+                *reinterpret_cast<float4 *>(&opg[t & 3][l32 * 4]) = g;
+                opc[t & 3][l32] = cn;
+                opp[t & 3][l32] = t > 0 ? cp : 0.f;
+                opd[t & 3][l32] = dd;
+            }
+        };
+        float4 g0, g[4]; float cn0, cn[4], cp0, cp[4]; bf16_t d0, d[4];
+        fetch(U - 1, g0, cn0, cp0, d0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fetch(U - 2 - k, g[k], cn[k], cp[k], d[k]);      // four steps ahead (see the forward kernel)
+        put(U - 1, g0, cn0, cp0, d0);
+        __syncthreads();
+#pragma unroll 1
+        for (int t = U - 2; t >= 0; t -= 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tt = t - k;
+                if (tt >= 0) {
+                    put(tt, g[k], cn[k], cp[k], d[k]);
+                    fetch(tt - 4, g[k], cn[k], cp[k], d[k]);
+                    __syncthreads();
+                    if (fail_flag) return;
+                }
+            }
+        }
+        return;
+    }
+    __syncthreads();
+    if (wave == 4) {      // the polling wave: the row dG_{t+1} is 4 KB = four 16-byte pieces per lane, requested together every round
+#pragma unroll 1
+        for (int t = U - 2; t >= 0; --t) {
+            u32x4 row[4];
+            unsigned spins = 0;
+            bool ok = true;
+            for (;;) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((t + 1) * K4 + (64 * q + lane) * 8) * 2, 0, 16);
+                const bool bad = has_unwritten(row[0]) || has_unwritten(row[1]) || has_unwritten(row[2]) || has_unwritten(row[3]);
+                if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
+                if (++spins > LQ1_SPINS) { ok = false; break; }
+            }
+            if (ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4 *>(gbuf[t & 1] + (64 * q + lane) * 8) = row[q];
+            } else if (lane == 0) fail_flag = 1;
+            __syncthreads();
+            if (fail_flag) break;
+        }
+        if (fail_flag && lane == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int uw = ub + 8 * wave;      // this wave's eight units
+    // A operand: row m = unit uw + (m & 7) of W_hh^T over half (m >> 3) of the reduction range [0, 4H) (gate-major, as dgates rows are laid out);
+    // B column n carries half (n & 1) of dG_{t+1}: D[u][0] + D[8 + u][1] is the full sum
+    bf16x8 af[KS];
+    {
+        const bf16_t *wrow = whhT + (long long)(uw + (m16 & 7)) * K4 + (m16 >> 3) * KH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * s + 8 * kg);
+    }
+    // The even B columns all carry the first half of dG_{t+1}, the odd ones the second: lane (n = 2 r, kg = k') holds in accumulator register r
+    // the first-half sum of unit 4 k' + r, lane (n = 2 r + 1, kg = k' + 2) = that lane + 33 the second-half sum in the same register. Every lane
+    // picks "its" register, one cross-lane add finishes the sum, and the cell arithmetic runs ONCE per wave-instruction, a unit per lane
+    // (lanes 0, 2, 4, 6, 16, 18, 20, 22), instead of four times in two lanes.
+    const int rsel = (m16 >> 1) & 3, ul = 8 * wave + 4 * (kg & 1) + rsel;
+    const bool owner = (m16 & 1) == 0 && kg < 2;
+    float dcar = 0.f;
+    LQ1_INIT();
+#pragma unroll 1
+    for (int t = U - 1; t >= 0; --t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const bool last = (t == U - 1);
+        LQ1_STAMP(3);
+        if (!last) {
+            __syncthreads();
+            if (fail_flag) break;
+        }
+        LQ1_STAMP(0);
+        const float4 g4 = *reinterpret_cast<const float4 *>(&opg[t & 3][ul * 4]);
+        const float cnv = opc[t & 3][ul], cpv = opp[t & 3][ul], dov = (float)opd[t & 3][ul];
+        if (!last) {
+            const bf16_t *gb = gbuf[t & 1] + (m16 & 1) * KH + 8 * kg;
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {      // two chains: a dependent 16x16x32 MFMA issues every 16 cycles
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], *reinterpret_cast<const bf16x8 *>(gb + 32 * s), acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s + 1], *reinterpret_cast<const bf16x8 *>(gb + 32 * s + 32), acc2, 0, 0, 0);
+            }
+            acc += acc2;
+        }
+        const float part = rsel == 0 ? acc[0] : rsel == 1 ? acc[1] : rsel == 2 ? acc[2] : acc[3];
+        float other;      // (inline asm: hipcc (ROCm 7.2) folded several __builtin_amdgcn_ds_bpermute of different registers into one)
+        asm volatile("s_nop 1\n\tds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(other) : "v"(((lane + 33) & 63) * 4), "v"(part));
+        const float dhr = part + other;
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tanh_fast(cnv);
+        const float dh = dov + (last ? 0.f : dhr);
+        const float dc = dh * go * (1.f - tc * tc) + dcar;
+        const float dgi = dc * gg * gi * (1.f - gi), dgf = dc * cpv * gf * (1.f - gf), dgg = dc * gi * (1.f - gg * gg), dgo = dh * tc * go * (1.f - go);
+        dcar = dc * gf;
+        if (owner) {      // 2-byte stores, eight lanes per gate = the wave's 16-byte piece of that gate's row (see the forward kernel)
+            const int o = (t * K4 + ub + ul) * 2;
+            const unsigned short v0 = __builtin_bit_cast(unsigned short, (bf16_t)dgi), v1 = __builtin_bit_cast(unsigned short, (bf16_t)dgf),
+                                 v2 = __builtin_bit_cast(unsigned short, (bf16_t)dgg), v3 = __builtin_bit_cast(unsigned short, (bf16_t)dgo);
+            if (one_l2) {
+                __builtin_amdgcn_raw_buffer_store_b16(v0, rs, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(v1, rs, o + 2 * H, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(v2, rs, o + 4 * H, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(v3, rs, o + 6 * H, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b16(v0, rs, o, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b16(v1, rs, o + 2 * H, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b16(v2, rs, o + 4 * H, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b16(v3, rs, o + 6 * H, 0, 16);
+            }
+        }
+        LQ1_STAMP(2);
+    }
+    LQ1_DUMP();
+}
+
+static bool lq_seq1(int B, int U, int H) {      // TSASR_LSTM_SEQ1=0: the exchange-group kernels for one utterance too (A/B)
+    const char *e = getenv("TSASR_LSTM_SEQ1");      // (read per call: the tests run both routes in one process)
+    return (!e || e[0] != '0') && B == 1 && H == 512 && (long long)U * 4 * H * 2 < (1ll << 31);
+}
+static void fill_async(void *p, size_t bytes, unsigned v, hipStream_t st) {   // bytes % 4 == 0
+    const size_t n = bytes / 4;
+    fill_words_kernel<<<(unsigned)std::min<size_t>(1024, (n + 255) / 256), 256, 0, st>>>((unsigned *)p, n, v);
+}
+
 #define LQ_BR 16   // batch rows per exchange group
 // B <= 8 (long-form, one utterance per GPU): groups of 8 rows - the exchange tile a workgroup pulls per step halves (backward: 64 -> 32 KB)
 static int lq_br(int B) {
     static const int forced = 0;
     if (forced == 8 || forced == 16) return forced;
     return B <= 8 ? 8 : LQ_BR;
+}
+
+static int lq_one_xcd() {      // TSASR_LSTM_XCD=1: every exchange group on one XCD (A/B)
+    static const int v = [] { const char *e = getenv("TSASR_LSTM_XCD"); return e && e[0] == '1' ? 1 : 0; }();
+    return v;
 }
 
 // Zero-fill by a kernel, NOT hipMemsetAsync: a memset node captured into a hipGraph wrote stale host bytes instead of zeros from
@@ -498,7 +857,8 @@ static void launch_seq_fwd_br(float *gates, float *c, void *h, const void *whh, 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     zero_async(ws, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    const int xcd = lq_one_xcd();
+    kern<<<dim3((H / LQ_UN) * (xcd ? 8 : 1), cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (bf16_t *)(ws + 256), (unsigned *)ws, B, U, xcd);
 }
 template <int H>
 static void launch_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, int U, char *ws, hipStream_t st) {
@@ -511,7 +871,8 @@ static void launch_seq_bwd_br(const float *gates, const float *c, const void *do
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     zero_async(ws, 256, st);
-    kern<<<dim3(H / LQ_UN, cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U);
+    const int xcd = lq_one_xcd();
+    kern<<<dim3((H / LQ_UN) * (xcd ? 8 : 1), cdiv(B, BR)), 256, 96 * 1024, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (bf16_t *)(ws + 256), (unsigned *)ws, B, U, xcd);
 }
 template <int H>
 static void launch_seq_bwd(const float *gates, const float *c, const void *dout, void *dgates, const void *whhT, int B, int U, char *ws, hipStream_t st) {
@@ -646,7 +1007,11 @@ int tsasr_lstm_seq_fwd(float *gates, float *c, void *h, const void *whh, int B, 
     hipStream_t st = (hipStream_t)stream;
     if (seq_persistent_ok(B, H, io_dtype)) {
         TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_lstm_seq_workspace_bytes(B, U, H), "tsasr_lstm_seq_fwd: workspace too small");
-        if (H == 512) launch_seq_fwd<512>(gates, c, h, whh, B, U, (char *)workspace, st);
+        if (lq_seq1(B, U, H)) {
+            zero_async(workspace, 256, st);
+            fill_async(h, (size_t)U * H * sizeof(bf16_t), 0xFFFFFFFFu, st);
+            lstm_seq1_fwd_kernel<512><<<8 * LQ1_WGS, 384, 0, st>>>(gates, c, (bf16_t *)h, (const bf16_t *)whh, (unsigned *)workspace, U);
+        } else if (H == 512) launch_seq_fwd<512>(gates, c, h, whh, B, U, (char *)workspace, st);
         else launch_seq_fwd<256>(gates, c, h, whh, B, U, (char *)workspace, st);
         TSASR_CHECK_LAUNCH("tsasr_lstm_seq_fwd");
         return 0;
@@ -665,7 +1030,11 @@ int tsasr_lstm_seq_bwd(const float *gates, const float *c, const void *dout, voi
     TSASR_CHECK_ARG(workspace && workspace_bytes >= tsasr_lstm_seq_workspace_bytes(B, U, H), "tsasr_lstm_seq_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (seq_persistent_ok(B, H, io_dtype)) {
-        if (H == 512) launch_seq_bwd<512>(gates, c, dout, dgates, whhT, B, U, (char *)workspace, st);
+        if (lq_seq1(B, U, H)) {
+            zero_async(workspace, 256, st);
+            fill_async(dgates, (size_t)U * 4 * H * sizeof(bf16_t), 0xFFFFFFFFu, st);
+            lstm_seq1_bwd_kernel<512><<<8 * LQ1_WGS, 384, 0, st>>>(gates, c, (const bf16_t *)dout, (bf16_t *)dgates, (const bf16_t *)whhT, (unsigned *)workspace, U);
+        } else if (H == 512) launch_seq_bwd<512>(gates, c, dout, dgates, whhT, B, U, (char *)workspace, st);
         else launch_seq_bwd<256>(gates, c, dout, dgates, whhT, B, U, (char *)workspace, st);
         TSASR_CHECK_LAUNCH("tsasr_lstm_seq_bwd");
         return 0;
