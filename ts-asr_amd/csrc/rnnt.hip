@@ -353,8 +353,11 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_j;
 __device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // ---- X: ddec + head-weight slabs ------------------------------------------------------------
+#ifndef JBX_OCC
+#define JBX_OCC 1   // workgroups of joint_bwd_x_kernel a CU is meant to hold (lab builds: -DKB=2 -DJBX_OCC=2)
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void joint_bwd_x_kernel(
+__global__ __launch_bounds__(256, JBX_OCC) void joint_bwd_x_kernel(
     const float *__restrict__ dlogits, const T *__restrict__ enc, const T *__restrict__ dec,
     const float *__restrict__ W, T *__restrict__ ddec, float *__restrict__ slab_w /*[B*nut][32][J]*/,
     float *__restrict__ slab_b /*[B*nut][32]*/, const int32_t *__restrict__ tlen, const int32_t *__restrict__ ulen,
@@ -1384,7 +1387,7 @@ static int joint_tsplit(int B, int T, int U1, int J) {
     static const int forced = [] { const char *e = getenv("TSASR_JOINT_TSPLIT"); return e ? atoi(e) : 0; }();
     if (forced > 0) return std::min(forced, 4);
     const long long wgs = (long long)B * cdiv(U1, 32) * cdiv(J / 32, 4 * KB);
-    int ts = (int)std::min<long long>(4, device_cu_count_rnnt() / std::max<long long>(wgs, 1));
+    int ts = (int)std::min<long long>(4, (long long)JBX_OCC * device_cu_count_rnnt() / std::max<long long>(wgs, 1));
     while (ts > 1 && T / ts < 32) --ts;
     return std::max(ts, 1);
 }
