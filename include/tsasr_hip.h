@@ -179,6 +179,10 @@ int tsasr_conv3x3s2_fwd(const void *x, const void *Wm, const float *b1, const vo
 size_t tsasr_conv3x3s2_wgrad_workspace_bytes(int B, int T, int F, int Ci);
 int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* the same with the 3x3 gradient in the reference's parameter layout dW1 [128][Ci][kF][kT] (torch Conv2d weight, SB/nnet/CNN.py:629-711): added to
+ * the parameter's gradient as it is */
+int tsasr_conv3x3s2_wgrad_filters(const void *dy1, const void *dy2, const void *x, float *dW1, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 size_t tsasr_conv3x3s2_dgrad_plan_bytes(int B, int T, int F, int causal);
 int tsasr_conv3x3s2_dgrad_plan(int B, int T, int F, int causal, void *plan_host, size_t plan_bytes);
 int tsasr_conv3x3s2_dgrad(const void *dy1, const void *dy2, const void *Wm, const void *W2, void *dx, int B, int T, int F, int Ci, int Co, int causal,

@@ -69,6 +69,7 @@ _PROTOS = {
     "tsasr_conv3x3s2_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "tsasr_conv3x3s2_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "tsasr_conv3x3s2_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "tsasr_conv3x3s2_wgrad_filters": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "tsasr_conv3x3s2_dgrad_plan_bytes": (c_size_t, [c_int] * 4),
     "tsasr_conv3x3s2_dgrad_plan": (c_int, [c_int] * 4 + [c_void_p, c_size_t]),
     "tsasr_conv3x3s2_dgrad": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),

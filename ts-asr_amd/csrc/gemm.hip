@@ -1634,8 +1634,32 @@ size_t tsasr_conv3x3s2_wgrad_workspace_bytes(int B, int T, int F, int Ci) {
 }
 /* dWm [128, 9*Ci] = dy1^T . patches(x), dW2 [128, Ci] = dy2^T . centre tap (fp32, OVERWRITTEN; the workspace holds the split-K slabs, added
  * in fixed order by two small launches). dy1, dy2 [P, 128] bf16. */
+// dW1 [co][ci][kf][kt] = sum_z slab[z][co][(kt * 3 + kf) * Ci + ci]  (fixed order): the 3x3 filter gradient in the reference's parameter layout
+__global__ __launch_bounds__(256) void conv_filter_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dW, int Ci, int nslab, long long slab_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // index in the slabs' order [co][(kt, kf)][ci]: coalesced reads of every slab, one scattered store
+    if (i >= 128 * 9 * Ci) return;
+    const int ci = i % Ci, tap = (i / Ci) % 9, co = i / (9 * Ci), kt = tap / 3, kf = tap % 3;
+    float a = 0.f;
+    for (int z = 0; z < nslab; ++z) a += slab[(long long)z * slab_stride + i];
+    dW[((long long)co * Ci + ci) * 9 + kf * 3 + kt] = a;
+}
+
+static int conv3x3s2_wgrad_impl(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                                void *workspace, size_t workspace_bytes, void *stream, bool filter_layout);
+
 int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
                           void *workspace, size_t workspace_bytes, void *stream) {
+    return conv3x3s2_wgrad_impl(dy1, dy2, x, dWm, dW2, B, T, F, Ci, Co, causal, workspace, workspace_bytes, stream, false);
+}
+/* The same, the 3x3 gradient written as the reference keeps the parameter: dW1 [128][Ci][kF = 3][kT = 3] (SB/nnet/CNN.py Conv2d weight) - the caller
+ * adds it to the parameter's gradient as it is (no permuting copy). */
+int tsasr_conv3x3s2_wgrad_filters(const void *dy1, const void *dy2, const void *x, float *dW1, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    return conv3x3s2_wgrad_impl(dy1, dy2, x, dW1, dW2, B, T, F, Ci, Co, causal, workspace, workspace_bytes, stream, true);
+}
+
+static int conv3x3s2_wgrad_impl(const void *dy1, const void *dy2, const void *x, float *dWm, float *dW2, int B, int T, int F, int Ci, int Co, int causal,
+                                void *workspace, size_t workspace_bytes, void *stream, bool filter_layout) {
     TSASR_CHECK_ARG(dy1 && dy2 && x && dWm && dW2 && workspace, "tsasr_conv3x3s2_wgrad: null pointer");
     TSASR_CHECK_ARG(B > 0 && T >= 2 && F >= 2 && Co == 128 && Ci % 64 == 0 && Ci >= 64 && Ci <= 128, "tsasr_conv3x3s2_wgrad: unsupported shape (Ci=%d Co=%d)", Ci, Co);
     TSASR_CHECK_ARG(workspace_bytes >= tsasr_conv3x3s2_wgrad_workspace_bytes(B, T, F, Ci), "tsasr_conv3x3s2_wgrad: workspace too small");
@@ -1652,7 +1676,8 @@ int tsasr_conv3x3s2_wgrad(const void *dy1, const void *dy2, const void *x, float
     conv_s2_wgrad_kernel<<<(unsigned)((9 * Ci / 64) * 2 * z1), RING_THREADS, lds, st>>>((const bf16_t *)dy1, (const bf16_t *)x, slab1, g, P, 0, 9 * Ci, kc1, z1);
     conv_s2_wgrad_kernel<<<(unsigned)((Ci / 64) * 2 * z2), RING_THREADS, lds, st>>>((const bf16_t *)dy2, (const bf16_t *)x, slab2, g, P, (causal ? 7 : 4) * Ci, Ci, kc2, z2);
     // the split-K slabs are added right away, in fixed order (the caller permutes dWm into the reference's filter layout next)
-    gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * 9 * Ci / 4, 256), 256, 0, st>>>(slab1, dWm, 128, 9 * Ci, 9 * Ci, z1, (long long)128 * 9 * Ci, 0);
+    if (filter_layout) conv_filter_reduce_kernel<<<(unsigned)cdiv(128 * 9 * Ci, 256), 256, 0, st>>>(slab1, dWm, Ci, z1, (long long)128 * 9 * Ci);
+    else gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * 9 * Ci / 4, 256), 256, 0, st>>>(slab1, dWm, 128, 9 * Ci, 9 * Ci, z1, (long long)128 * 9 * Ci, 0);
     gemm_slab_reduce_kernel<<<(unsigned)cdiv(128 * Ci / 4, 256), 256, 0, st>>>(slab2, dW2, 128, Ci, Ci, z2, (long long)128 * Ci, 0);
     TSASR_CHECK_LAUNCH("tsasr_conv3x3s2_wgrad");
     return 0;

@@ -107,13 +107,16 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float *__restrict__ p, 
     }
 }
 
-// dst[i][0..n[i]) += src[i][0..n[i])  for `count` small fp32 vectors: one workgroup per vector
+// dst[i][0..n[i]) += src[i][0..n[i])  for `count` fp32 vectors: ACC_SPLIT workgroups per vector, interleaved 256-element pieces (most vectors are
+// biases and LayerNorm rows, a few are filter gradients of 10^5 elements: walked by ONE workgroup they were 576 dependent read-modify-write rounds
+// at the very end of the step)
+#define ACC_SPLIT 16
 __global__ __launch_bounds__(256) void accumulate_many_kernel(const float *const *__restrict__ src, float *const *__restrict__ dst,
                                                               const int *__restrict__ n) {
     const float *s = src[blockIdx.x];
     float *d = dst[blockIdx.x];
     const int len = n[blockIdx.x];
-    for (int i = threadIdx.x; i < len; i += 256) d[i] += s[i];
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < len; i += 256 * ACC_SPLIT) d[i] += s[i];
 }
 
 // dst_j[c][r] = src_j[r][c] for a list of 2-D bf16 matrices, one launch: transposed copies of the GEMM weights, refreshed after
@@ -188,7 +191,7 @@ int tsasr_accumulate_many(const void *table, int count, void *stream) {
     const float *const *src = (const float *const *)table;
     float *const *dst = (float *const *)((const char *)table + (size_t)count * sizeof(void *));
     const int *n = (const int *)((const char *)table + (size_t)2 * count * sizeof(void *));
-    accumulate_many_kernel<<<count, 256, 0, (hipStream_t)stream>>>(src, dst, n);
+    accumulate_many_kernel<<<dim3(count, ACC_SPLIT), 256, 0, (hipStream_t)stream>>>(src, dst, n);
     TSASR_CHECK_LAUNCH("tsasr_accumulate_many");
     return 0;
 }

@@ -1753,8 +1753,11 @@ class _FrontendConvFn(torch.autograd.Function):
         Co = w1.shape[0]
         To, Fo = _out_len(T), _out_len(Fq)
         P = B * To * Fo
-        wm = w1.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype).contiguous()   # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]
-        w2m = w2.reshape(Co, Ci).to(xc.dtype).contiguous()
+        # [Co, (kt, kf, ci)] from the reference's [Co, ci, kF, kT]; in bf16 from the arena's bf16 shadow of the parameters (one permuting copy
+        # instead of a permuting copy + two casts, at the head of each branch's forward)
+        w1s, w2s = (_bf16_weight(w1), _bf16_weight(w2)) if xc.dtype == torch.bfloat16 else (w1, w2)
+        wm = w1s.permute(0, 3, 2, 1).reshape(Co, 9 * Ci).to(xc.dtype).contiguous()
+        w2m = w2s.reshape(Co, Ci).to(xc.dtype).contiguous()
         centre = 7 if causal else 4                                      # the tap that reads x[2t', 2f']
         hip = xc.dtype == torch.bfloat16 and Ci % 8 == 0 and Co % 8 == 0
         implicit = hip and CONV_IMPLICIT and Co == 128 and Ci in (64, 128)
@@ -1766,7 +1769,7 @@ class _FrontendConvFn(torch.autograd.Function):
                                                     C.ptr(y1), C.ptr(y2), B, T, Fq, Ci, Co, int(causal), C.stream_ptr()), "tsasr_conv3x3s2_fwd")
             ctx.save_for_backward(xc, wm, w2m)
             ctx.cfg = (bool(causal), (B, T, Fq, Ci), Co, centre, w1.dtype, b1.dtype, w2.dtype, b2.dtype, w2.shape, hip)
-            ctx.biases, ctx.implicit = (b1, b2), True
+            ctx.biases, ctx.weights, ctx.implicit = (b1, b2), (w1, w2), True
             return y1, y2
         A = torch.empty(P, 9 * Ci, dtype=xc.dtype, device=xc.device)
         with prof.region("frontend_im2col"):
@@ -1798,12 +1801,14 @@ class _FrontendConvFn(torch.autograd.Function):
         g1, g2 = dy1.reshape(P, Co).contiguous(), dy2.reshape(P, Co).contiguous()
         if ctx.implicit:    # A is x itself: the filter gradients gather their patch rows in the loader waves; the data gradient is dA + col2im
             xc = A
-            dwm = torch.empty(Co, 9 * Ci, dtype=torch.float32, device=xc.device)
+            # the 3x3 gradient comes out in the parameter's own layout [Co, ci, kF, kT]: both filter gradients join the arena's batched add
+            # (they were a permuting ATen add + a plain one per branch, the speaker branch's at the very end of backward)
+            dwm = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device=xc.device)
             dw2f = torch.empty(Co, Ci, dtype=torch.float32, device=xc.device)
             ws = _ws(C.lib().tsasr_conv3x3s2_wgrad_workspace_bytes(B, T, Fq, Ci), xc.device)
             with prof.region("conv3x3s2_wgrad", 2.0 * P * Co * 10 * Ci):
-                C.check(C.lib().tsasr_conv3x3s2_wgrad(C.ptr(g1), C.ptr(g2), C.ptr(xc), C.ptr(dwm), C.ptr(dw2f), B, T, Fq, Ci, Co, int(causal),
-                                                      C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_conv3x3s2_wgrad")
+                C.check(C.lib().tsasr_conv3x3s2_wgrad_filters(C.ptr(g1), C.ptr(g2), C.ptr(xc), C.ptr(dwm), C.ptr(dw2f), B, T, Fq, Ci, Co, int(causal),
+                                                              C.ptr(ws), ws.numel(), C.stream_ptr()), "tsasr_conv3x3s2_wgrad_filters")
             db1, db2 = _pgrad(ctx.biases[0], colsum(g1)), _pgrad(ctx.biases[1], colsum(g2))
             dx = torch.empty(B, T, Fq, Ci, dtype=xc.dtype, device=xc.device)
             plan = _conv_dgrad_plan(B, T, Fq, causal, xc.device) if CONV_DGRAD_IMPLICIT else None
@@ -1817,7 +1822,7 @@ class _FrontendConvFn(torch.autograd.Function):
                 with prof.region("frontend_col2im"):
                     C.check(C.lib().tsasr_frontend_col2im(C.ptr(dA), C.ptr(dR), C.ptr(dx), B, T, Fq, Ci, int(causal), C.io_dtype(xc), C.stream_ptr()),
                             "tsasr_frontend_col2im")
-            return dx, _pgrad_view(dwm, Co, Ci, dw1t), db1, _pgrad_view2(dw2f, w2shape, dw2t), db2, None
+            return dx, _pgrad(ctx.weights[0], dwm.to(dw1t)), db1, _pgrad(ctx.weights[1], dw2f.to(dw2t)), db2, None
         if hip:
             dwm = gemm_bf16(g1, A, Co, 9 * Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32)              # g1^T . A
             dw2 = gemm_bf16(g2, A[:, centre * Ci:], Co, Ci, P, Co, 9 * Ci, 1, 1, out_dtype=torch.float32).view(w2shape).to(dw2t)

@@ -122,6 +122,8 @@ class TSASR(core.Brain):
         batch = batch.to(self.device)
         mixed, mixed_lens = batch.mixed_sig
         tokens_bos, tokens_bos_lens = batch.tokens_bos
+        tok = batch.tokens.data      # the loss's targets as the lattice kernels read them (int32): cast here, off the loss's own chain
+        self._tokens32 = (tok, tok if tok.dtype == torch.int32 else tok.to(torch.int32).contiguous())
         # Two parts of the forward do not depend on the mixture encoder: the speaker branch (6 encoder layers over the enrollment,
         # half-filled grids; needed at the injection point) and the predictor (embedding -> LSTM -> projection; its persistent
         # recurrence kernels occupy 32 of 256 CUs for 0.4 + 0.7 ms; needed at the joint). Both run on a second HIP stream; the
@@ -219,6 +221,9 @@ class TSASR(core.Brain):
         logits, hyps = predictions
         _, mixed_lens = batch.mixed_sig
         tokens, tokens_lens = batch.tokens
+        t32 = getattr(self, "_tokens32", None)
+        if t32 is not None and t32[0].data_ptr() == tokens.data_ptr() and t32[0].shape == tokens.shape:
+            tokens = t32[1]
         loss = self.hparams.transducer_loss(logits, tokens, mixed_lens, tokens_lens)
         prof.stamp("loss forward done [main]")
         if hyps is not None:
