@@ -33,6 +33,10 @@ WORKLOADS = {
     "longform": dict(yaml="conformer-t_scratch_mi355x.yaml", B=1, T=16000, Te=500, U=1920, emb=0,
                      overrides=dict(causal_encoder=True, frontend_padding="causal"),
                      name="BASELINE.json configs[4]: causal conformer-t (causal encoder + causal front-end padding, as the reference's --causal_encoder True --frontend_padding causal), B=1/GPU, mel [1,16000,80] -> T'=4000, tokens [1,1920], enrollment mel [1,500,80], dropout 0.1"),
+    "inject_sum": dict(yaml="conformer-t_scratch_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides=dict(injection_mode="sum"), emb=0,
+                       name="configs[1] with injection_mode: sum (the reference's other mean-pooled injection; pricing run, not the headline)"),
+    "inject_xattn": dict(yaml="conformer-t_scratch_mi355x.yaml", B=32, T=1000, Te=500, U=120, overrides=dict(injection_mode="cross_attention"), emb=0,
+                         name="configs[1] with injection_mode: cross_attention (the speaker encoder's frames as keys / values of one attention layer in front of the encoder; pricing run, not the headline)"),
     "longform_chunk40": dict(yaml="conformer-t_scratch_mi355x.yaml", B=1, T=16000, Te=500, U=1920, emb=0,
                              overrides=dict(causal_encoder=True, frontend_padding="causal", attention_chunk_size=40),
                              name="BASELINE.json configs[4] with the BUILD EXTENSION chunk=40 (block-causal attention: a frame sees its whole 40-frame chunk and everything before it; the reference has no chunked attention), B=1/GPU, mel [1,16000,80] -> T'=4000, tokens [1,1920]"),
